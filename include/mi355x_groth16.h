@@ -1,0 +1,198 @@
+/* mi355x_groth16.h — C-ABI of the MI355X-native Groth16 prove path (BN254).
+ *
+ * Drop-in boundary for the one hot path of reilabs/gnark-whir: everything that happens inside
+ *     proof, _ := groth16.Prove(ccs, pk, witness, backend.WithSolverOptions(...))
+ * at /root/reference/mt.go:496 *after* gnark's R1CS solver has produced the wire vector W
+ * and the per-constraint vectors a, b, c — i.e. computeH (7 NTTs), the scalar filters, four
+ * G1 MSMs, one G2 MSM and proof assembly (SURVEY.md section 3.3 steps 4-8, section 8a rows
+ * a3-a9).  The reference has no FFI of its own; the seam a maintainer binds is gnark's
+ * accelerator seam (backend/groth16/bn254/icicle in gnark v0.11.0, go.mod:6), whose shape
+ * (device-resident proving key + one Prove call) these entry points mirror.  The cgo
+ * binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns an int32 status (MI_OK == 0, negative on error); no C++
+ *     exception crosses the ABI; mi_last_error() gives a message for the last failure.
+ *   - mi_fr / mi_fp are 4 x uint64 little-endian limbs in Montgomery form (R = 2^256), the
+ *     in-memory layout of gnark-crypto's fr.Element / fp.Element.  The limb order is the one
+ *     /root/reference/typeConverters/typeConverters.go:30-39 spells out (that file's values
+ *     are canonical, not Montgomery).  Go passes unsafe.Pointer(&slice[0]) with zero copies.
+ *   - affine infinity is (0,0); Jacobian infinity has Z == 0 (gnark-crypto's encoding).
+ *   - functions without suffix take HOST pointers and copy over PCIe; "_dev" variants take
+ *     DEVICE pointers (hipMalloc'ed, 32-byte aligned) and never touch host memory.
+ *   - the caller owns every buffer; the library keeps no caller pointer after return
+ *     (cgo rule).  mi_ctx / mi_pk are opaque library-owned handles.
+ *   - one mi_ctx drives one GPU.  Calls on one ctx are serialised on its HIP stream.
+ */
+#ifndef MI355X_GROTH16_H
+#define MI355X_GROTH16_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ---- */
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument: size not a power of two, log_n > 28, null pointer */
+#define MI_EHIP (-2)     /* a HIP runtime call failed; see mi_last_error */
+#define MI_ENOMEM (-3)   /* device or host allocation failed */
+#define MI_ENODEV (-4)   /* no usable gfx950 device / code object missing */
+
+/* ---- value types (layout == gnark-crypto structs) ---- */
+typedef struct { uint64_t l[4]; } mi_fr;              /* fr.Element, replaces ecc/bn254/fr */
+typedef struct { uint64_t l[4]; } mi_fp;              /* fp.Element */
+typedef struct { mi_fp a0, a1; } mi_fp2;              /* fptower.E2: a0 + a1*u, u^2 = -1 */
+typedef struct { mi_fp x, y; } mi_g1_affine;          /* bn254.G1Affine, 64 B */
+typedef struct { mi_fp x, y, z; } mi_g1_jac;          /* bn254.G1Jac, 96 B */
+typedef struct { mi_fp2 x, y; } mi_g2_affine;         /* bn254.G2Affine, 128 B */
+typedef struct { mi_fp2 x, y, z; } mi_g2_jac;         /* bn254.G2Jac, 192 B */
+
+typedef struct mi_ctx mi_ctx;
+typedef struct mi_pk mi_pk;
+
+/* ---- NTT flags: mirror fft.Domain.FFT / FFTInverse options (gnark-crypto fr/fft) ---- */
+#define MI_NTT_INVERSE 1u   /* FFTInverse: uses GeneratorInv and scales by CardinalityInv */
+#define MI_NTT_COSET 2u     /* fft.OnCoset(): shift by FrMultiplicativeGen = 5 */
+#define MI_NTT_DIT 4u       /* fft.DIT: bit-reversed in, natural out. Default fft.DIF:
+                               natural in, bit-reversed out */
+
+/* ---- MSM flags ---- */
+#define MI_MSM_SCALARS_CANONICAL 1u /* scalars are plain integers < r (default: Montgomery) */
+
+/* Proving key as gnark keeps it in memory (groth16/bn254 ProvingKey, built by groth16.Setup at
+ * mt.go:448).  All arrays are read during mi_pk_load only. */
+typedef struct mi_pk_desc {
+    uint32_t log_n;                 /* pk.Domain.Cardinality = 2^log_n, log_n <= 28          */
+    uint32_t nb_public;             /* r1cs.GetNbPublicVariables(), includes the ONE wire     */
+    uint64_t nb_wires;              /* len(solution.W)                                        */
+    const mi_g1_affine *g1_a;  uint64_t n_g1_a;   /* pk.G1.A, points at infinity filtered out */
+    const mi_g1_affine *g1_b;  uint64_t n_g1_b;   /* pk.G1.B, idem                            */
+    const mi_g1_affine *g1_k;  uint64_t n_g1_k;   /* pk.G1.K, private non-committed wires     */
+    const mi_g1_affine *g1_z;  uint64_t n_g1_z;   /* pk.G1.Z, >= 2^log_n - 1 points, in the
+                                                     bit-reversed order Setup leaves them in  */
+    const mi_g2_affine *g2_b;  uint64_t n_g2_b;   /* pk.G2.B                                  */
+    mi_g1_affine alpha1, beta1, delta1;           /* pk.G1.Alpha / Beta / Delta               */
+    mi_g2_affine beta2, delta2;                   /* pk.G2.Beta / Delta                       */
+    const uint8_t *infinity_a;      /* pk.InfinityA, nb_wires Go bools (1 byte each)          */
+    const uint8_t *infinity_b;      /* pk.InfinityB                                           */
+    const uint32_t *committed_wires;/* wires removed from the K MSM (BSB22 private committed +
+                                       commitment wires), ascending; may be NULL              */
+    uint64_t n_committed;
+} mi_pk_desc;
+
+/* groth16 Proof{Ar, Bs, Krs} exactly as gnark's struct holds it (affine, Montgomery). */
+typedef struct mi_proof_out {
+    mi_g1_affine ar;
+    mi_g2_affine bs;
+    mi_g1_affine krs;
+} mi_proof_out;
+
+/* Per-phase device times in milliseconds, measured with HIP events on the ctx stream. */
+typedef struct mi_stats {
+    float h2d_ms, compute_h_ms, filter_ms;
+    float msm_a_ms, msm_b1_ms, msm_k_ms, msm_z_ms, msm_b2_ms;
+    float assemble_ms, total_ms;
+    /* dominant-kernel accounting for the roofline line (last prove / msm call) */
+    float g1_accum_kernel_ms;       /* summed duration of the G1 bucket-accumulate launches   */
+    uint64_t g1_accum_pairs;        /* (point, scalar) pairs those launches consumed          */
+    uint32_t g1_accum_launches;
+    float ntt_kernel_ms;            /* summed duration of NTT pass launches                   */
+    uint64_t ntt_elems;             /* elements transformed (N per size-N transform)          */
+    uint32_t ntt_launches;
+} mi_stats;
+
+/* ---- lifecycle ---- */
+int32_t mi_init(int device_id, mi_ctx **out);             /* replaces icicle device init      */
+int32_t mi_shutdown(mi_ctx *ctx);
+const char *mi_last_error(mi_ctx *ctx);                   /* never NULL                       */
+/* Use the caller's HIP stream (a hipStream_t passed as void*) for all later work of ctx. */
+int32_t mi_set_stream(mi_ctx *ctx, void *hip_stream);
+
+/* ---- proving key: upload once, device-resident across proofs ---- */
+int32_t mi_pk_load(mi_ctx *ctx, const mi_pk_desc *desc, mi_pk **out);      /* host arrays     */
+int32_t mi_pk_load_dev(mi_ctx *ctx, const mi_pk_desc *desc, mi_pk **out);  /* point arrays are
+        device pointers that the pk ADOPTS BY REFERENCE (caller keeps them alive); masks and
+        committed_wires stay host pointers                                                    */
+int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk);
+
+/* ---- fft.Domain.FFT / FFTInverse over Fr, in place, n = 2^log_n (row a3/a4) ---- */
+int32_t mi_ntt(mi_ctx *ctx, mi_fr *inout, uint32_t log_n, uint32_t flags);
+int32_t mi_ntt_dev(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t flags);
+
+/* ---- computeH (gnark prove.go): a, b, c have n_constraints entries, zero-padded to 2^log_n;
+ * h_out receives 2^log_n elements in the bit-reversed order gnark leaves them in ---- */
+int32_t mi_compute_h(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                     size_t n_constraints, mi_fr *h_out);
+int32_t mi_compute_h_dev(mi_ctx *ctx, uint32_t log_n, const mi_fr *a_dev, const mi_fr *b_dev,
+                         const mi_fr *c_dev, size_t n_constraints, mi_fr *h_out_dev);
+
+/* ---- G1Jac.MultiExp / G2Jac.MultiExp (rows a5, a6, a8).  out is a HOST pointer in both
+ * variants; the result is normalised (Z = 1, or X = Y = 1, Z = 0 for infinity). ---- */
+int32_t mi_msm_g1(mi_ctx *ctx, const mi_g1_affine *pts, const mi_fr *scalars, size_t n,
+                  uint32_t flags, mi_g1_jac *out);
+int32_t mi_msm_g1_dev(mi_ctx *ctx, const mi_g1_affine *pts_dev, const mi_fr *scalars_dev, size_t n,
+                      uint32_t flags, mi_g1_jac *out);
+int32_t mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *pts, const mi_fr *scalars, size_t n,
+                  uint32_t flags, mi_g2_jac *out);
+int32_t mi_msm_g2_dev(mi_ctx *ctx, const mi_g2_affine *pts_dev, const mi_fr *scalars_dev, size_t n,
+                      uint32_t flags, mi_g2_jac *out);
+
+/* ---- the fused prove path: replaces groth16.Prove after the solve (mt.go:496).
+ * W: nb_wires wire values; a, b, c: n_constraints values each (solution.A/B/C);
+ * r, s: the two blinding scalars gnark samples with fr.SetRandom (passed in so that CPU and
+ * GPU proofs of the same (pk, witness, r, s) are byte-identical — SURVEY section 7 H1).
+ * stats may be NULL. ---- */
+int32_t mi_groth16_prove(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires,
+                         const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
+                         const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats);
+int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, size_t n_wires,
+                             const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev,
+                             size_t n_constraints, const mi_fr *r, const mi_fr *s,
+                             mi_proof_out *out, mi_stats *stats);
+/* Stats of the last mi_msm_* / mi_ntt* / mi_compute_h* / prove call on ctx. */
+int32_t mi_get_stats(mi_ctx *ctx, mi_stats *out);
+
+/* ---- Proof.WriteTo / point encoding (row a12), pure host code ---- */
+void mi_g1_compress(const mi_g1_affine *p, uint8_t out[32]);
+void mi_g2_compress(const mi_g2_affine *p, uint8_t out[64]);
+/* Ar | Bs | Krs | u32-BE n_commitments | commitments | commitment_pok ; returns bytes written
+ * (164 + 32*n_commitments).  commitment_pok may be NULL (encoded as infinity). */
+size_t mi_proof_write(const mi_proof_out *proof, const mi_g1_affine *commitments,
+                      uint32_t n_commitments, const mi_g1_affine *commitment_pok, uint8_t *out);
+
+/* ---- partial-sum combine for the point-sharded MSM (SURVEY section 8e option i): adds n
+ * Jacobian partial results (e.g. all-gathered from the ranks), host side ---- */
+int32_t mi_g1_sum(const mi_g1_jac *parts, size_t n, mi_g1_jac *out);
+int32_t mi_g2_sum(const mi_g2_jac *parts, size_t n, mi_g2_jac *out);
+
+/* ---- device-side test / bench utilities (not part of the reference surface) ---- */
+#define MI_DIST_UNIFORM 0
+#define MI_DIST_WHIR 1      /* 45% {0,1}, 25% bytes, 5% 64-bit, 25% uniform */
+int32_t mi_gen_scalars_dev(mi_ctx *ctx, mi_fr *out_dev, size_t n, uint64_t seed, int dist);
+int32_t mi_gen_g1_dev(mi_ctx *ctx, mi_g1_affine *out_dev, size_t n, uint64_t seed);
+int32_t mi_gen_g2_dev(mi_ctx *ctx, mi_g2_affine *out_dev, size_t n, uint64_t seed);
+/* elementwise field ops for parity tests of the device field layer:
+ * field: 0 = Fr, 1 = Fp; op: 0 add, 1 sub, 2 mul, 3 inv(x), 4 to_mont(x), 5 from_mont(x) */
+int32_t mi_field_op_dev(mi_ctx *ctx, int field, int op, void *z_dev, const void *x_dev,
+                        const void *y_dev, size_t n);
+/* out[i] = a[i] + b[i] on G1 (affine in, affine out; exercises add/double/inf cases) */
+int32_t mi_g1_add_dev(mi_ctx *ctx, mi_g1_affine *out_dev, const mi_g1_affine *a_dev,
+                      const mi_g1_affine *b_dev, size_t n);
+int32_t mi_g2_add_dev(mi_ctx *ctx, mi_g2_affine *out_dev, const mi_g2_affine *a_dev,
+                      const mi_g2_affine *b_dev, size_t n);
+/* modular-multiply throughput probe: chains `iters` dependent Fp products per thread */
+int32_t mi_bench_modmul_dev(mi_ctx *ctx, int field, size_t n_threads, uint32_t iters,
+                            void *scratch_dev, float *ms_out);
+/* raw device memory helpers so hosts without a HIP binding (ctypes, cgo) can stage data */
+int32_t mi_dev_alloc(mi_ctx *ctx, size_t bytes, void **out_dev);
+int32_t mi_dev_free(mi_ctx *ctx, void *dev);
+int32_t mi_dev_upload(mi_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int32_t mi_dev_download(mi_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int32_t mi_dev_sync(mi_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
