@@ -1,0 +1,277 @@
+"""ctypes binding of libmi355x_groth16.so (the C-ABI of include/mi355x_groth16.h).
+
+This is plumbing for tests/ and bench.py: it mirrors the C entry points one to one and adds no
+compute.  There is NO fallback: if the HIP library is missing or no gfx950 device is present,
+load()/Context() raise.  numpy layouts: Fr/Fp (n,4) uint64; G1 affine (n,8); G1 jac (12,);
+G2 affine (n,16); G2 jac (24,), all Montgomery little-endian limbs.
+"""
+from __future__ import annotations
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355x_groth16.so")
+_LIB = None
+
+EXPORTS = [
+    "mi_init", "mi_shutdown", "mi_last_error", "mi_set_stream", "mi_pk_load", "mi_pk_load_dev", "mi_pk_free",
+    "mi_ntt", "mi_ntt_dev", "mi_compute_h", "mi_compute_h_dev", "mi_msm_g1", "mi_msm_g1_dev", "mi_msm_g2",
+    "mi_msm_g2_dev", "mi_groth16_prove", "mi_groth16_prove_dev", "mi_get_stats", "mi_g1_compress",
+    "mi_g2_compress", "mi_proof_write", "mi_g1_sum", "mi_g2_sum", "mi_gen_scalars_dev", "mi_gen_g1_dev",
+    "mi_gen_g2_dev", "mi_field_op_dev", "mi_g1_add_dev", "mi_g2_add_dev", "mi_bench_modmul_dev", "mi_bench_valu_dev",
+    "mi_dev_alloc", "mi_dev_free", "mi_dev_upload", "mi_dev_download", "mi_dev_sync",
+]
+
+
+class PkDesc(C.Structure):
+    _fields_ = [
+        ("log_n", C.c_uint32), ("nb_public", C.c_uint32), ("nb_wires", C.c_uint64),
+        ("g1_a", C.c_void_p), ("n_g1_a", C.c_uint64), ("g1_b", C.c_void_p), ("n_g1_b", C.c_uint64),
+        ("g1_k", C.c_void_p), ("n_g1_k", C.c_uint64), ("g1_z", C.c_void_p), ("n_g1_z", C.c_uint64),
+        ("g2_b", C.c_void_p), ("n_g2_b", C.c_uint64),
+        ("alpha1", C.c_uint64 * 8), ("beta1", C.c_uint64 * 8), ("delta1", C.c_uint64 * 8),
+        ("beta2", C.c_uint64 * 16), ("delta2", C.c_uint64 * 16),
+        ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p),
+        ("committed_wires", C.c_void_p), ("n_committed", C.c_uint64),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("h2d_ms", "compute_h_ms", "filter_ms", "msm_a_ms", "msm_b1_ms", "msm_k_ms",
+                                         "msm_z_ms", "msm_b2_ms", "assemble_ms", "total_ms")] + [
+        ("g1_accum_kernel_ms", C.c_float), ("g1_accum_pairs", C.c_uint64), ("g1_accum_launches", C.c_uint32),
+        ("ntt_kernel_ms", C.c_float), ("ntt_elems", C.c_uint64), ("ntt_launches", C.c_uint32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class MiError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library; raises if it has not been built (no CPU fallback exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise MiError(f"{LIB_PATH} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _LIB = C.CDLL(LIB_PATH)
+        _LIB.mi_last_error.restype = C.c_char_p
+        _LIB.mi_proof_write.restype = C.c_size_t
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))  # raw device pointer
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+class DevArray:
+    """A hipMalloc'ed buffer owned through the C-ABI (mi_dev_alloc)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        ptr = C.c_void_p()
+        ctx._ck(ctx.lib.mi_dev_alloc(ctx.h, C.c_size_t(self.nbytes), C.byref(ptr)))
+        self.ptr = ptr.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._ck(self.ctx.lib.mi_dev_upload(self.ctx.h, C.c_void_p(self.ptr), _p(arr), C.c_size_t(arr.nbytes)))
+        return self
+
+    def download(self, shape, dtype=np.uint64):
+        out = np.zeros(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._ck(self.ctx.lib.mi_dev_download(self.ctx.h, _p(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.mi_dev_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = None
+
+
+class Context:
+    def __init__(self, device_id=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.mi_init(C.c_int(device_id), C.byref(h))
+        if rc != 0:
+            raise MiError(f"mi_init failed: {rc} (no gfx950 device? the product has no CPU path)")
+        self.h = h
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MiError(f"rc={rc}: {self.lib.mi_last_error(self.h).decode()}")
+
+    def close(self):
+        if self.h:
+            self.lib.mi_shutdown(self.h)
+            self.h = None
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.mi_set_stream(self.h, C.c_void_p(int(stream_ptr))))
+
+    def sync(self):
+        self._ck(self.lib.mi_dev_sync(self.h))
+
+    def alloc(self, nbytes):
+        return DevArray(self, nbytes)
+
+    def to_dev(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DevArray(self, max(arr.nbytes, 32)).upload(arr)
+
+    # ---- utilities
+    def gen_scalars(self, n, seed, dist):
+        d = self.alloc(32 * n); self._ck(self.lib.mi_gen_scalars_dev(self.h, _p(d.ptr), C.c_size_t(n), C.c_uint64(seed), C.c_int(dist))); return d
+
+    def gen_g1(self, n, seed):
+        d = self.alloc(64 * n); self._ck(self.lib.mi_gen_g1_dev(self.h, _p(d.ptr), C.c_size_t(n), C.c_uint64(seed))); return d
+
+    def gen_g2(self, n, seed):
+        d = self.alloc(128 * n); self._ck(self.lib.mi_gen_g2_dev(self.h, _p(d.ptr), C.c_size_t(n), C.c_uint64(seed))); return d
+
+    def field_op(self, field, op, x, y=None):
+        x = _u64(x); n = x.shape[0]
+        dx = self.to_dev(x); dy = self.to_dev(_u64(y)) if y is not None else None; dz = self.alloc(32 * n)
+        self._ck(self.lib.mi_field_op_dev(self.h, field, op, _p(dz.ptr), _p(dx.ptr), _p(dy.ptr if dy else None), C.c_size_t(n)))
+        out = dz.download((n, 4))
+        for b in (dx, dy, dz):
+            if b: b.free()
+        return out
+
+    def ec_add(self, a, b, g2=False):
+        a, b = _u64(a), _u64(b); n = a.shape[0]
+        da, db = self.to_dev(a), self.to_dev(b); do = self.alloc(a.nbytes)
+        f = self.lib.mi_g2_add_dev if g2 else self.lib.mi_g1_add_dev
+        self._ck(f(self.h, _p(do.ptr), _p(da.ptr), _p(db.ptr), C.c_size_t(n)))
+        out = do.download(a.shape)
+        for x in (da, db, do): x.free()
+        return out
+
+    def bench_modmul(self, field, n_threads, iters):
+        s = self.alloc(1024 * 32); ms = C.c_float()
+        self._ck(self.lib.mi_bench_modmul_dev(self.h, field, C.c_size_t(n_threads), C.c_uint32(iters), _p(s.ptr), C.byref(ms)))
+        s.free(); return ms.value
+
+    def bench_valu(self, kind, n_threads, iters):
+        s = self.alloc(1024); ms = C.c_float()
+        self._ck(self.lib.mi_bench_valu_dev(self.h, kind, C.c_size_t(n_threads), C.c_uint32(iters), _p(s.ptr), C.byref(ms)))
+        s.free(); return ms.value
+
+    # ---- NTT / computeH
+    def ntt(self, a, log_n, flags):
+        a = _u64(a).copy(); self._ck(self.lib.mi_ntt(self.h, _p(a), C.c_uint32(log_n), C.c_uint32(flags))); return a
+
+    def ntt_dev(self, dptr, log_n, flags):
+        self._ck(self.lib.mi_ntt_dev(self.h, _p(dptr), C.c_uint32(log_n), C.c_uint32(flags)))
+
+    def compute_h(self, log_n, a, b, c):
+        h = np.zeros((1 << log_n, 4), np.uint64)
+        a, b, c = _u64(a), _u64(b), _u64(c)
+        self._ck(self.lib.mi_compute_h(self.h, C.c_uint32(log_n), _p(a), _p(b), _p(c), C.c_size_t(a.shape[0]), _p(h)))
+        return h
+
+    def compute_h_dev(self, log_n, a, b, c, n_constraints, h):
+        self._ck(self.lib.mi_compute_h_dev(self.h, C.c_uint32(log_n), _p(a), _p(b), _p(c), C.c_size_t(n_constraints), _p(h)))
+
+    # ---- MSM
+    def msm_g1(self, pts, sc, flags=0):
+        out = np.zeros(12, np.uint64); pts, sc = _u64(pts), _u64(sc)
+        self._ck(self.lib.mi_msm_g1(self.h, _p(pts), _p(sc), C.c_size_t(pts.shape[0]), C.c_uint32(flags), _p(out))); return out
+
+    def msm_g2(self, pts, sc, flags=0):
+        out = np.zeros(24, np.uint64); pts, sc = _u64(pts), _u64(sc)
+        self._ck(self.lib.mi_msm_g2(self.h, _p(pts), _p(sc), C.c_size_t(pts.shape[0]), C.c_uint32(flags), _p(out))); return out
+
+    def msm_g1_dev(self, pts_ptr, sc_ptr, n, flags=0):
+        out = np.zeros(12, np.uint64)
+        self._ck(self.lib.mi_msm_g1_dev(self.h, _p(pts_ptr), _p(sc_ptr), C.c_size_t(n), C.c_uint32(flags), _p(out))); return out
+
+    def msm_g2_dev(self, pts_ptr, sc_ptr, n, flags=0):
+        out = np.zeros(24, np.uint64)
+        self._ck(self.lib.mi_msm_g2_dev(self.h, _p(pts_ptr), _p(sc_ptr), C.c_size_t(n), C.c_uint32(flags), _p(out))); return out
+
+    # ---- proving key + prove
+    def pk_load(self, pk: dict, device_points=False):
+        """pk arrays: numpy (host) or raw device pointers with explicit counts when device_points."""
+        d = PkDesc(); keep = []
+        d.log_n, d.nb_public, d.nb_wires = pk["log_n"], pk["nb_public"], pk["nb_wires"]
+        for name in ("g1_a", "g1_b", "g1_k", "g1_z", "g2_b"):
+            if device_points:
+                ptr, cnt = pk[name]
+                setattr(d, name, int(ptr)); setattr(d, "n_" + name, int(cnt))
+            else:
+                arr = _u64(pk[name]); keep.append(arr)
+                setattr(d, name, arr.ctypes.data); setattr(d, "n_" + name, arr.shape[0])
+        for name, k in (("alpha1", 8), ("beta1", 8), ("delta1", 8), ("beta2", 16), ("delta2", 16)):
+            setattr(d, name, (C.c_uint64 * k)(*[int(v) for v in _u64(pk[name]).reshape(-1)]))
+        ia = np.ascontiguousarray(pk["infinity_a"], dtype=np.uint8); ib = np.ascontiguousarray(pk["infinity_b"], dtype=np.uint8)
+        keep += [ia, ib]
+        d.infinity_a, d.infinity_b = ia.ctypes.data, ib.ctypes.data
+        cw = pk.get("committed_wires")
+        if cw is not None and len(cw):
+            cw = np.ascontiguousarray(cw, dtype=np.uint32); keep.append(cw)
+            d.committed_wires, d.n_committed = cw.ctypes.data, cw.shape[0]
+        h = C.c_void_p()
+        f = self.lib.mi_pk_load_dev if device_points else self.lib.mi_pk_load
+        self._ck(f(self.h, C.byref(d), C.byref(h)))
+        return h
+
+    def pk_free(self, pkh):
+        self._ck(self.lib.mi_pk_free(self.h, pkh))
+
+    def prove(self, pkh, W, a, b, c, r, s, device=False, n_wires=None, n_constraints=None):
+        out = np.zeros(32, np.uint64); st = Stats()
+        r, s = _u64(r), _u64(s)
+        if device:
+            self._ck(self.lib.mi_groth16_prove_dev(self.h, pkh, _p(W), C.c_size_t(n_wires), _p(a), _p(b), _p(c),
+                                                   C.c_size_t(n_constraints), _p(r), _p(s), _p(out), C.byref(st)))
+        else:
+            W, a, b, c = _u64(W), _u64(a), _u64(b), _u64(c)
+            self._ck(self.lib.mi_groth16_prove(self.h, pkh, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c),
+                                               C.c_size_t(a.shape[0]), _p(r), _p(s), _p(out), C.byref(st)))
+        return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
+
+    def stats(self):
+        st = Stats(); self._ck(self.lib.mi_get_stats(self.h, C.byref(st))); return st.as_dict()
+
+
+# ---- host-only helpers (no ctx)
+def proof_write(raw, commitments=None, pok=None):
+    n = 0 if commitments is None else commitments.shape[0]
+    buf = np.zeros(164 + 32 * n, np.uint8)
+    ln = load().mi_proof_write(_p(_u64(raw)), _p(commitments), C.c_uint32(n), _p(pok), _p(buf))
+    return bytes(buf[:ln])
+
+
+def g1_compress(p):
+    buf = np.zeros(32, np.uint8); load().mi_g1_compress(_p(_u64(p)), _p(buf)); return bytes(buf)
+
+
+def g2_compress(p):
+    buf = np.zeros(64, np.uint8); load().mi_g2_compress(_p(_u64(p)), _p(buf)); return bytes(buf)
+
+
+def g1_sum(parts):
+    parts = _u64(parts); out = np.zeros(12, np.uint64)
+    assert load().mi_g1_sum(_p(parts), C.c_size_t(parts.shape[0]), _p(out)) == 0
+    return out
+
+
+def g2_sum(parts):
+    parts = _u64(parts); out = np.zeros(24, np.uint64)
+    assert load().mi_g2_sum(_p(parts), C.c_size_t(parts.shape[0]), _p(out)) == 0
+    return out

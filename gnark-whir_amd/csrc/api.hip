@@ -1,0 +1,160 @@
+// Lifecycle, device-memory helpers and the host-only pieces of the C-ABI (point encoding,
+// partial-sum combine).  See include/mi355x_groth16.h for the contract of each entry point.
+#include "ctx.h"
+#include "curve.cuh"
+#include <cstring>
+
+extern "C" {
+
+int32_t mi_init(int device_id, mi_ctx **out) {
+    if (!out) return MI_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return MI_ENODEV;
+    if (hipSetDevice(device_id) != hipSuccess) return MI_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return MI_ENODEV;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MI_ENODEV;  // gfx950-only code object
+    mi_ctx *ctx = new (std::nothrow) mi_ctx();
+    if (!ctx) return MI_ENOMEM;
+    ctx->dev = device_id;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return MI_EHIP; }
+    ctx->own_stream = true;
+    mi_ntt_state_init(ctx);
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return MI_EHIP; }
+    *out = ctx;
+    return MI_OK;
+}
+int32_t mi_shutdown(mi_ctx *ctx) {
+    if (!ctx) return MI_EINVAL;
+    hipSetDevice(ctx->dev);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->ws) if (b.p) hipFree(b.p);
+    mi_ntt_state_free(ctx);
+    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MI_OK;
+}
+const char *mi_last_error(mi_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+int32_t mi_set_stream(mi_ctx *ctx, void *hip_stream) {
+    if (!ctx) return MI_EINVAL;
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return MI_OK;
+}
+int32_t mi_get_stats(mi_ctx *ctx, mi_stats *out) {
+    if (!ctx || !out) return MI_EINVAL;
+    *out = ctx->stats;
+    return MI_OK;
+}
+int32_t mi_dev_alloc(mi_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return MI_EINVAL;
+    MI_CHECK_HIP(ctx, hipSetDevice(ctx->dev));
+    MI_CHECK_HIP(ctx, hipMalloc(out, bytes ? bytes : 32));
+    return MI_OK;
+}
+int32_t mi_dev_free(mi_ctx *ctx, void *dev) {
+    if (!ctx) return MI_EINVAL;
+    MI_CHECK_HIP(ctx, hipFree(dev));
+    return MI_OK;
+}
+int32_t mi_dev_upload(mi_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || ((!dst || !src) && bytes)) return MI_EINVAL;
+    if (bytes) MI_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+int32_t mi_dev_download(mi_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx || ((!dst || !src) && bytes)) return MI_EINVAL;
+    if (bytes) MI_CHECK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+int32_t mi_dev_sync(mi_ctx *ctx) {
+    if (!ctx) return MI_EINVAL;
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+
+// ---------------------------------------------------------------- encoding (Proof.WriteTo, marshal.go by behaviour)
+static void fp_be_bytes(const Fp &mont, uint8_t out[32]) {
+    Fp c = fe_from_mont(mont);
+    for (int i = 0; i < 8; i++)
+        for (int k = 0; k < 4; k++) out[31 - (4 * i + k)] = (uint8_t)(c.l[i] >> (8 * k));
+}
+static bool fp_lex_largest(const Fp &mont) {  // canonical y > (q-1)/2
+    static const u32 half[8] = {0x6c3e7ea3u, 0x9e10460bu, 0xb438e546u, 0xcbc0b548u, 0x40c0ac2eu, 0xdc2822dbu, 0x7098d014u, 0x18322739u};
+    Fp c = fe_from_mont(mont);
+    for (int i = 7; i >= 0; i--) {
+        if (c.l[i] > half[i]) return true;
+        if (c.l[i] < half[i]) return false;
+    }
+    return false;
+}
+void mi_g1_compress(const mi_g1_affine *p, uint8_t out[32]) {
+    G1Aff a;
+    std::memcpy(&a, p, sizeof(a));
+    if (a.is_inf()) { std::memset(out, 0, 32); out[0] = 0x40; return; }
+    fp_be_bytes(a.x, out);
+    out[0] |= fp_lex_largest(a.y) ? 0xC0 : 0x80;
+}
+void mi_g2_compress(const mi_g2_affine *p, uint8_t out[64]) {
+    G2Aff a;
+    std::memcpy(&a, p, sizeof(a));
+    if (a.is_inf()) { std::memset(out, 0, 64); out[0] = 0x40; return; }
+    fp_be_bytes(a.x.a1, out);
+    fp_be_bytes(a.x.a0, out + 32);
+    bool largest = a.y.a1.is_zero() ? fp_lex_largest(a.y.a0) : fp_lex_largest(a.y.a1);
+    out[0] |= largest ? 0xC0 : 0x80;
+}
+size_t mi_proof_write(const mi_proof_out *proof, const mi_g1_affine *commitments, uint32_t n_commitments,
+                      const mi_g1_affine *pok, uint8_t *out) {
+    uint8_t *p = out;
+    mi_g1_compress(&proof->ar, p); p += 32;
+    mi_g2_compress(&proof->bs, p); p += 64;
+    mi_g1_compress(&proof->krs, p); p += 32;
+    p[0] = (uint8_t)(n_commitments >> 24); p[1] = (uint8_t)(n_commitments >> 16);
+    p[2] = (uint8_t)(n_commitments >> 8); p[3] = (uint8_t)n_commitments; p += 4;
+    for (uint32_t i = 0; i < n_commitments; i++) { mi_g1_compress(&commitments[i], p); p += 32; }
+    if (pok) mi_g1_compress(pok, p);
+    else { std::memset(p, 0, 32); p[0] = 0x40; }
+    p += 32;
+    return (size_t)(p - out);
+}
+
+}  // extern "C"
+// ---------------------------------------------------------------- partial-sum combine (host)
+template <class F, class JacT>
+static void sum_parts(const JacT *parts, size_t n, JacT *out) {
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = 0; i < n; i++) {
+        Jac<F> j;
+        std::memcpy(&j, &parts[i], sizeof(j));
+        if (j.z.is_zero()) continue;
+        // Jacobian (X,Y,Z) -> XYZZ (X, Y, Z^2, Z^3)
+        F zz = fe_sqr(j.z);
+        XYZZ<F> q{j.x, j.y, zz, zz * j.z};
+        xyzz_add(acc, q);
+    }
+    Jac<F> r;
+    if (acc.is_inf()) r = Jac<F>{F::one(), F::one(), F::zero()};
+    else { Affine<F> a = xyzz_to_affine(acc); r = Jac<F>{a.x, a.y, F::one()}; }
+    std::memcpy(out, &r, sizeof(r));
+}
+extern "C" {
+int32_t mi_g1_sum(const mi_g1_jac *parts, size_t n, mi_g1_jac *out) {
+    if ((!parts && n) || !out) return MI_EINVAL;
+    sum_parts<Fp>(parts, n, out);
+    return MI_OK;
+}
+int32_t mi_g2_sum(const mi_g2_jac *parts, size_t n, mi_g2_jac *out) {
+    if ((!parts && n) || !out) return MI_EINVAL;
+    sum_parts<Fp2>(parts, n, out);
+    return MI_OK;
+}
+}

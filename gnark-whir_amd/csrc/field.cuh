@@ -1,0 +1,224 @@
+// BN254 Fr / Fp on gfx950: 8 x 32-bit little-endian limbs (same bytes as gnark-crypto's 4 x u64
+// fr.Element / fp.Element, typeConverters.go:30-39 limb order), Montgomery form, R = 2^256.
+// Replaces gnark-crypto ecc/bn254/{fr,fp} element arithmetic on the path reached from
+// /root/reference/mt.go:496.
+//
+// Multiplication is the "no-carry" CIOS variant (valid because the top limb of both moduli is
+// < 2^31): one fused row of x*y[i] and m*p per outer step, written so that hipcc lowers each
+// 32x32+64 step to v_mad_u64_u32.  Everything is MI_HD so tests can run the identical code on
+// the host (tests/emu), the product only ever runs it on the device.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MI_HD __host__ __device__ __forceinline__
+#define MI_D __device__ __forceinline__
+#else
+#define MI_HD inline
+#define MI_D inline
+#endif
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct FrParams {
+    static constexpr u32 p[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr u32 r2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    static constexpr u32 one[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr u32 inv = 0xefffffffu;  // -p^-1 mod 2^32
+};
+struct FpParams {
+    static constexpr u32 p[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr u32 r2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    static constexpr u32 one[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    static constexpr u32 inv = 0xe4866389u;
+};
+
+template <class P>
+struct Fe {
+    u32 l[8];
+
+    static MI_HD Fe zero() { Fe z; 
+#pragma unroll
+        for (int i = 0; i < 8; i++) z.l[i] = 0; 
+        return z; }
+    static MI_HD Fe one() { Fe z; 
+#pragma unroll
+        for (int i = 0; i < 8; i++) z.l[i] = P::one[i]; 
+        return z; }
+    static MI_HD Fe r2() { Fe z; 
+#pragma unroll
+        for (int i = 0; i < 8; i++) z.l[i] = P::r2[i]; 
+        return z; }
+    static MI_HD Fe modulus() { Fe z; 
+#pragma unroll
+        for (int i = 0; i < 8; i++) z.l[i] = P::p[i]; 
+        return z; }
+
+    MI_HD bool is_zero() const { u32 o = 0; 
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= l[i]; 
+        return o == 0; }
+    MI_HD bool operator==(const Fe &b) const { u32 o = 0; 
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i]; 
+        return o == 0; }
+    MI_HD bool operator!=(const Fe &b) const { return !(*this == b); }
+};
+
+// z = x - y, returns borrow
+template <class P>
+MI_HD u32 fe_sub_raw(Fe<P> &z, const Fe<P> &x, const Fe<P> &y) {
+    u64 b = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 d = (u64)x.l[i] - y.l[i] - b;
+        z.l[i] = (u32)d;
+        b = (d >> 32) & 1;
+    }
+    return (u32)b;
+}
+template <class P>
+MI_HD u32 fe_add_raw(Fe<P> &z, const Fe<P> &x, const Fe<P> &y) {
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (u64)x.l[i] + y.l[i];
+        z.l[i] = (u32)c;
+        c >>= 32;
+    }
+    return (u32)c;
+}
+// if x >= p: x -= p   (x < 2p)
+template <class P>
+MI_HD Fe<P> fe_reduce_once(const Fe<P> &x) {
+    Fe<P> d;
+    u32 borrow = fe_sub_raw(d, x, Fe<P>::modulus());
+    Fe<P> z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z.l[i] = borrow ? x.l[i] : d.l[i];
+    return z;
+}
+template <class P>
+MI_HD Fe<P> operator+(const Fe<P> &x, const Fe<P> &y) {
+    Fe<P> s;
+    fe_add_raw(s, x, y);  // p < 2^254: no carry out
+    return fe_reduce_once(s);
+}
+template <class P>
+MI_HD Fe<P> operator-(const Fe<P> &x, const Fe<P> &y) {
+    Fe<P> d, e;
+    u32 borrow = fe_sub_raw(d, x, y);
+    fe_add_raw(e, d, Fe<P>::modulus());
+    Fe<P> z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z.l[i] = borrow ? e.l[i] : d.l[i];
+    return z;
+}
+template <class P>
+MI_HD Fe<P> fe_neg(const Fe<P> &x) {
+    Fe<P> d;
+    fe_sub_raw(d, Fe<P>::modulus(), x);
+    bool zr = x.is_zero();
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.l[i] = zr ? 0u : d.l[i];
+    return d;
+}
+template <class P>
+MI_HD Fe<P> fe_dbl(const Fe<P> &x) { return x + x; }
+
+// Montgomery product x*y/R mod p, no-carry CIOS over 32-bit limbs.
+template <class P>
+MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
+    u32 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 a = (u64)x.l[0] * y.l[i] + t[0];
+        u32 m = (u32)a * P::inv;
+        u64 c = (u64)m * P::p[0] + (u32)a;
+        a >>= 32;
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            a += (u64)x.l[j] * y.l[i] + t[j];
+            c += (u64)m * P::p[j] + (u32)a;
+            t[j - 1] = (u32)c;
+            a >>= 32;
+            c >>= 32;
+        }
+        t[7] = (u32)(a + c);
+    }
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    return fe_reduce_once(r);
+}
+template <class P>
+MI_HD Fe<P> fe_sqr(const Fe<P> &x) { return x * x; }
+
+template <class P>
+MI_HD Fe<P> fe_to_mont(const Fe<P> &x) { return x * Fe<P>::r2(); }
+template <class P>
+MI_HD Fe<P> fe_from_mont(const Fe<P> &x) {
+    Fe<P> o = Fe<P>::zero();
+    o.l[0] = 1;
+    return x * o;
+}
+// x^e, e = 8 x u32 little-endian plain integer
+template <class P>
+MI_HD Fe<P> fe_pow(const Fe<P> &x, const u32 e[8]) {
+    Fe<P> acc = Fe<P>::one();
+    for (int i = 255; i >= 0; i--) {
+        acc = fe_sqr(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = acc * x;
+    }
+    return acc;
+}
+template <class P>
+MI_HD Fe<P> fe_inv(const Fe<P> &x) {  // Fermat, 0 -> 0
+    u32 e[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) e[i] = P::p[i];
+    e[0] -= 2;  // low limb of both moduli is >= 2
+    return fe_pow(x, e);
+}
+template <class P>
+MI_HD Fe<P> fe_from_u32(u32 v) {
+    Fe<P> t = Fe<P>::zero();
+    t.l[0] = v;
+    return fe_to_mont(t);
+}
+
+typedef Fe<FrParams> Fr;
+typedef Fe<FpParams> Fp;
+
+// ---------------------------------------------------------------- Fp2 = Fp[u]/(u^2+1)  (fptower.E2)
+struct Fp2 {
+    Fp a0, a1;
+    static MI_HD Fp2 zero() { return Fp2{Fp::zero(), Fp::zero()}; }
+    static MI_HD Fp2 one() { return Fp2{Fp::one(), Fp::zero()}; }
+    MI_HD bool is_zero() const { return a0.is_zero() && a1.is_zero(); }
+    MI_HD bool operator==(const Fp2 &b) const { return a0 == b.a0 && a1 == b.a1; }
+    MI_HD bool operator!=(const Fp2 &b) const { return !(*this == b); }
+};
+MI_HD Fp2 operator+(const Fp2 &x, const Fp2 &y) { return Fp2{x.a0 + y.a0, x.a1 + y.a1}; }
+MI_HD Fp2 operator-(const Fp2 &x, const Fp2 &y) { return Fp2{x.a0 - y.a0, x.a1 - y.a1}; }
+MI_HD Fp2 fe_neg(const Fp2 &x) { return Fp2{fe_neg(x.a0), fe_neg(x.a1)}; }
+MI_HD Fp2 fe_dbl(const Fp2 &x) { return x + x; }
+// Karatsuba: 3 base multiplications
+MI_HD Fp2 operator*(const Fp2 &x, const Fp2 &y) {
+    Fp v0 = x.a0 * y.a0, v1 = x.a1 * y.a1;
+    Fp s = (x.a0 + x.a1) * (y.a0 + y.a1);
+    return Fp2{v0 - v1, s - v0 - v1};
+}
+// (a0+a1)(a0-a1), 2 a0 a1 : 2 base multiplications
+MI_HD Fp2 fe_sqr(const Fp2 &x) {
+    Fp m = x.a0 * x.a1;
+    return Fp2{(x.a0 + x.a1) * (x.a0 - x.a1), m + m};
+}
+MI_HD Fp2 fe_inv(const Fp2 &x) {
+    Fp n = fe_inv(fe_sqr(x.a0) + fe_sqr(x.a1));
+    return Fp2{x.a0 * n, fe_neg(x.a1 * n)};
+}

@@ -1,0 +1,256 @@
+// Radix-2 NTT over Fr for gfx950 and the fused computeH pipeline.
+// Replaces fft.Domain.FFT / FFTInverse (gnark-crypto ecc/bn254/fr/fft) and computeH (gnark
+// backend/groth16/bn254/prove.go) on the path reached from /root/reference/mt.go:496
+// (SURVEY.md 8a rows a3/a4).  Pass structure and index arithmetic: ntt_tile.cuh.
+//
+// HBM layout: the caller's array of 32-byte Montgomery elements, transformed in place.  Each pass
+// is one launch; a workgroup owns one LDS tile (<= 2^log_e elements, two 16-byte planes), loads
+// it with >= 256-byte contiguous runs, runs log2(R) butterfly stages out of LDS and stores it
+// back.  Root tables: one 1024-entry table serves every in-tile stage; inter-pass twiddles and
+// coset powers come from two sqrt(N)-sized tables and one product (no N-sized table is ever read).
+// Bound: HBM for the load/store (64 B per element per pass), VALU (one 256-bit Montgomery product
+// per butterfly) for the stages -- see DESIGN.md for the measured split.
+#include "ctx.h"
+#include "ntt_tile.cuh"
+#include <cstring>
+
+struct NttState {
+    u32 log_n = 0xffffffffu;
+    Fr *small_f = nullptr, *small_i = nullptr;          // N independent
+    Fr *tw_lo_f = nullptr, *tw_hi_f = nullptr, *tw_lo_i = nullptr, *tw_hi_i = nullptr;
+    Fr *g_lo = nullptr, *g_hi = nullptr, *gi_lo = nullptr, *gi_hi = nullptr, *ninv = nullptr;
+    u32 tw_h = 0;
+    // plan knobs (mi_debug_set_ntt_plan)
+    u32 log_e = 11, max_contig = 11, max_strided = 8;
+};
+static NttState *state_of(mi_ctx *ctx) {
+    static_assert(sizeof(NttState) <= 256, "NttState lives in ctx->ntt_state");
+    return reinterpret_cast<NttState *>(ctx->ntt_state);
+}
+
+void mi_ntt_state_init(mi_ctx *ctx) { new (ctx->ntt_state) NttState(); }
+void mi_ntt_state_free(mi_ctx *ctx) {
+    NttState *st = state_of(ctx);
+    Fr **all[] = {&st->small_f, &st->small_i, &st->tw_lo_f, &st->tw_hi_f, &st->tw_lo_i, &st->tw_hi_i,
+                  &st->g_lo, &st->g_hi, &st->gi_lo, &st->gi_hi, &st->ninv};
+    for (Fr **p : all) if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+// out[j] = c * base^(j << shift)
+__global__ void k_pow_table(Fr *out, u32 count, Fr base, Fr c, u32 shift) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    u64 e = (u64)j << shift;
+    Fr acc = c, b = base;
+    while (e) {
+        if (e & 1) acc = acc * b;
+        b = fe_sqr(b);
+        e >>= 1;
+    }
+    out[j] = acc;
+}
+
+__global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, NttPass p, NttTables t) {
+    extern __shared__ U4 lds[];
+    const u64 tile = blockIdx.x;
+    ntt_tile_load(p, t, src, tile, threadIdx.x, blockDim.x, lds);
+    __syncthreads();
+    for (u32 s = 0; s < p.log_r; s++) {
+        ntt_tile_stage(p, t, s, threadIdx.x, blockDim.x, lds);
+        __syncthreads();
+    }
+    ntt_tile_store(p, t, dst, tile, threadIdx.x, blockDim.x, lds);
+}
+
+// a[i] = (a[i]*b[i] - c[i]) * den      (computeH's pointwise step)
+__global__ void k_h_pointwise(Fr *a, const Fr *b, const Fr *c, Fr den, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    a[i] = (a[i] * b[i] - c[i]) * den;
+}
+
+static Fr host_fr_from_u64x4(u64 a, u64 b, u64 c, u64 d) {
+    Fr t;
+    t.l[0] = (u32)a; t.l[1] = (u32)(a >> 32); t.l[2] = (u32)b; t.l[3] = (u32)(b >> 32);
+    t.l[4] = (u32)c; t.l[5] = (u32)(c >> 32); t.l[6] = (u32)d; t.l[7] = (u32)(d >> 32);
+    return fe_to_mont(t);
+}
+static Fr domain_generator(u32 log_n) {  // fft.NewDomain: Generator = root^(2^(28-log_n))
+    Fr g = host_fr_from_u64x4(0x9bd61b6e725b19f0ull, 0x402d111e41112ed4ull, 0x00e0a7eb8ef62abcull, 0x2a3c09f0a58a7e85ull);
+    for (u32 k = log_n; k < 28; k++) g = fe_sqr(g);
+    return g;
+}
+
+static int32_t build_table(mi_ctx *ctx, Fr **slot, u32 count, const Fr &base, const Fr &c, u32 shift) {
+    if (*slot) { MI_CHECK_HIP(ctx, hipFree(*slot)); *slot = nullptr; }
+    MI_CHECK_HIP(ctx, hipMalloc((void **)slot, sizeof(Fr) * (count ? count : 1)));
+    hipLaunchKernelGGL(k_pow_table, dim3((count + 127) / 128), dim3(128), 0, ctx->stream, *slot, count, base, c, shift);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+
+static int32_t ensure_tables(mi_ctx *ctx, u32 log_n) {
+    NttState *st = state_of(ctx);
+    if (!st->small_f) {
+        Fr w2048 = domain_generator(11);
+        MI_TRY(build_table(ctx, &st->small_f, 1024, w2048, Fr::one(), 0));
+        MI_TRY(build_table(ctx, &st->small_i, 1024, fe_inv(w2048), Fr::one(), 0));
+    }
+    if (st->log_n == log_n) return MI_OK;
+    Fr w = domain_generator(log_n), wi = fe_inv(w);
+    Fr g = fe_from_u32<FrParams>(5), gi = fe_inv(g);
+    Fr nn = Fr::zero();
+    nn.l[0] = (u32)(1u << log_n);  // log_n <= 28
+    Fr ninv = fe_inv(fe_to_mont(nn));
+    u32 h = (log_n + 1) / 2;
+    u32 nlo = 1u << h, nhi = 1u << (log_n - h);
+    st->tw_h = h;
+    MI_TRY(build_table(ctx, &st->tw_lo_f, nlo, w, Fr::one(), 0));
+    MI_TRY(build_table(ctx, &st->tw_hi_f, nhi, w, Fr::one(), h));
+    MI_TRY(build_table(ctx, &st->tw_lo_i, nlo, wi, Fr::one(), 0));
+    MI_TRY(build_table(ctx, &st->tw_hi_i, nhi, wi, Fr::one(), h));
+    MI_TRY(build_table(ctx, &st->g_lo, nlo, g, Fr::one(), 0));
+    MI_TRY(build_table(ctx, &st->g_hi, nhi, g, Fr::one(), h));
+    MI_TRY(build_table(ctx, &st->gi_lo, nlo, gi, Fr::one(), 0));
+    MI_TRY(build_table(ctx, &st->gi_hi, nhi, gi, ninv, h));
+    MI_TRY(build_table(ctx, &st->ninv, 1, Fr::one(), ninv, 0));
+    st->log_n = log_n;
+    return MI_OK;
+}
+
+// One transform of size 2^log_n: dst <- NTT(src[0..n_valid) zero padded).  dst == src allowed.
+static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log_n, u32 flags) {
+    NttState *st = state_of(ctx);
+    MI_TRY(ensure_tables(ctx, log_n));
+    const bool inverse = flags & MI_NTT_INVERSE, coset = flags & MI_NTT_COSET, dit = flags & MI_NTT_DIT;
+    NttTables t{};
+    t.small = inverse ? st->small_i : st->small_f;
+    t.tw_lo = inverse ? st->tw_lo_i : st->tw_lo_f;
+    t.tw_hi = inverse ? st->tw_hi_i : st->tw_hi_f;
+    t.tw_h = st->tw_h;
+    u32 load_scale = 0, store_scale = 0;
+    if (coset && !inverse) { t.sc_lo = st->g_lo; t.sc_hi = st->g_hi; load_scale = dit ? 1 : 2; }
+    else if (coset && inverse) { t.sc_lo = st->gi_lo; t.sc_hi = st->gi_hi; store_scale = dit ? 4 : 3; }
+    else if (inverse) { t.sc_lo = st->ninv; t.sc_hi = st->ninv; store_scale = 5; }
+
+    NttPlan pl = ntt_make_plan(log_n, st->max_contig, st->max_strided);
+    // log_s of pass i (DIF order): product of later radices
+    u32 log_s[8];
+    for (u32 i = 0, acc = log_n; i < pl.n_pass; i++) { acc -= pl.log_r[i]; log_s[i] = acc; }
+    const Fr *cur_src = src;
+    for (u32 step = 0; step < pl.n_pass; step++) {
+        u32 i = dit ? pl.n_pass - 1 - step : step;
+        NttPass p{};
+        p.log_n = log_n; p.log_r = pl.log_r[i]; p.log_s = log_s[i];
+        u32 room = st->log_e > p.log_r ? st->log_e - p.log_r : 0;
+        u32 avail = p.log_s == 0 ? log_n - p.log_r : p.log_s;
+        p.log_c = room < avail ? room : avail;
+        p.dit = dit ? 1 : 0;
+        p.twiddle = p.log_s != 0;
+        p.scale = 0;
+        if (step == 0 && load_scale) p.scale = load_scale;
+        if (step == pl.n_pass - 1 && store_scale) {
+            if (p.scale) MI_FAIL(ctx, MI_EINVAL, "internal: load and store scale on one pass");
+            p.scale = store_scale;
+        }
+        p.n_valid = step == 0 ? n_valid : (1u << log_n);
+        u32 tiles = 1u << (log_n - p.log_r - p.log_c);
+        size_t lds_bytes = (size_t)32 << (p.log_r + p.log_c);
+        u32 E = 1u << (p.log_r + p.log_c);
+        u32 threads = E / 2 >= 256 ? 256 : (E / 2 >= 64 ? E / 2 : 64);
+        hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(threads), lds_bytes, ctx->stream, dst, cur_src, p, t);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+        cur_src = dst;
+        ctx->stats.ntt_launches++;
+    }
+    ctx->stats.ntt_elems += (u64)1 << log_n;
+    return MI_OK;
+}
+
+int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t flags) {
+    return ntt_run(ctx, (Fr *)inout_dev, (const Fr *)inout_dev, 1u << log_n, log_n, flags);
+}
+
+int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                              size_t n_constraints, mi_fr *h_out) {
+    const size_t n = (size_t)1 << log_n;
+    MI_TRY(mi_reserve(ctx, ctx->ws[0], n * sizeof(Fr)));
+    MI_TRY(mi_reserve(ctx, ctx->ws[1], n * sizeof(Fr)));
+    Fr *A = (Fr *)h_out, *B = (Fr *)ctx->ws[0].p, *C = (Fr *)ctx->ws[1].p;
+    // 1. a,b,c <- FFTInverse(., DIF)  (zero padding fused into the first pass's load)
+    MI_TRY(ntt_run(ctx, A, (const Fr *)a, (u32)n_constraints, log_n, MI_NTT_INVERSE));
+    MI_TRY(ntt_run(ctx, B, (const Fr *)b, (u32)n_constraints, log_n, MI_NTT_INVERSE));
+    MI_TRY(ntt_run(ctx, C, (const Fr *)c, (u32)n_constraints, log_n, MI_NTT_INVERSE));
+    // 2. a,b,c <- FFT(., DIT, OnCoset)
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET));
+    MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET));
+    MI_TRY(ntt_run(ctx, C, C, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET));
+    // 3. a <- (a*b - c) / (g^n - 1)
+    Fr g = fe_from_u32<FrParams>(5), gn = g;
+    for (u32 k = 0; k < log_n; k++) gn = fe_sqr(gn);
+    Fr den = fe_inv(gn - Fr::one());
+    hipLaunchKernelGGL(k_h_pointwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, B, C, den, n);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    // 4. h <- FFTInverse(a, DIF, OnCoset), left bit-reversed like gnark
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET));
+    return MI_OK;
+}
+
+static void stats_begin(mi_ctx *ctx) { std::memset(&ctx->stats, 0, sizeof(ctx->stats)); }
+
+extern "C" {
+int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, uint32_t max_strided) {
+    if (!ctx || log_e < 1 || log_e > 12 || max_contig < 1 || max_contig > 11 || max_contig > log_e || max_strided < 1 || max_strided > log_e)
+        return MI_EINVAL;
+    NttState *st = state_of(ctx);
+    st->log_e = log_e; st->max_contig = max_contig; st->max_strided = max_strided;
+    return MI_OK;
+}
+int32_t mi_ntt_dev(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t flags) {
+    if (!ctx || !inout_dev || log_n > 28 || (flags & ~7u)) return MI_EINVAL;
+    stats_begin(ctx);
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MI_TRY(mi_ntt_dev_impl(ctx, inout_dev, log_n, flags));
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    MI_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.ntt_kernel_ms, ctx->ev[0], ctx->ev[1]));
+    return MI_OK;
+}
+int32_t mi_ntt(mi_ctx *ctx, mi_fr *inout, uint32_t log_n, uint32_t flags) {
+    if (!ctx || !inout || log_n > 28 || (flags & ~7u)) return MI_EINVAL;
+    size_t bytes = sizeof(Fr) << log_n;
+    MI_TRY(mi_reserve(ctx, ctx->ws[2], bytes));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(ctx->ws[2].p, inout, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MI_TRY(mi_ntt_dev(ctx, (mi_fr *)ctx->ws[2].p, log_n, flags));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(inout, ctx->ws[2].p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+int32_t mi_compute_h_dev(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                         size_t n_constraints, mi_fr *h_out) {
+    if (!ctx || !a || !b || !c || !h_out || log_n > 28 || n_constraints > ((size_t)1 << log_n)) return MI_EINVAL;
+    stats_begin(ctx);
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MI_TRY(mi_compute_h_dev_impl(ctx, log_n, a, b, c, n_constraints, h_out));
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    MI_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.compute_h_ms, ctx->ev[0], ctx->ev[1]));
+    ctx->stats.ntt_kernel_ms = ctx->stats.compute_h_ms;
+    return MI_OK;
+}
+int32_t mi_compute_h(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                     size_t n_constraints, mi_fr *h_out) {
+    if (!ctx || !a || !b || !c || !h_out || log_n > 28 || n_constraints > ((size_t)1 << log_n)) return MI_EINVAL;
+    size_t nb = n_constraints * sizeof(Fr), full = sizeof(Fr) << log_n;
+    MI_TRY(mi_reserve(ctx, ctx->ws[2], full));
+    MI_TRY(mi_reserve(ctx, ctx->ws[3], nb * 3 + 96));
+    char *in = (char *)ctx->ws[3].p;
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(in, a, nb, hipMemcpyHostToDevice, ctx->stream));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(in + nb, b, nb, hipMemcpyHostToDevice, ctx->stream));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(in + 2 * nb, c, nb, hipMemcpyHostToDevice, ctx->stream));
+    MI_TRY(mi_compute_h_dev(ctx, log_n, (mi_fr *)in, (mi_fr *)(in + nb), (mi_fr *)(in + 2 * nb), n_constraints, (mi_fr *)ctx->ws[2].p));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(h_out, ctx->ws[2].p, full, hipMemcpyDeviceToHost, ctx->stream));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+}

@@ -1,0 +1,174 @@
+// One pass of the multi-pass radix-2 NTT over Fr, expressed as three per-thread phases
+// (load / stage / store) over an LDS-resident tile, so that the HIP kernel (ntt.hip) and the
+// host emulation used by the CPU tests run the identical index arithmetic.
+//
+// Replaces gnark-crypto ecc/bn254/fr/fft difFFT / ditFFT (+ the OnCoset scaling loops of
+// Domain.FFT / FFTInverse) on the computeH path reached from /root/reference/mt.go:496
+// (SURVEY.md 8a rows a3/a4).  Same results, different decomposition:
+//
+//   N = R_1 * R_2 * ... * R_m.  Pass t views the array as blocks of M = R*S elements
+//   (S = stride = product of the later radices for DIF, of the earlier ones for DIT); inside a
+//   block, element (row rho, column lo) sits at rho*S + lo.  A tile is all R rows x C columns.
+//     DIF pass:  size-R DIF over the rows (natural in, bit-reversed out), then row rho is
+//                multiplied by w_M^(lo * bitrev_R(rho)).
+//     DIT pass:  row rho is first multiplied by w_M^(lo * bitrev_R(rho)), then size-R DIT over
+//                the rows (bit-reversed in, natural out).
+//   This is the Cooley-Tukey regrouping of the radix-2 stage twiddles (exact in a field), so the
+//   output equals gnark's stage-by-stage result bit for bit.  Coset shifts and 1/N are folded
+//   into the first pass's load or the last pass's store.
+//
+// LDS image: two planes of 16-byte halves (lo / hi 128 bits of each element) so that a wave's
+// ds_read_b128 / ds_write_b128 walk consecutive 16-byte slots (conflict-free at unit stride).
+#pragma once
+#include "field.cuh"
+
+struct U4 { u32 x, y, z, w; };  // 16-byte LDS slot (uint4 without pulling hip headers into host builds)
+
+struct NttTables {
+    const Fr *small;    // small[j] = w_2048^j, j < 1024  (in-tile butterfly twiddles for every radix <= 2^11)
+    const Fr *tw_lo;    // tw_lo[j] = w_N^j,          j < 2^tw_h
+    const Fr *tw_hi;    // tw_hi[j] = w_N^(j * 2^tw_h)
+    const Fr *sc_lo;    // scale tables: sc_lo[j] = g^j, sc_hi[j] = const * g^(j * 2^tw_h)  (g = 5 or 1/5)
+    const Fr *sc_hi;
+    u32 tw_h;
+};
+
+struct NttPass {
+    u32 log_n;      // transform size
+    u32 log_r;      // radix of this pass (rows per tile)
+    u32 log_s;      // stride between rows: element (rho, lo) of block hi is at hi*R*S + rho*S + lo
+    u32 log_c;      // columns per tile (C <= S) -- for S == 1 the C "columns" are consecutive blocks
+    u32 dit;        // 0: DIF butterflies + post twiddle; 1: pre twiddle + DIT butterflies
+    u32 twiddle;    // apply the inter-pass twiddle (0 on the pass with S == 1)
+    u32 scale;      // 0 none; 1 load * sc[bitrev_N(i)]; 2 load * sc[i]; 3 store * sc[bitrev_N(i)];
+                    // 4 store * sc[i]; 5 store * sc_hi[0] (constant)
+    u32 n_valid;    // loads at global index >= n_valid read as zero (fused zero padding)
+};
+
+MI_HD u32 bitrev_u32(u32 x, u32 bits) {
+#if defined(__HIPCC__)
+    return bits ? (__builtin_bitreverse32(x) >> (32 - bits)) : 0u;   // v_bfrev_b32
+#else
+    u32 r = 0;
+    for (u32 k = 0; k < bits; k++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+#endif
+}
+MI_HD Fr pow_from_tables(const Fr *lo, const Fr *hi, u32 h, u32 e) {
+    return lo[e & ((1u << h) - 1)] * hi[e >> h];
+}
+
+// tile-local element index (rho, col) -> global element index, and LDS slot.
+// Strided pass (S > 1): tile = R rows x C consecutive columns; LDS slot = rho*C + col.
+// Contiguous pass (S == 1): tile = C consecutive blocks of R elements; LDS slot = col*R + rho.
+MI_HD u64 ntt_global_index(const NttPass &p, u64 tile, u32 rho, u32 col) {
+    if (p.log_s == 0) return ((tile << p.log_c) + col) * ((u64)1 << p.log_r) + rho;
+    u64 tiles_per_block = (u64)1 << (p.log_s - p.log_c);
+    u64 hi = tile / tiles_per_block, lo0 = (tile % tiles_per_block) << p.log_c;
+    return (hi << (p.log_r + p.log_s)) + ((u64)rho << p.log_s) + lo0 + col;
+}
+MI_HD u32 ntt_lds_slot(const NttPass &p, u32 rho, u32 col) {
+    return p.log_s == 0 ? (col << p.log_r) + rho : (rho << p.log_c) + col;
+}
+MI_HD void lds_put(U4 *lds, u32 plane_elems, u32 slot, const Fr &v) {
+    lds[slot] = U4{v.l[0], v.l[1], v.l[2], v.l[3]};
+    lds[plane_elems + slot] = U4{v.l[4], v.l[5], v.l[6], v.l[7]};
+}
+MI_HD Fr lds_get(const U4 *lds, u32 plane_elems, u32 slot) {
+    U4 a = lds[slot], b = lds[plane_elems + slot];
+    Fr v;
+    v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+    v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+    return v;
+}
+// inter-pass twiddle of (rho, lo): w_M^(lo * bitrev_R(rho)) = w_N^((lo * bitrev_R(rho)) << (log_n - log_m))
+MI_HD Fr ntt_interpass_twiddle(const NttPass &p, const NttTables &t, u32 rho, u64 g) {
+    u32 lo = (u32)(g & (((u64)1 << p.log_s) - 1));
+    u32 e = (lo * bitrev_u32(rho, p.log_r)) << (p.log_n - p.log_r - p.log_s);
+    return pow_from_tables(t.tw_lo, t.tw_hi, t.tw_h, e);
+}
+
+// phase 1: global -> LDS (+ fused zero padding, coset pre-scale, DIT pre-twiddle)
+MI_HD void ntt_tile_load(const NttPass &p, const NttTables &t, const Fr *data, u64 tile, u32 tid, u32 nthr, U4 *lds) {
+    const u32 E = 1u << (p.log_r + p.log_c);
+    for (u32 e = tid; e < E; e += nthr) {
+        // walk the tile in the order that is contiguous in global memory
+        u32 rho, col;
+        if (p.log_s == 0) { rho = e & ((1u << p.log_r) - 1); col = e >> p.log_r; }
+        else { col = e & ((1u << p.log_c) - 1); rho = e >> p.log_c; }
+        u64 g = ntt_global_index(p, tile, rho, col);
+        Fr v = g < p.n_valid ? data[g] : Fr::zero();
+        if (p.scale == 1) v = v * pow_from_tables(t.sc_lo, t.sc_hi, t.tw_h, bitrev_u32((u32)g, p.log_n));
+        else if (p.scale == 2) v = v * pow_from_tables(t.sc_lo, t.sc_hi, t.tw_h, (u32)g);
+        if (p.dit && p.twiddle) v = v * ntt_interpass_twiddle(p, t, rho, g);
+        lds_put(lds, E, ntt_lds_slot(p, rho, col), v);
+    }
+}
+// phase 2: one radix-2 stage over the rows.  stage = 0 .. log_r-1 in execution order.
+MI_HD void ntt_tile_stage(const NttPass &p, const NttTables &t, u32 stage, u32 tid, u32 nthr, U4 *lds) {
+    const u32 E = 1u << (p.log_r + p.log_c);
+    // DIF: half-distance d = R/2, R/4, ..., 1 ; DIT: d = 1, 2, ..., R/2
+    const u32 log_d = p.dit ? stage : (p.log_r - 1 - stage);
+    const u32 d = 1u << log_d;
+    for (u32 b = tid; b < E / 2; b += nthr) {
+        // butterfly b -> (column, pair index q within the rows)
+        u32 col, q;
+        if (p.log_s == 0) { q = b & ((1u << (p.log_r - 1)) - 1); col = b >> (p.log_r - 1); }
+        else { col = b & ((1u << p.log_c) - 1); q = b >> p.log_c; }
+        u32 j = q & (d - 1);                 // position inside the half block
+        u32 r0 = ((q >> log_d) << (log_d + 1)) + j;
+        u32 r1 = r0 + d;
+        u32 s0 = ntt_lds_slot(p, r0, col), s1 = ntt_lds_slot(p, r1, col);
+        Fr x = lds_get(lds, E, s0), y = lds_get(lds, E, s1);
+        // twiddle w_(2d)^j = w_2048^(j * 1024/d)
+        const Fr &w = t.small[j << (10 - log_d)];
+        if (p.dit) {
+            if (j) y = y * w;
+            lds_put(lds, E, s0, x + y);
+            lds_put(lds, E, s1, x - y);
+        } else {
+            Fr dd = x - y;
+            if (j) dd = dd * w;
+            lds_put(lds, E, s0, x + y);
+            lds_put(lds, E, s1, dd);
+        }
+    }
+}
+// phase 3: LDS -> global (+ DIF post-twiddle, inverse / coset post-scale)
+MI_HD void ntt_tile_store(const NttPass &p, const NttTables &t, Fr *data, u64 tile, u32 tid, u32 nthr, const U4 *lds) {
+    const u32 E = 1u << (p.log_r + p.log_c);
+    for (u32 e = tid; e < E; e += nthr) {
+        u32 rho, col;
+        if (p.log_s == 0) { rho = e & ((1u << p.log_r) - 1); col = e >> p.log_r; }
+        else { col = e & ((1u << p.log_c) - 1); rho = e >> p.log_c; }
+        u64 g = ntt_global_index(p, tile, rho, col);
+        Fr v = lds_get(lds, E, ntt_lds_slot(p, rho, col));
+        if (!p.dit && p.twiddle) v = v * ntt_interpass_twiddle(p, t, rho, g);
+        if (p.scale == 3) v = v * pow_from_tables(t.sc_lo, t.sc_hi, t.tw_h, bitrev_u32((u32)g, p.log_n));
+        else if (p.scale == 4) v = v * pow_from_tables(t.sc_lo, t.sc_hi, t.tw_h, (u32)g);
+        else if (p.scale == 5) v = v * t.sc_hi[0];
+        data[g] = v;
+    }
+}
+
+// ---------------------------------------------------------------- plan: radices of the passes
+struct NttPlan {
+    u32 n_pass;
+    u32 log_r[8];
+};
+// Contiguous pass up to 2^max_contig, strided passes up to 2^max_strided each.
+MI_HD NttPlan ntt_make_plan(u32 log_n, u32 max_contig, u32 max_strided) {
+    NttPlan pl;
+    pl.n_pass = 0;
+    if (log_n <= max_contig) { pl.n_pass = 1; pl.log_r[0] = log_n; return pl; }
+    u32 rest = log_n - max_contig;
+    u32 ns = (rest + max_strided - 1) / max_strided;
+    // spread `rest` evenly over ns strided passes; order = execution order for DIF (strided first)
+    for (u32 i = 0; i < ns; i++) {
+        u32 r = rest / (ns - i);
+        pl.log_r[pl.n_pass++] = r;
+        rest -= r;
+    }
+    pl.log_r[pl.n_pass++] = max_contig;
+    return pl;
+}

@@ -185,6 +185,11 @@ int32_t mi_g2_add_dev(mi_ctx *ctx, mi_g2_affine *out_dev, const mi_g2_affine *a_
 /* modular-multiply throughput probe: chains `iters` dependent Fp products per thread */
 int32_t mi_bench_modmul_dev(mi_ctx *ctx, int field, size_t n_threads, uint32_t iters,
                             void *scratch_dev, float *ms_out);
+/* raw VALU issue-rate probe (the integer-MAC ceiling SURVEY 8d asks to report beside the MSM):
+ * kind 0 = 32x32+64 mad, 1 = mul_lo+mul_hi u32, 2 = fma f64, 3 = 24-bit mul+add, 4 = 64-bit add;
+ * each thread runs 8 independent chains x iters steps */
+int32_t mi_bench_valu_dev(mi_ctx *ctx, int kind, size_t n_threads, uint32_t iters,
+                          void *scratch_dev, float *ms_out);
 /* raw device memory helpers so hosts without a HIP binding (ctypes, cgo) can stage data */
 int32_t mi_dev_alloc(mi_ctx *ctx, size_t bytes, void **out_dev);
 int32_t mi_dev_free(mi_ctx *ctx, void *dev);

@@ -1,0 +1,104 @@
+// Host build of the device arithmetic headers (test infrastructure): lets the CPU test-suite run
+// the exact field / curve code of gnark-whir_amd/csrc on the host and compare it with the oracle.
+#include <cstddef>
+#include <cstring>
+#include "../../gnark-whir_amd/csrc/curve.cuh"
+
+template <class P>
+static void field_op(int op, Fe<P> *z, const Fe<P> *x, const Fe<P> *y, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        switch (op) {
+        case 0: z[i] = x[i] + y[i]; break;
+        case 1: z[i] = x[i] - y[i]; break;
+        case 2: z[i] = x[i] * y[i]; break;
+        case 3: z[i] = fe_inv(x[i]); break;
+        case 4: z[i] = fe_to_mont(x[i]); break;
+        case 5: z[i] = fe_from_mont(x[i]); break;
+        case 6: z[i] = fe_neg(x[i]); break;
+        }
+    }
+}
+template <class F>
+static void ec_add(Affine<F> *out, const Affine<F> *a, const Affine<F> *b, size_t n, int mode) {
+    for (size_t i = 0; i < n; i++) {
+        XYZZ<F> acc = XYZZ<F>::from_affine(a[i]);
+        if (mode == 0) xyzz_madd(acc, b[i], false);
+        else if (mode == 1) {  // full add with non-trivial zz on both sides: scale by doubling tricks
+            XYZZ<F> q = XYZZ<F>::from_affine(b[i]);
+            // re-randomise representation: (X l^2, Y l^3, ZZ l^2, ZZZ l^3) with l = x-coordinate+1
+            if (!acc.is_inf()) { F l = a[i].x + F::one(); F l2 = fe_sqr(l), l3 = l2 * l; acc = XYZZ<F>{acc.x * l2, acc.y * l3, acc.zz * l2, acc.zzz * l3}; }
+            if (!q.is_inf()) { F l = b[i].y + F::one(); F l2 = fe_sqr(l), l3 = l2 * l; q = XYZZ<F>{q.x * l2, q.y * l3, q.zz * l2, q.zzz * l3}; }
+            xyzz_add(acc, q);
+        } else {  // a - b via negated madd
+            xyzz_madd(acc, b[i], true);
+        }
+        out[i] = xyzz_to_affine(acc);
+    }
+}
+extern "C" {
+int emu_field_op(int field, int op, void *z, const void *x, const void *y, size_t n) {
+    if (field == 0) field_op<FrParams>(op, (Fr *)z, (const Fr *)x, (const Fr *)y, n);
+    else field_op<FpParams>(op, (Fp *)z, (const Fp *)x, (const Fp *)y, n);
+    return 0;
+}
+int emu_g1_add(void *out, const void *a, const void *b, size_t n, int mode) { ec_add<Fp>((G1Aff *)out, (const G1Aff *)a, (const G1Aff *)b, n, mode); return 0; }
+int emu_g2_add(void *out, const void *a, const void *b, size_t n, int mode) { ec_add<Fp2>((G2Aff *)out, (const G2Aff *)a, (const G2Aff *)b, n, mode); return 0; }
+int emu_g1_mul_u32(void *out, const void *a, uint32_t k) { G1X r = xyzz_mul_u32(G1X::from_affine(*(const G1Aff *)a), k); *(G1Aff *)out = xyzz_to_affine(r); return 0; }
+void emu_g2_b(void *out) { Fp2 b = curve_b((const Fp2 *)0); memcpy(out, &b, sizeof(b)); }
+}
+
+// ---------------------------------------------------------------- NTT pass emulation (ntt_tile.cuh on the host)
+#include <vector>
+#include "../../gnark-whir_amd/csrc/ntt_tile.cuh"
+static Fr fr_pow_u64(Fr b, u64 e) { Fr acc = Fr::one(); while (e) { if (e & 1) acc = acc * b; b = fe_sqr(b); e >>= 1; } return acc; }
+static Fr fr_from_u64x4(u64 a, u64 b, u64 c, u64 d) {
+    Fr t; t.l[0] = (u32)a; t.l[1] = (u32)(a >> 32); t.l[2] = (u32)b; t.l[3] = (u32)(b >> 32);
+    t.l[4] = (u32)c; t.l[5] = (u32)(c >> 32); t.l[6] = (u32)d; t.l[7] = (u32)(d >> 32);
+    return fe_to_mont(t);
+}
+extern "C" int emu_ntt(void *data_v, uint32_t log_n, uint32_t flags, uint32_t log_e, uint32_t max_contig, uint32_t max_strided,
+                       uint32_t nthr, uint32_t n_valid) {
+    Fr *data = (Fr *)data_v;
+    const bool inverse = flags & 1, coset = flags & 2, dit = flags & 4;
+    Fr root = fr_from_u64x4(0x9bd61b6e725b19f0ull, 0x402d111e41112ed4ull, 0x00e0a7eb8ef62abcull, 0x2a3c09f0a58a7e85ull);
+    Fr w2048 = root; for (int k = 11; k < 28; k++) w2048 = fe_sqr(w2048);
+    Fr w = root; for (u32 k = log_n; k < 28; k++) w = fe_sqr(w);
+    if (inverse) { w = fe_inv(w); w2048 = fe_inv(w2048); }
+    Fr g = fe_from_u32<FrParams>(5); if (inverse) g = fe_inv(g);
+    Fr nn = Fr::zero(); nn.l[0] = 1u << log_n; Fr ninv = fe_inv(fe_to_mont(nn));
+    u32 h = (log_n + 1) / 2, nlo = 1u << h, nhi = 1u << (log_n - h);
+    std::vector<Fr> small(1024), twlo(nlo), twhi(nhi), sclo(nlo), schi(nhi);
+    for (u32 j = 0; j < 1024; j++) small[j] = fr_pow_u64(w2048, j);
+    for (u32 j = 0; j < nlo; j++) { twlo[j] = fr_pow_u64(w, j); sclo[j] = fr_pow_u64(g, j); }
+    for (u32 j = 0; j < nhi; j++) { twhi[j] = fr_pow_u64(w, (u64)j << h); schi[j] = fr_pow_u64(g, (u64)j << h); if (inverse) schi[j] = schi[j] * ninv; }
+    NttTables t{small.data(), twlo.data(), twhi.data(), sclo.data(), schi.data(), h};
+    std::vector<Fr> nv(1, ninv);
+    u32 load_scale = 0, store_scale = 0;
+    if (coset && !inverse) load_scale = dit ? 1 : 2;
+    else if (coset && inverse) store_scale = dit ? 4 : 3;
+    else if (inverse) { t.sc_lo = nv.data(); t.sc_hi = nv.data(); store_scale = 5; }
+    NttPlan pl = ntt_make_plan(log_n, max_contig, max_strided);
+    u32 log_s[8];
+    for (u32 i = 0, acc = log_n; i < pl.n_pass; i++) { acc -= pl.log_r[i]; log_s[i] = acc; }
+    for (u32 step = 0; step < pl.n_pass; step++) {
+        u32 i = dit ? pl.n_pass - 1 - step : step;
+        NttPass p{};
+        p.log_n = log_n; p.log_r = pl.log_r[i]; p.log_s = log_s[i];
+        u32 room = log_e > p.log_r ? log_e - p.log_r : 0;
+        u32 avail = p.log_s == 0 ? log_n - p.log_r : p.log_s;
+        p.log_c = room < avail ? room : avail;
+        p.dit = dit; p.twiddle = p.log_s != 0; p.scale = 0;
+        if (step == 0 && load_scale) p.scale = load_scale;
+        if (step == pl.n_pass - 1 && store_scale) { if (p.scale) return -1; p.scale = store_scale; }
+        p.n_valid = step == 0 ? n_valid : (1u << log_n);
+        u32 tiles = 1u << (log_n - p.log_r - p.log_c);
+        std::vector<U4> lds((size_t)2 << (p.log_r + p.log_c));
+        for (u32 tile = 0; tile < tiles; tile++) {
+            for (u32 tid = 0; tid < nthr; tid++) ntt_tile_load(p, t, data, tile, tid, nthr, lds.data());
+            for (u32 s = 0; s < p.log_r; s++)
+                for (u32 tid = 0; tid < nthr; tid++) ntt_tile_stage(p, t, s, tid, nthr, lds.data());
+            for (u32 tid = 0; tid < nthr; tid++) ntt_tile_store(p, t, data, tile, tid, nthr, lds.data());
+        }
+    }
+    return (int)pl.n_pass;
+}

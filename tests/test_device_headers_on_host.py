@@ -1,0 +1,92 @@
+"""CPU suite: the device arithmetic headers (gnark-whir_amd/csrc/field.cuh, curve.cuh) compiled
+for the host and compared with the oracle.  The product never runs this build; it exists so that
+limb-level arithmetic is proven before a kernel is launched on a GPU."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+import pytest
+import pyref as P
+import cref
+from helpers import *
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(HERE, "emu", "libemu.so")
+    src = os.path.join(HERE, "emu", "emu.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    return C.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_field_ops_bit_exact(emu):
+    rng = P.SplitMix64(21)
+    for field, mod, arr in ((0, P.R_MOD, fr_arr), (1, P.Q_MOD, fp_arr)):
+        xs = [rng.fr() % mod for _ in range(300)] + [0, 1, mod - 1, mod - 2, 2, 0, mod - 1]
+        ys = [rng.fr() % mod for _ in range(300)] + [0, mod - 1, mod - 1, 1, mod - 2, 5, 1]
+        X, Y = arr(xs), arr(ys)
+        for op in range(6):
+            Z = np.zeros_like(X)
+            emu.emu_field_op(field, op, _p(Z), _p(X), _p(Y), C.c_size_t(len(xs)))
+            assert np.array_equal(Z, cref.field_op(field, op, X, Y)), (field, op)
+        Z = np.zeros_like(X)
+        emu.emu_field_op(field, 6, _p(Z), _p(X), _p(Y), C.c_size_t(len(xs)))
+        assert np.array_equal(Z, cref.field_op(field, 1, np.zeros_like(X), X))
+
+
+def test_curve_ops_bit_exact(emu):
+    g1 = cref.gen_g1(64, 5)
+    a = np.concatenate([g1[:32], g1[:4], g1[4:8], np.zeros((2, 8), np.uint64), g1[8:9]])
+    neg = g1_arr([P.g1_neg(p) for p in g1_pts(g1[4:8])])
+    b = np.concatenate([g1[32:], g1[:4], neg, g1[9:10], np.zeros((1, 8), np.uint64), np.zeros((1, 8), np.uint64)])
+    want = cref.g1_add(a, b)
+    for mode in (0, 1):
+        out = np.zeros_like(a)
+        emu.emu_g1_add(_p(out), _p(a), _p(b), C.c_size_t(a.shape[0]), mode)
+        assert np.array_equal(out, want), mode
+    out = np.zeros_like(a)
+    emu.emu_g1_add(_p(out), _p(a), _p(b), C.c_size_t(a.shape[0]), 2)
+    nb = g1_arr([P.g1_neg(p) for p in g1_pts(b)])
+    assert np.array_equal(out, cref.g1_add(a, nb))
+    g2 = cref.gen_g2(24, 6)
+    a2 = np.concatenate([g2[:8], g2[:2], np.zeros((1, 16), np.uint64)])
+    b2 = np.concatenate([g2[8:16], g2[:2], g2[3:4]])
+    want2 = cref.g2_add(a2, b2)
+    for mode in (0, 1):
+        out = np.zeros_like(a2)
+        emu.emu_g2_add(_p(out), _p(a2), _p(b2), C.c_size_t(a2.shape[0]), mode)
+        assert np.array_equal(out, want2), mode
+    o = np.zeros(8, np.uint64)
+    emu.emu_g1_mul_u32(_p(o), _p(g1[0].copy()), 0xDEADBEEF)
+    assert g1_pts(o) == [P.g1_mul(g1_pts(g1[:1])[0], 0xDEADBEEF)]
+    b2c = np.zeros(8, np.uint64)
+    emu.emu_g2_b(_p(b2c))
+    assert tuple(fp_vals(b2c.reshape(2, 4))) == P.G2_B
+
+
+@pytest.mark.parametrize("log_n,log_e,mc,ms", [(1, 11, 11, 8), (4, 11, 11, 8), (6, 3, 3, 2), (9, 5, 4, 3), (10, 6, 3, 3), (12, 11, 11, 8), (13, 7, 5, 4)])
+def test_ntt_pass_decomposition_matches_oracle(emu, log_n, log_e, mc, ms):
+    """ntt_tile.cuh (the kernel's index arithmetic) run on the host with small tiles / radices so
+    that 1-, 2-, 3- and 4-pass plans are all exercised, against the C oracle, all 8 modes."""
+    n = 1 << log_n
+    a = cref.gen_scalars(n, 100 + log_n, 0)
+    for flags in range(8):
+        got = a.copy()
+        npass = emu.emu_ntt(_p(got), log_n, flags, log_e, mc, ms, 64, n)
+        assert npass >= 1
+        assert np.array_equal(got, cref.ntt(a, log_n, flags)), (flags, npass)
+
+
+def test_ntt_fused_zero_padding(emu):
+    log_n, n_valid = 8, 150
+    a = cref.gen_scalars(1 << log_n, 3, 0)
+    padded = a.copy(); padded[n_valid:] = 0
+    got = a.copy()
+    emu.emu_ntt(_p(got), log_n, 1, 5, 4, 2, 64, n_valid)
+    assert np.array_equal(got, cref.ntt(padded, log_n, 1))

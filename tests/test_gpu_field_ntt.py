@@ -1,0 +1,121 @@
+"""GPU parity (through the C-ABI): device field / curve layer, generators, NTT, computeH."""
+import os
+import json
+import numpy as np
+import pytest
+import pyref as P
+import cref
+from helpers import *
+from gpu_common import load_binding
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    B = load_binding()
+    c = B.Context(0)
+    yield c
+    c.close()
+
+
+def test_field_ops_bit_exact(ctx):
+    rng = P.SplitMix64(21)
+    for field, mod, arr in ((0, P.R_MOD, fr_arr), (1, P.Q_MOD, fp_arr)):
+        xs = [rng.fr() % mod for _ in range(500)] + [0, 1, mod - 1, mod - 2, 2, 0, mod - 1]
+        ys = [rng.fr() % mod for _ in range(500)] + [0, mod - 1, mod - 1, 1, mod - 2, 5, 1]
+        X, Y = arr(xs), arr(ys)
+        for op in range(6):
+            assert np.array_equal(ctx.field_op(field, op, X, Y), cref.field_op(field, op, X, Y)), (field, op)
+    # large random sweep of the multiplier
+    X = cref.gen_scalars(1 << 16, 1, 0); Y = cref.gen_scalars(1 << 16, 2, 0)
+    assert np.array_equal(ctx.field_op(0, 2, X, Y), cref.field_op(0, 2, X, Y))
+    assert np.array_equal(ctx.field_op(1, 2, X, Y), cref.field_op(1, 2, X, Y))
+
+
+def test_generators_match_oracle(ctx):
+    n = 3000
+    for dist in (0, 1):
+        assert np.array_equal(ctx.gen_scalars(n, 77, dist).download((n, 4)), cref.gen_scalars(n, 77, dist))
+    assert np.array_equal(ctx.gen_g1(n, 5).download((n, 8)), cref.gen_g1(n, 5))
+    assert np.array_equal(ctx.gen_g2(200, 6).download((200, 16)), cref.gen_g2(200, 6))
+
+
+def test_curve_add_all_cases(ctx):
+    g1 = cref.gen_g1(64, 5)
+    neg = g1_arr([P.g1_neg(p) for p in g1_pts(g1[4:8])])
+    a = np.concatenate([g1[:32], g1[:4], g1[4:8], np.zeros((2, 8), np.uint64), g1[8:9]])
+    b = np.concatenate([g1[32:], g1[:4], neg, g1[9:10], np.zeros((1, 8), np.uint64), np.zeros((1, 8), np.uint64)])
+    assert np.array_equal(ctx.ec_add(a, b), cref.g1_add(a, b))
+    g2 = cref.gen_g2(24, 6)
+    neg2 = g2_arr([P.g2_neg(p) for p in g2_pts(g2[2:4])])
+    a2 = np.concatenate([g2[:8], g2[:2], g2[2:4], np.zeros((1, 16), np.uint64)])
+    b2 = np.concatenate([g2[8:16], g2[:2], neg2, g2[3:4]])
+    assert np.array_equal(ctx.ec_add(a2, b2, g2=True), cref.g2_add(a2, b2))
+
+
+def test_ntt_golden_vectors(ctx):
+    with open(os.path.join(GOLD, "ntt.json")) as f:
+        g = json.load(f)
+    for case in g["cases"]:
+        a = [int(x, 16) for x in case["in"]]
+        want = [int(x, 16) for x in case["out"]]
+        assert fr_vals(ctx.ntt(fr_arr(a), case["log_n"], case["flags"])) == want, (case["log_n"], case["flags"])
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 8, 11, 12, 13, 16, 19, 20])
+def test_ntt_all_modes_vs_oracle(ctx, log_n):
+    n = 1 << log_n
+    a = cref.gen_scalars(n, 100 + log_n, 0)
+    modes = range(8) if log_n <= 16 else (1, 6, 3)
+    for flags in modes:
+        assert np.array_equal(ctx.ntt(a, log_n, flags), cref.ntt(a, log_n, flags)), flags
+
+
+def test_ntt_small_tiles_multi_pass(ctx):
+    """same kernels with the tile / radix knobs turned down: 3- and 4-pass plans at small n"""
+    lib = ctx.lib
+    try:
+        for (log_e, mc, ms, log_n) in ((6, 3, 3, 10), (7, 5, 4, 13), (8, 8, 2, 14)):
+            assert lib.mi_debug_set_ntt_plan(ctx.h, log_e, mc, ms) == 0
+            a = cref.gen_scalars(1 << log_n, 7, 0)
+            for flags in range(8):
+                assert np.array_equal(ctx.ntt(a, log_n, flags), cref.ntt(a, log_n, flags)), (log_e, flags)
+    finally:
+        assert lib.mi_debug_set_ntt_plan(ctx.h, 11, 11, 8) == 0
+
+
+def test_ntt_roundtrip_and_linearity_at_scale(ctx):
+    """size-independent properties at a BASELINE-sized domain (2^23): inverse(forward(x)) == x,
+    NTT(x + y) == NTT(x) + NTT(y), compared on device-downloaded samples."""
+    log_n = 23
+    n = 1 << log_n
+    x = ctx.gen_scalars(n, 1, 0); y = ctx.gen_scalars(n, 2, 0)
+    x0 = x.download((n, 4))
+    ctx.ntt_dev(x.ptr, log_n, 0)            # forward DIF -> bit-reversed
+    ctx.ntt_dev(x.ptr, log_n, 1 | 4)        # inverse DIT (bit-reversed in) -> natural
+    assert np.array_equal(x.download((n, 4)), x0)
+    ctx.ntt_dev(x.ptr, log_n, 2 | 4)        # coset DIT on natural-as-bitrev input; then inverse coset DIF
+    ctx.ntt_dev(x.ptr, log_n, 1 | 2)
+    # DIT(bitrev in) then DIF-inverse(natural in -> bitrev out): net effect is the bit-reversal permutation
+    got = x.download((n, 4))
+    idx = np.arange(n, dtype=np.uint32)
+    rev = np.zeros(n, dtype=np.uint32)
+    for b in range(log_n):
+        rev |= ((idx >> b) & 1) << (log_n - 1 - b)
+    assert np.array_equal(got[rev], x0)
+    for d in (x, y):
+        d.free()
+
+
+@pytest.mark.parametrize("nc", [1, 7, 1000, 5000, 70000])
+def test_compute_h_vs_oracle(ctx, nc):
+    log_n = max(nc - 1, 0).bit_length()
+    a = cref.gen_scalars(nc, 1, 1); b = cref.gen_scalars(nc, 2, 0); c = cref.field_op(0, 2, a, b)
+    assert np.array_equal(ctx.compute_h(log_n, a, b, c), cref.compute_h(log_n, a, b, c))
+
+
+def test_compute_h_golden_toy1000(ctx):
+    z = np.load(os.path.join(GOLD, "prove_toy1000.npz"))
+    assert np.array_equal(ctx.compute_h(int(z["log_n"]), z["a"], z["b"], z["c"]), z["h"])
