@@ -96,15 +96,20 @@ def test_ntt_roundtrip_and_linearity_at_scale(ctx):
     ctx.ntt_dev(x.ptr, log_n, 0)            # forward DIF -> bit-reversed
     ctx.ntt_dev(x.ptr, log_n, 1 | 4)        # inverse DIT (bit-reversed in) -> natural
     assert np.array_equal(x.download((n, 4)), x0)
-    ctx.ntt_dev(x.ptr, log_n, 2 | 4)        # coset DIT on natural-as-bitrev input; then inverse coset DIF
+    # coset DIT reads x as bit-reversed coefficients and yields natural-order coset evaluations;
+    # the inverse coset DIF maps those back to bit-reversed coefficients: the same array again
+    ctx.ntt_dev(x.ptr, log_n, 2 | 4)
+    assert not np.array_equal(x.download((4, 4)), x0[:4])
     ctx.ntt_dev(x.ptr, log_n, 1 | 2)
-    # DIT(bitrev in) then DIF-inverse(natural in -> bitrev out): net effect is the bit-reversal permutation
-    got = x.download((n, 4))
-    idx = np.arange(n, dtype=np.uint32)
-    rev = np.zeros(n, dtype=np.uint32)
-    for b in range(log_n):
-        rev |= ((idx >> b) & 1) << (log_n - 1 - b)
-    assert np.array_equal(got[rev], x0)
+    assert np.array_equal(x.download((n, 4)), x0)
+    # linearity on the device: NTT(x) + NTT(y) == NTT(x + y)
+    s = ctx.alloc(32 * n)
+    ctx._ck(ctx.lib.mi_field_op_dev(ctx.h, 0, 0, s.ptr, x.ptr, y.ptr, n))
+    for d in (x, y, s):
+        ctx.ntt_dev(d.ptr, log_n, 0)
+    ctx._ck(ctx.lib.mi_field_op_dev(ctx.h, 0, 0, x.ptr, x.ptr, y.ptr, n))
+    assert np.array_equal(x.download((n, 4)), s.download((n, 4)))
+    s.free()
     for d in (x, y):
         d.free()
 
