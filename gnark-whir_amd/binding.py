@@ -152,6 +152,9 @@ class Context:
             if b: b.free()
         return out
 
+    def field_op_dev(self, field, op, z_ptr, x_ptr, y_ptr, n):
+        self._ck(self.lib.mi_field_op_dev(self.h, C.c_int(field), C.c_int(op), _p(z_ptr), _p(x_ptr), _p(y_ptr), C.c_size_t(n)))
+
     def ec_add(self, a, b, g2=False):
         a, b = _u64(a), _u64(b); n = a.shape[0]
         da, db = self.to_dev(a), self.to_dev(b); do = self.alloc(a.nbytes)

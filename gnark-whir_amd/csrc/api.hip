@@ -22,6 +22,7 @@ int32_t mi_init(int device_id, mi_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return MI_EHIP; }
     ctx->own_stream = true;
     mi_ntt_state_init(ctx);
+    mi_msm_state_init(ctx);
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { delete ctx; return MI_EHIP; }
     *out = ctx;

@@ -20,7 +20,8 @@ struct mi_ctx {
     hipEvent_t ev[24]{};
     // scratch
     alignas(16) unsigned char ntt_state[256];  // NttState (ntt.hip): root tables + plan knobs
-    DevBuf ws[16];          // MSM / prove workspaces, see msm.hip / prove.hip
+    alignas(16) unsigned char msm_knobs[64];   // MsmKnobs (msm.hip)
+    DevBuf ws[24];          // MSM / prove workspaces, see msm.hip / prove.hip
     int cu_count = 256;
 };
 
@@ -59,3 +60,7 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
                               size_t n_constraints, mi_fr *h_out);
 void mi_ntt_state_init(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);
+void mi_msm_state_init(mi_ctx *ctx);
+// MSM returning the XYZZ result on the host (used by prove.hip); pts/scalars are device pointers
+int32_t mi_msm_g1_xyzz(mi_ctx *ctx, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, void *out_xyzz_host);
+int32_t mi_msm_g2_xyzz(mi_ctx *ctx, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, void *out_xyzz_host);

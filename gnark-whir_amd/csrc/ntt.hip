@@ -28,7 +28,11 @@ static NttState *state_of(mi_ctx *ctx) {
     return reinterpret_cast<NttState *>(ctx->ntt_state);
 }
 
-void mi_ntt_state_init(mi_ctx *ctx) { new (ctx->ntt_state) NttState(); }
+__global__ void k_ntt_pass(Fr *dst, const Fr *src, NttPass p, NttTables t);
+void mi_ntt_state_init(mi_ctx *ctx) {
+    new (ctx->ntt_state) NttState();
+    (void)hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
     Fr **all[] = {&st->small_f, &st->small_i, &st->tw_lo_f, &st->tw_hi_f, &st->tw_lo_i, &st->tw_hi_i,

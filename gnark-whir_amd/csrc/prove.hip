@@ -1,0 +1,198 @@
+// Proving key residency and the fused prove path: everything groth16.Prove does after the solve
+// (gnark v0.11.0 backend/groth16/bn254/prove.go, reached from /root/reference/mt.go:496; SURVEY.md
+// section 3.3 steps 4-8, 8a rows a7 and a9).
+//
+//   mi_pk_load   uploads pk.G1.{A,B,K,Z}, pk.G2.B once and turns the static masks pk.InfinityA/B and the
+//                public / committed wire sets into device gather-index arrays (row a7).
+//   prove        computeH on the device -> three gathers of W -> five MSMs -> O(1)-point blinding and
+//                assembly on the host (Ar, Bs1, Krs, Bs exactly as prove.go composes them).
+#include "ctx.h"
+#include "curve.cuh"
+#include <cstring>
+#include <vector>
+
+struct mi_pk {
+    u32 log_n = 0, nb_public = 0;
+    u64 nb_wires = 0;
+    void *g1_a = nullptr, *g1_b = nullptr, *g1_k = nullptr, *g1_z = nullptr, *g2_b = nullptr;
+    u64 n_a = 0, n_b = 0, n_k = 0, n_z = 0;
+    bool owns_points = false;
+    u32 *idx_a = nullptr, *idx_b = nullptr, *idx_k = nullptr;  // wire index of every A / B / K point
+    G1Aff alpha1, beta1, delta1;
+    G2Aff beta2, delta2;
+};
+
+__global__ void k_gather_fr(Fr *out, const Fr *W, const u32 *idx, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = W[idx[i]];
+}
+
+static int32_t upload(mi_ctx *ctx, void **dst, const void *src, size_t bytes) {
+    MI_CHECK_HIP(ctx, hipMalloc(dst, bytes ? bytes : 32));
+    if (bytes) MI_CHECK_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MI_OK;
+}
+
+static int32_t pk_load_common(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points) {
+    if (!ctx || !d || !out) return MI_EINVAL;
+    *out = nullptr;
+    if (d->log_n > 28 || d->nb_public > d->nb_wires || !d->infinity_a || !d->infinity_b) MI_FAIL(ctx, MI_EINVAL, "pk: bad header");
+    const u64 N = (u64)1 << d->log_n;
+    if (d->n_g1_z + 1 < N) MI_FAIL(ctx, MI_EINVAL, "pk: G1.Z needs at least 2^log_n - 1 points");
+    if (d->nb_wires >= ((u64)1 << 31)) MI_FAIL(ctx, MI_EINVAL, "pk: too many wires");
+    if (d->n_g2_b != d->n_g1_b) MI_FAIL(ctx, MI_EINVAL, "pk: G1.B and G2.B differ in length");
+    // gather indices from the static masks (prove.go: wireValuesA/B filters; K drops public + committed)
+    std::vector<u32> ia, ib, ik;
+    ia.reserve(d->n_g1_a); ib.reserve(d->n_g1_b); ik.reserve(d->n_g1_k);
+    u64 ci = 0;
+    for (u64 j = 0; j < d->nb_wires; j++) {
+        if (!d->infinity_a[j]) ia.push_back((u32)j);
+        if (!d->infinity_b[j]) ib.push_back((u32)j);
+        if (j >= d->nb_public) {
+            while (ci < d->n_committed && d->committed_wires[ci] < j) ci++;
+            if (ci < d->n_committed && d->committed_wires[ci] == j) continue;
+            ik.push_back((u32)j);
+        }
+    }
+    if (ia.size() != d->n_g1_a || ib.size() != d->n_g1_b || ik.size() != d->n_g1_k)
+        MI_FAIL(ctx, MI_EINVAL, "pk: point counts do not match the infinity masks / public / committed wire sets");
+    mi_pk *pk = new (std::nothrow) mi_pk();
+    if (!pk) return MI_ENOMEM;
+    pk->log_n = d->log_n; pk->nb_public = d->nb_public; pk->nb_wires = d->nb_wires;
+    pk->n_a = d->n_g1_a; pk->n_b = d->n_g1_b; pk->n_k = d->n_g1_k; pk->n_z = d->n_g1_z;
+    std::memcpy(&pk->alpha1, &d->alpha1, 64); std::memcpy(&pk->beta1, &d->beta1, 64); std::memcpy(&pk->delta1, &d->delta1, 64);
+    std::memcpy(&pk->beta2, &d->beta2, 128); std::memcpy(&pk->delta2, &d->delta2, 128);
+    int32_t rc = MI_OK;
+    if (device_points) {
+        pk->g1_a = (void *)d->g1_a; pk->g1_b = (void *)d->g1_b; pk->g1_k = (void *)d->g1_k; pk->g1_z = (void *)d->g1_z; pk->g2_b = (void *)d->g2_b;
+    } else {
+        pk->owns_points = true;
+        if (rc == MI_OK) rc = upload(ctx, &pk->g1_a, d->g1_a, d->n_g1_a * 64);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g1_b, d->g1_b, d->n_g1_b * 64);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g1_k, d->g1_k, d->n_g1_k * 64);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g1_z, d->g1_z, d->n_g1_z * 64);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g2_b, d->g2_b, d->n_g2_b * 128);
+    }
+    if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_a, ia.data(), ia.size() * 4);
+    if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_b, ib.data(), ib.size() * 4);
+    if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_k, ik.data(), ik.size() * 4);
+    if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pk upload sync failed"; rc = MI_EHIP; }
+    if (rc != MI_OK) { mi_pk_free(ctx, pk); return rc; }
+    *out = pk;
+    return MI_OK;
+}
+
+// k * p on the host, k canonical 8 x u32
+template <class F>
+static XYZZ<F> host_scalar_mul(const Affine<F> &p, const Fr &k_canon) { return xyzz_mul_256(XYZZ<F>::from_affine(p), k_canon.l); }
+
+extern "C" {
+int32_t mi_pk_load(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out) {
+    if (d && (!d->g1_a && d->n_g1_a)) return MI_EINVAL;
+    return pk_load_common(ctx, d, out, false);
+}
+int32_t mi_pk_load_dev(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out) { return pk_load_common(ctx, d, out, true); }
+int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
+    if (!ctx || !pk) return MI_EINVAL;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (pk->owns_points) for (void *p : {pk->g1_a, pk->g1_b, pk->g1_k, pk->g1_z, pk->g2_b}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)pk->idx_a, (void *)pk->idx_b, (void *)pk->idx_k}) if (p) (void)hipFree(p);
+    delete pk;
+    return MI_OK;
+}
+
+int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                             size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, mi_proof_out *out, mi_stats *stats) {
+    if (!ctx || !pk || !W || !a || !b || !c || !r_m || !s_m || !out) return MI_EINVAL;
+    const size_t N = (size_t)1 << pk->log_n;
+    if (n_wires != pk->nb_wires || n_constraints > N) MI_FAIL(ctx, MI_EINVAL, "prove: witness size does not match the proving key");
+    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    hipEvent_t *ev = ctx->ev;
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+    // step 4: h = computeH(a, b, c)  (bit-reversed, like gnark leaves it)
+    MI_TRY(mi_reserve(ctx, ctx->ws[14], N * sizeof(Fr)));
+    Fr *h = (Fr *)ctx->ws[14].p;
+    MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, c, n_constraints, (mi_fr *)h));
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+    // step 5: wireValuesA / wireValuesB / K scalars by the static gather indices
+    size_t mx = pk->n_a > pk->n_b ? pk->n_a : pk->n_b;
+    if (pk->n_k > mx) mx = pk->n_k;
+    MI_TRY(mi_reserve(ctx, ctx->ws[15], (mx + 1) * sizeof(Fr)));
+    Fr *gath = (Fr *)ctx->ws[15].p;
+    auto gather = [&](const u32 *idx, size_t n) -> int32_t {
+        if (n) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, gath, (const Fr *)W, idx, n);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+        return MI_OK;
+    };
+    // step 7: the five MSMs (each call drains the stream when it downloads its window sums)
+    G1X msm_a, msm_b1, msm_k, msm_z;
+    G2X msm_b2;
+    MI_TRY(gather(pk->idx_a, pk->n_a));
+    MI_TRY(mi_msm_g1_xyzz(ctx, pk->g1_a, gath, pk->n_a, 0, &msm_a));
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
+    MI_TRY(gather(pk->idx_b, pk->n_b));
+    MI_TRY(mi_msm_g1_xyzz(ctx, pk->g1_b, gath, pk->n_b, 0, &msm_b1));
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[5], ctx->stream));
+    MI_TRY(mi_msm_g2_xyzz(ctx, pk->g2_b, gath, pk->n_b, 0, &msm_b2));
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[6], ctx->stream));
+    MI_TRY(gather(pk->idx_k, pk->n_k));
+    MI_TRY(mi_msm_g1_xyzz(ctx, pk->g1_k, gath, pk->n_k, 0, &msm_k));
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[7], ctx->stream));
+    MI_TRY(mi_msm_g1_xyzz(ctx, pk->g1_z, h, N - 1, 0, &msm_z));   // h[:N-1] against the bit-reversed pk.G1.Z
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[8], ctx->stream));
+    // steps 6 + 7 tail: blinding and assembly, O(1) point operations on the host
+    Fr r, s;
+    std::memcpy(&r, r_m, 32); std::memcpy(&s, s_m, 32);
+    Fr rc = fe_from_mont(r), sc = fe_from_mont(s), krc = fe_from_mont(fe_neg(r * s));
+    G1X ar = msm_a;
+    xyzz_madd(ar, pk->alpha1, false);
+    { G1X t = host_scalar_mul<Fp>(pk->delta1, rc); xyzz_add(ar, t); }
+    G1X bs1 = msm_b1;
+    xyzz_madd(bs1, pk->beta1, false);
+    { G1X t = host_scalar_mul<Fp>(pk->delta1, sc); xyzz_add(bs1, t); }
+    G1X krs = msm_k;
+    xyzz_add(krs, msm_z);
+    { G1X t = host_scalar_mul<Fp>(pk->delta1, krc); xyzz_add(krs, t); }
+    G1Aff ar_aff = xyzz_to_affine(ar), bs1_aff = xyzz_to_affine(bs1);
+    { G1X t = host_scalar_mul<Fp>(ar_aff, sc); xyzz_add(krs, t); }
+    { G1X t = host_scalar_mul<Fp>(bs1_aff, rc); xyzz_add(krs, t); }
+    G2X bs = msm_b2;
+    xyzz_madd(bs, pk->beta2, false);
+    { G2X t = host_scalar_mul<Fp2>(pk->delta2, sc); xyzz_add(bs, t); }
+    G1Aff krs_aff = xyzz_to_affine(krs);
+    G2Aff bs_aff = xyzz_to_affine(bs);
+    std::memcpy(&out->ar, &ar_aff, 64); std::memcpy(&out->bs, &bs_aff, 128); std::memcpy(&out->krs, &krs_aff, 64);
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[9], ctx->stream));
+    MI_CHECK_HIP(ctx, hipEventSynchronize(ev[9]));
+    mi_stats &st = ctx->stats;
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.compute_h_ms, ev[2], ev[3]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_a_ms, ev[3], ev[4]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_b1_ms, ev[4], ev[5]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_b2_ms, ev[5], ev[6]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_k_ms, ev[6], ev[7]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_z_ms, ev[7], ev[8]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.assemble_ms, ev[8], ev[9]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.total_ms, ev[2], ev[9]));
+    if (stats) *stats = st;
+    return MI_OK;
+}
+
+int32_t mi_groth16_prove(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                         size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats) {
+    if (!ctx || !pk || !W || !a || !b || !c || !r || !s || !out) return MI_EINVAL;
+    const size_t wb = n_wires * 32, cb = n_constraints * 32;
+    MI_TRY(mi_reserve(ctx, ctx->ws[16], wb + 3 * cb + 128));
+    char *base = (char *)ctx->ws[16].p;
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[10], ctx->stream));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(base, W, wb, hipMemcpyHostToDevice, ctx->stream));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(base + wb, a, cb, hipMemcpyHostToDevice, ctx->stream));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(base + wb + cb, b, cb, hipMemcpyHostToDevice, ctx->stream));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(base + wb + 2 * cb, c, cb, hipMemcpyHostToDevice, ctx->stream));
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[11], ctx->stream));
+    MI_TRY(mi_groth16_prove_dev(ctx, pk, (mi_fr *)base, n_wires, (mi_fr *)(base + wb), (mi_fr *)(base + wb + cb), (mi_fr *)(base + wb + 2 * cb),
+                                n_constraints, r, s, out, nullptr));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.h2d_ms, ctx->ev[10], ctx->ev[11]));
+    if (stats) *stats = ctx->stats;
+    return MI_OK;
+}
+}

@@ -102,3 +102,100 @@ extern "C" int emu_ntt(void *data_v, uint32_t log_n, uint32_t flags, uint32_t lo
     }
     return (int)pl.n_pass;
 }
+
+// ---------------------------------------------------------------- MSM pipeline emulation (msm_core.cuh on the host)
+#include "../../gnark-whir_amd/csrc/msm_core.cuh"
+static void excl_scan(const std::vector<u32> &in, std::vector<u32> &out) {
+    out.resize(in.size() + 1);
+    u32 acc = 0;
+    for (size_t i = 0; i < in.size(); i++) { out[i] = acc; acc += in[i]; }
+    out[in.size()] = acc;
+}
+// runs the item/level machinery until every key is final; returns number of levels
+template <class F>
+static int run_levels(u32 nkeys, std::vector<u32> start, std::vector<u32> cnt, std::vector<u32> items, u32 L,
+                      const Affine<F> *pts, const u32 *sorted, std::vector<XYZZ<F>> partial, std::vector<XYZZ<F>> &bucket, u32 nthr_unused) {
+    int level = 0;
+    for (;;) {
+        std::vector<u32> item_start;
+        excl_scan(items, item_start);
+        u32 total = item_start[nkeys];
+        std::vector<XYZZ<F>> out(total ? total : 1);
+        bool more = false;
+        for (u32 k = 0; k < nkeys; k++) more |= items[k] > 1;
+        for (u32 it = 0; it < total + 3; it++) {  // over-launch like the GPU grid does
+            if (level == 0) msm_accum_affine_body<F>(pts, sorted, start.data(), cnt.data(), items.data(), item_start.data(), nkeys, L, bucket.data(), out.data(), it);
+            else msm_accum_xyzz_body<F>(partial.data(), start.data(), cnt.data(), items.data(), item_start.data(), nkeys, L, bucket.data(), out.data(), it);
+        }
+        level++;
+        if (!more) break;
+        std::vector<u32> s2(nkeys), c2(nkeys), i2(nkeys);
+        for (u32 k = 0; k < nkeys; k++) msm_prep_next(items.data(), item_start.data(), L, s2.data(), c2.data(), i2.data(), k);
+        start = s2; cnt = c2; items = i2; partial = out;
+    }
+    return level;
+}
+template <class F>
+static int emu_msm_t(void *out_v, const void *pts_v, const void *sc_v, u32 n, int mont, u32 c, u32 G, u32 L, u32 seg, u32 nthr) {
+    const Affine<F> *pts = (const Affine<F> *)pts_v;
+    MsmShape s = msm_shape(n, c, G);
+    std::vector<int16_t> digits((size_t)s.nwin * n + 1);
+    for (u32 i = 0; i < n; i++) msm_digits_body(s, (const Fr *)sc_v, mont != 0, digits.data(), i);
+    std::vector<u32> H((size_t)s.nkeys * G), lds(s.nbuckets);
+    for (u32 w = 0; w < s.nwin; w++)
+        for (u32 g = 0; g < G; g++) {
+            for (u32 t = 0; t < nthr; t++) msm_hist_zero(s, lds.data(), t, nthr);
+            for (u32 t = 0; t < nthr; t++) msm_hist_count(s, digits.data(), g, w, lds.data(), t, nthr);
+            for (u32 t = 0; t < nthr; t++) msm_hist_write(s, H.data(), g, w, lds.data(), t, nthr);
+        }
+    std::vector<u32> S;
+    excl_scan(H, S);
+    std::vector<u32> sorted(S.back() + 1);
+    for (u32 w = 0; w < s.nwin; w++)
+        for (u32 g = 0; g < G; g++) {
+            for (u32 t = 0; t < nthr; t++) msm_scatter_init(s, S.data(), g, w, lds.data(), t, nthr);
+            for (u32 t = 0; t < nthr; t++) msm_scatter_move(s, digits.data(), g, w, lds.data(), sorted.data(), t, nthr);
+        }
+    std::vector<u32> start(s.nkeys), cnt(s.nkeys), items(s.nkeys);
+    for (u32 k = 0; k < s.nkeys; k++) msm_prep_level1(s, S.data(), L, start.data(), cnt.data(), items.data(), k);
+    std::vector<XYZZ<F>> bucket(s.nkeys);
+    memset(bucket.data(), 0, sizeof(XYZZ<F>) * s.nkeys);  // zz == 0 : infinity
+    int levels = run_levels<F>(s.nkeys, start, cnt, items, L, pts, sorted.data(), std::vector<XYZZ<F>>(), bucket, nthr);
+    // bucket reduce + reduce by window
+    u32 tb = (s.nbuckets + seg - 1) / seg;
+    std::vector<XYZZ<F>> P((size_t)s.nwin * tb);
+    for (u32 w = 0; w < s.nwin; w++)
+        for (u32 t = 0; t < tb; t++) msm_bucket_reduce_body<F>(bucket.data(), s.nbuckets, seg, P.data(), w, t);
+    std::vector<u32> ws(s.nwin), wc(s.nwin), wi(s.nwin);
+    for (u32 w = 0; w < s.nwin; w++) { ws[w] = w * tb; wc[w] = tb; wi[w] = (tb + L - 1) / L; }
+    std::vector<XYZZ<F>> wsum(s.nwin);
+    memset(wsum.data(), 0, sizeof(XYZZ<F>) * s.nwin);
+    // level machinery over partials: level index starts at 1 (xyzz source)
+    {
+        std::vector<u32> start2 = ws, cnt2 = wc, items2 = wi;
+        std::vector<XYZZ<F>> partial = P;
+        for (;;) {
+            std::vector<u32> item_start;
+            excl_scan(items2, item_start);
+            u32 total = item_start[s.nwin];
+            std::vector<XYZZ<F>> out(total ? total : 1);
+            bool more = false;
+            for (u32 k = 0; k < s.nwin; k++) more |= items2[k] > 1;
+            for (u32 it = 0; it < total + 2; it++)
+                msm_accum_xyzz_body<F>(partial.data(), start2.data(), cnt2.data(), items2.data(), item_start.data(), s.nwin, L, wsum.data(), out.data(), it);
+            if (!more) break;
+            std::vector<u32> s3(s.nwin), c3(s.nwin), i3(s.nwin);
+            for (u32 k = 0; k < s.nwin; k++) msm_prep_next(items2.data(), item_start.data(), L, s3.data(), c3.data(), i3.data(), k);
+            start2 = s3; cnt2 = c3; items2 = i3; partial = out;
+        }
+    }
+    XYZZ<F> tot = msm_combine_windows<F>(wsum.data(), s.nwin, s.c);
+    *(Affine<F> *)out_v = xyzz_to_affine(tot);
+    return levels;
+}
+extern "C" int emu_msm_g1(void *out, const void *pts, const void *sc, uint32_t n, int mont, uint32_t c, uint32_t G, uint32_t L, uint32_t seg, uint32_t nthr) {
+    return emu_msm_t<Fp>(out, pts, sc, n, mont, c, G, L, seg, nthr);
+}
+extern "C" int emu_msm_g2(void *out, const void *pts, const void *sc, uint32_t n, int mont, uint32_t c, uint32_t G, uint32_t L, uint32_t seg, uint32_t nthr) {
+    return emu_msm_t<Fp2>(out, pts, sc, n, mont, c, G, L, seg, nthr);
+}

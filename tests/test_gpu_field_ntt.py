@@ -104,10 +104,10 @@ def test_ntt_roundtrip_and_linearity_at_scale(ctx):
     assert np.array_equal(x.download((n, 4)), x0)
     # linearity on the device: NTT(x) + NTT(y) == NTT(x + y)
     s = ctx.alloc(32 * n)
-    ctx._ck(ctx.lib.mi_field_op_dev(ctx.h, 0, 0, s.ptr, x.ptr, y.ptr, n))
+    ctx.field_op_dev(0, 0, s.ptr, x.ptr, y.ptr, n)
     for d in (x, y, s):
         ctx.ntt_dev(d.ptr, log_n, 0)
-    ctx._ck(ctx.lib.mi_field_op_dev(ctx.h, 0, 0, x.ptr, x.ptr, y.ptr, n))
+    ctx.field_op_dev(0, 0, x.ptr, x.ptr, y.ptr, n)
     assert np.array_equal(x.download((n, 4)), s.download((n, 4)))
     s.free()
     for d in (x, y):

@@ -1,0 +1,173 @@
+"""GPU parity (through the C-ABI): G1/G2 MSM and the full prove path against the oracle and the
+committed golden fixtures, plus size-independent properties at BASELINE sizes."""
+import json
+import os
+import numpy as np
+import pytest
+import pyref as P
+import cref
+from helpers import *
+from gpu_common import load_binding
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+INF_G1 = None
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    B = load_binding()
+    c = B.Context(0)
+    yield c
+    c.close()
+
+
+def _jac_eq(got, want):
+    """both normalised: equal limbs, or both infinity (Z == 0)"""
+    k = got.shape[0] // 3
+    if not want[2 * k:].any():
+        return not got[2 * k:].any()
+    return np.array_equal(got, want)
+
+
+def test_msm_golden_json(ctx):
+    with open(os.path.join(GOLD, "msm.json")) as f:
+        g = json.load(f)
+    for case in g["g1"]:
+        pts = [None if p is None else (int(p[0], 16), int(p[1], 16)) for p in case["points"]]
+        sc = [int(x, 16) for x in case["scalars"]]
+        want = None if case["out"] is None else (int(case["out"][0], 16), int(case["out"][1], 16))
+        assert g1_from_jac(ctx.msm_g1(g1_arr(pts), fr_arr(sc))) == want
+    for case in g["g2"]:
+        unflat = lambda p: None if p is None else ((int(p[0], 16), int(p[1], 16)), (int(p[2], 16), int(p[3], 16)))
+        pts = [unflat(p) for p in case["points"]]
+        sc = [int(x, 16) for x in case["scalars"]]
+        assert g2_from_jac(ctx.msm_g2(g2_arr(pts), fr_arr(sc))) == unflat(case["out"])
+
+
+def test_msm_golden_npz(ctx):
+    for name in ("msm_g1_4096_uniform.npz", "msm_g1_4096_whir.npz"):
+        z = np.load(os.path.join(GOLD, name))
+        assert np.array_equal(ctx.msm_g1(z["points"], z["scalars"])[:8], z["out"])
+    z = np.load(os.path.join(GOLD, "msm_g2_512_whir.npz"))
+    assert np.array_equal(ctx.msm_g2(z["points"], z["scalars"])[:16], z["out"])
+
+
+@pytest.mark.parametrize("n,dist", [(0, 0), (1, 0), (2, 1), (3, 0), (63, 1), (64, 0), (65, 1), (1000, 0), (4097, 1), (50000, 0), (200000, 1)])
+def test_msm_g1_vs_oracle(ctx, n, dist):
+    pts = cref.gen_g1(n, 77 + n); sc = cref.gen_scalars(n, 5 + n, dist)
+    if n > 10:
+        pts[3] = 0; sc[1] = fr_arr([P.R_MOD - 1])[0]; sc[2] = 0; pts[6] = pts[5]; sc[6] = sc[5]
+        pts[8] = g1_arr([P.g1_neg(g1_pts(pts[7:8])[0])])[0]; sc[8] = sc[7]
+    assert _jac_eq(ctx.msm_g1(pts, sc), cref.msm_g1(pts, sc))
+
+
+@pytest.mark.parametrize("n,dist", [(1, 0), (17, 1), (300, 0), (5000, 1)])
+def test_msm_g2_vs_oracle(ctx, n, dist):
+    pts = cref.gen_g2(n, 177 + n); sc = cref.gen_scalars(n, 15 + n, dist)
+    assert _jac_eq(ctx.msm_g2(pts, sc), cref.msm_g2(pts, sc))
+
+
+def test_msm_edge_scalars(ctx):
+    n = 200
+    pts = cref.gen_g1(n, 1)
+    zeros = np.zeros((n, 4), np.uint64)
+    assert not ctx.msm_g1(pts, zeros)[8:].any()                       # all-zero scalars -> infinity
+    ones = fr_arr([1] * n)
+    assert g1_from_jac(ctx.msm_g1(pts, ones)) == P.ec_sum(P.F1, g1_pts(pts))   # plain point sum
+    rm1 = fr_arr([P.R_MOD - 1] * n)
+    assert g1_from_jac(ctx.msm_g1(pts, rm1)) == P.g1_neg(P.ec_sum(P.F1, g1_pts(pts)))
+    allinf = np.zeros((n, 8), np.uint64)
+    assert not ctx.msm_g1(allinf, ones)[8:].any()
+    canon = cref.field_op(0, 5, cref.gen_scalars(n, 9, 1))
+    assert np.array_equal(ctx.msm_g1(pts, canon, flags=1), cref.msm_g1(pts, canon, flags=1))
+
+
+def test_msm_forced_small_windows_many_levels(ctx):
+    """knobs turned down so that every level / window path runs at a size the oracle finishes fast"""
+    lib = ctx.lib
+    try:
+        for (c, L1, L2, seg, G) in ((4, 3, 2, 2, 3), (7, 4, 3, 8, 5), (16, 8, 4, 64, 2), (11, 32, 16, 8, 1)):
+            assert lib.mi_debug_set_msm_plan(ctx.h, c, L1, L2, seg, G) == 0
+            for dist in (0, 1):
+                pts = cref.gen_g1(3000, 31 + c); sc = cref.gen_scalars(3000, 41 + c, dist)
+                assert _jac_eq(ctx.msm_g1(pts, sc), cref.msm_g1(pts, sc)), (c, dist)
+            p2 = cref.gen_g2(300, 51 + c); s2 = cref.gen_scalars(300, 61 + c, 1)
+            assert _jac_eq(ctx.msm_g2(p2, s2), cref.msm_g2(p2, s2)), c
+    finally:
+        assert lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
+
+
+@pytest.mark.parametrize("dist", [0, 1])
+def test_msm_linearity_at_baseline_size(ctx, dist):
+    """n = 2^23 pairs generated on the device: MSM(P, s) + MSM(P, t) == MSM(P, s + t), and
+    MSM over the two halves adds up to the whole (the sharding identity config 5 relies on)."""
+    B = load_binding()
+    n = 1 << 23
+    pts = ctx.gen_g1(n, 11); s = ctx.gen_scalars(n, 12, dist); t = ctx.gen_scalars(n, 13, 0)
+    st = ctx.alloc(32 * n)
+    ctx.field_op_dev(0, 0, st.ptr, s.ptr, t.ptr, n)
+    ms, mt, mst = ctx.msm_g1_dev(pts.ptr, s.ptr, n), ctx.msm_g1_dev(pts.ptr, t.ptr, n), ctx.msm_g1_dev(pts.ptr, st.ptr, n)
+    assert np.array_equal(B.g1_sum(np.stack([ms, mt])), mst)
+    h = n // 2
+    lo = ctx.msm_g1_dev(pts.ptr, s.ptr, h); hi = ctx.msm_g1_dev(pts.ptr + 64 * h, s.ptr + 32 * h, n - h)
+    assert np.array_equal(B.g1_sum(np.stack([lo, hi])), ms)
+    assert np.array_equal(cref.g1_sum(np.stack([lo, hi])), ms)   # the host combine agrees with the oracle's
+    for d in (pts, s, t, st):
+        d.free()
+
+
+def _load_toy():
+    z = np.load(os.path.join(GOLD, "prove_toy1000.npz"))
+    pk = {k: z[k] for k in ("g1_a", "g1_b", "g1_k", "g1_z", "g2_b", "alpha1", "beta1", "delta1", "beta2", "delta2", "infinity_a", "infinity_b")}
+    pk.update(log_n=int(z["log_n"]), nb_public=int(z["nb_public"]), nb_wires=int(z["nb_wires"]))
+    return z, pk
+
+
+def test_prove_golden_toy1000_bytes(ctx):
+    """full proof of the 1000-constraint toy circuit: bit-exact proof bytes (gnark Proof.WriteTo layout)"""
+    B = load_binding()
+    z, pk = _load_toy()
+    pkh = ctx.pk_load(pk)
+    proof, stats = ctx.prove(pkh, z["W"], z["a"], z["b"], z["c"], z["r"], z["s"])
+    assert np.array_equal(proof["ar"], z["ar"]) and np.array_equal(proof["bs"], z["bs"]) and np.array_equal(proof["krs"], z["krs"])
+    assert B.proof_write(proof["raw"]) == bytes(z["proof_bytes"])
+    with open(os.path.join(GOLD, "prove.json")) as f:
+        assert B.proof_write(proof["raw"]).hex() == json.load(f)["proof_bytes"]
+    assert stats["total_ms"] > 0
+    # a second proof on the same resident key, different blinding: must match the oracle again
+    r2, s2 = fr_arr([12345])[0], fr_arr([P.R_MOD - 7])[0]
+    proof2, _ = ctx.prove(pkh, z["W"], z["a"], z["b"], z["c"], r2, s2)
+    want2 = cref.prove(pk, z["W"], z["a"], z["b"], z["c"], r2, s2)
+    assert B.proof_write(proof2["raw"]) == cref.proof_write(want2["raw"])
+    ctx.pk_free(pkh)
+
+
+@pytest.mark.parametrize("log_n,n_committed", [(10, 0), (13, 37), (16, 0)])
+def test_prove_synthetic_vs_oracle(ctx, log_n, n_committed):
+    """shape-faithful synthetic key + witness (infinity masks 10% / 50%, public wires, committed
+    wires removed from K): GPU proof bytes == oracle proof bytes"""
+    B = load_binding()
+    n = 1 << log_n
+    nb_wires, nb_public, n_constraints = n - 13, 41, n - 5
+    pk = synthetic_pk(log_n, nb_wires, nb_public, 900 + log_n, n_committed=n_committed)
+    W = cref.gen_scalars(nb_wires, 1, 1)
+    a = cref.gen_scalars(n_constraints, 2, 1); b = cref.gen_scalars(n_constraints, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    pkh = ctx.pk_load(pk)
+    got, _ = ctx.prove(pkh, W, a, b, c, r, s)
+    want = cref.prove(pk, W, a, b, c, r, s)
+    assert B.proof_write(got["raw"]) == cref.proof_write(want["raw"])
+    ctx.pk_free(pkh)
+
+
+def test_prove_rejects_mismatched_inputs(ctx):
+    z, pk = _load_toy()
+    bad = dict(pk); bad["g1_a"] = pk["g1_a"][:-1]
+    B = load_binding()
+    with pytest.raises(B.MiError):
+        ctx.pk_load(bad)
+    pkh = ctx.pk_load(pk)
+    with pytest.raises(B.MiError):
+        ctx.prove(pkh, z["W"][:-1], z["a"], z["b"], z["c"], z["r"], z["s"])
+    ctx.pk_free(pkh)
