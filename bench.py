@@ -1,0 +1,164 @@
+"""bench.py --gpus N --steps K --warmup W
+
+One step = one full Groth16 prove (computeH: 7 NTTs of size 2^23; 4 G1 MSMs + 1 G2 MSM; blinding and
+assembly) of the synthetic WHIR-verifier-shaped workload of BASELINE.json configs[1] (2^20-variable
+multilinear -> FFT domain N = 2^23) with the proving key, the witness W and the
+solution vectors a, b, c already resident in HBM.  N > 1 GPUs: one independent proof stream per GPU
+(configs[3], no data-path collective) -> weak scaling, value = proofs of all ranks / max-rank time.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant
+kernel (G1 level-1 bucket accumulate) and `cpu_baseline` (the oracle's C restatement on the host cores,
+rank 0, N = 1 only, on a bounded sample).
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _binding():
+    spec = importlib.util.spec_from_file_location("gnark_whir_amd_binding", os.path.join(ROOT, "gnark-whir_amd", "binding.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["gnark_whir_amd_binding"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(log_n_sample, log_n_full):
+    """Times the oracle's prove (oracle/groth16_ref.c, OpenMP) at a reduced domain on this host and
+    scales linearly in N to the benchmark's domain.  The oracle is the checker, never the product."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import cref
+    from helpers import synthetic_pk
+    n = 1 << log_n_sample
+    nb_wires, nb_public, n_constraints = n - 1000, 4097, n - 100
+    pk = synthetic_pk(log_n_sample, nb_wires, nb_public, 0x57484952 + 1)
+    W = cref.gen_scalars(nb_wires, 1, 1)
+    a = cref.gen_scalars(n_constraints, 2, 1); b = cref.gen_scalars(n_constraints, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    t0 = time.perf_counter()
+    cref.prove(pk, W, a, b, c, r, s)
+    dt = time.perf_counter() - t0
+    scale = float(1 << (log_n_full - log_n_sample))
+    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cref.num_threads(), "kind": "port",
+            "sample": f"one full prove of the same synthetic shape at N=2^{log_n_sample} ({dt:.2f} s on {cref.num_threads()} threads), "
+                      f"scaled x{int(scale)} linearly in N to N=2^{log_n_full}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-n", type=int, default=23, help="FFT domain (2^23 = BASELINE configs[1])")
+    ap.add_argument("--dist", choices=["whir", "uniform"], default="whir")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=18)
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B = _binding()
+    ctx = B.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+
+    # ---- synthetic workload, generated on the device: seed "WHIR" + config index
+    import numpy as np
+    log_n = args.log_n
+    N = 1 << log_n
+    seed = 0x57484952 + 1 + 1000 * rank
+    nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
+    rng = np.random.default_rng(seed)
+    inf_a = (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8)
+    inf_b = (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
+    na, nb, nk = int((inf_a == 0).sum()), int((inf_b == 0).sum()), nb_wires - nb_public
+    dist_id = 1 if args.dist == "whir" else 0
+    g1a, g1b, g1k, g1z = ctx.gen_g1(na, seed + 1), ctx.gen_g1(nb, seed + 2), ctx.gen_g1(nk, seed + 3), ctx.gen_g1(N, seed + 4)
+    g2b = ctx.gen_g2(nb, seed + 5)
+    small = ctx.gen_g1(3, seed + 6).download((3, 8)); small2 = ctx.gen_g2(2, seed + 7).download((2, 16))
+    pk = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires,
+          "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk), "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb),
+          "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0], "delta2": small2[1],
+          "infinity_a": inf_a, "infinity_b": inf_b}
+    pkh = ctx.pk_load(pk, device_points=True)
+    W = ctx.gen_scalars(nb_wires, seed + 8, dist_id)
+    a = ctx.gen_scalars(n_constraints, seed + 9, dist_id); b = ctx.gen_scalars(n_constraints, seed + 10, 0)
+    c = ctx.alloc(32 * n_constraints)
+    ctx.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)   # c = a*b so that (a, b, c) is a satisfied R1CS row set
+    rs = ctx.gen_scalars(2, seed + 11, 0).download((2, 4))
+    ctx.sync()
+
+    def step():
+        return ctx.prove(pkh, W.ptr, a.ptr, b.ptr, c.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    accum_ms, accum_pairs, accum_launches, last = 0.0, 0, 0, None
+    for _ in range(args.steps):
+        proof, st = step()
+        accum_ms += st["g1_accum_kernel_ms"]; accum_pairs += st["g1_accum_pairs"]; accum_launches += st["g1_accum_launches"]; last = st
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        proofs = args.steps * world
+        # dominant kernel: G1 level-1 bucket accumulate; algorithmic bytes = 96 B per (point, scalar) pair
+        per_launch_ms = accum_ms / max(accum_launches, 1)
+        per_launch_bytes = 96.0 * accum_pairs / max(accum_launches, 1)
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+        g1_pairs_per_proof = na + nb + nk + (N - 1)
+        g1_msm_ms = last["msm_a_ms"] + last["msm_b1_ms"] + last["msm_k_ms"] + last["msm_z_ms"]
+        line = {
+            "metric": "Groth16 proofs/sec for WHIR-verifier circuit (2^20 poly); G1 MSM pts/sec",
+            "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8 Montgomery (BN254 Fr/Fp, exact modular integers)", "data": "synthetic",
+            "config": {"workload": f"full Groth16 prove, WHIR-verifier-shaped synthetic key/witness, FFT domain N=2^{log_n} "
+                                   f"(BASELINE configs[1]; configs[3] = one such proof stream per GPU when n_gpus>1)",
+                       "nb_wires": nb_wires, "nb_public": nb_public, "n_constraints": n_constraints, "scalar_dist": args.dist,
+                       "g1_msm_sizes": [na, nb, nk, N - 1], "g2_msm_size": nb},
+            "g1_msm_pts_per_s": g1_pairs_per_proof / (g1_msm_ms * 1e-3),
+            "phase_ms": {k: last[k] for k in ("compute_h_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "msm_k_ms", "msm_z_ms", "assemble_ms", "total_ms")},
+            "roofline": {"kernel": "k_msm_accum_affine<Fp> (G1 level-1 bucket accumulate)", "bound": "hbm", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, log_n)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    ctx.pk_free(pkh)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
