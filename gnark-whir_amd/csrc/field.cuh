@@ -127,32 +127,75 @@ MI_HD Fe<P> fe_neg(const Fe<P> &x) {
 template <class P>
 MI_HD Fe<P> fe_dbl(const Fe<P> &x) { return x + x; }
 
-// Montgomery product x*y/R mod p, no-carry CIOS over 32-bit limbs.
+// ---- 96-bit column accumulator primitive: (c : acc) += a * b
+// Device: one v_mad_u64_u32 into an even-aligned 64-bit pair plus one v_addc for the carry word; the
+// operands never leave their registers (the compiler's own lowering of the row-wise CIOS spent ~350
+// v_mov per product re-aligning 64-bit pairs).  Host (tests): the same arithmetic in plain C++.
+MI_HD void mac96(u64 &acc, u32 &c, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 cy;
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %0\n\tv_addc_co_u32_e64 %2, %1, 0, %2, %1"
+        : "+v"(acc), "=&s"(cy), "+v"(c)
+        : "v"(a), "v"(b));
+#else
+    u64 p = (u64)a * b;
+    acc += p;
+    c += acc < p;
+#endif
+}
+// modulus limb as the second factor: kept in an SGPR on the device (one scalar operand is legal)
+MI_HD void mac96_k(u64 &acc, u32 &c, u32 a, u32 k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 cy;
+    asm("v_mad_u64_u32 %0, %1, %3, %4, %0\n\tv_addc_co_u32_e64 %2, %1, 0, %2, %1"
+        : "+v"(acc), "=&s"(cy), "+v"(c)
+        : "v"(a), "s"(k));
+#else
+    mac96(acc, c, a, k);
+#endif
+}
+// first product of a column: acc < 2^37 on entry, so the sum cannot wrap -> no carry word update
+MI_HD void mac96_first(u64 &acc, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 cy;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=&s"(cy) : "v"(a), "v"(b));
+#else
+    acc += (u64)a * b;
+#endif
+}
+
+// Montgomery product x*y/R mod p: product scanning (column-wise, "FIPS") over 32-bit limbs with a
+// 96-bit accumulator.  Column k collects x_i*y_(k-i) and m_i*p_(k-i); m_k makes the column's low word 0.
 template <class P>
 MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
-    u32 t[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 a = (u64)x.l[0] * y.l[i] + t[0];
-        u32 m = (u32)a * P::inv;
-        u64 c = (u64)m * P::p[0] + (u32)a;
-        a >>= 32;
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            a += (u64)x.l[j] * y.l[i] + t[j];
-            c += (u64)m * P::p[j] + (u32)a;
-            t[j - 1] = (u32)c;
-            a >>= 32;
-            c >>= 32;
-        }
-        t[7] = (u32)(a + c);
-    }
+    u64 acc = 0;
+    u32 c = 0;
+    u32 m[8];
     Fe<P> r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    for (int k = 0; k < 8; k++) {
+        mac96_first(acc, x.l[0], y.l[k]);
+#pragma unroll
+        for (int i = 1; i <= k; i++) mac96(acc, c, x.l[i], y.l[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mac96_k(acc, c, m[i], P::p[k - i]);
+        m[k] = (u32)acc * P::inv;
+        mac96_k(acc, c, m[k], P::p[0]);
+        acc = (acc >> 32) | ((u64)c << 32);
+        c = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 15; k++) {
+        mac96_first(acc, x.l[k - 7], y.l[7]);
+#pragma unroll
+        for (int i = k - 6; i < 8; i++) mac96(acc, c, x.l[i], y.l[k - i]);
+#pragma unroll
+        for (int i = k - 7; i < 8; i++) mac96_k(acc, c, m[i], P::p[k - i]);
+        r.l[k - 8] = (u32)acc;
+        acc = (acc >> 32) | ((u64)c << 32);
+        c = 0;
+    }
+    r.l[7] = (u32)acc;   // column 15 is empty for 8-limb operands; p < 2^254 keeps the result < 2p < 2^256
     return fe_reduce_once(r);
 }
 template <class P>
