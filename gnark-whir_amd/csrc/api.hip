@@ -34,6 +34,7 @@ int32_t mi_shutdown(mi_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto &b : ctx->ws) if (b.p) hipFree(b.p);
     mi_ntt_state_free(ctx);
+    mi_msm_state_free(ctx);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

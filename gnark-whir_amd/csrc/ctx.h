@@ -11,6 +11,16 @@ struct DevBuf {             // growable device scratch owned by the ctx (no hipM
     size_t cap = 0;
 };
 
+#define MI_MSM_SLOTS 6
+struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, workspaces, pinned result
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job
+    DevBuf buf[10];
+    void *host_wsum = nullptr;
+    uint32_t n = 0, c = 0, G = 0;
+    bool active = false, timed = false;
+};
+
 struct mi_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -21,7 +31,8 @@ struct mi_ctx {
     // scratch
     alignas(16) unsigned char ntt_state[256];  // NttState (ntt.hip): root tables + plan knobs
     alignas(16) unsigned char msm_knobs[64];   // MsmKnobs (msm.hip)
-    DevBuf ws[24];          // MSM / prove workspaces, see msm.hip / prove.hip
+    DevBuf ws[24];
+    MsmSlot msm[MI_MSM_SLOTS];          // MSM / prove workspaces, see msm.hip / prove.hip
     int cu_count = 256;
 };
 
@@ -61,6 +72,11 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
 void mi_ntt_state_init(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);
 void mi_msm_state_init(mi_ctx *ctx);
-// MSM returning the XYZZ result on the host (used by prove.hip); pts/scalars are device pointers
-int32_t mi_msm_g1_xyzz(mi_ctx *ctx, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, void *out_xyzz_host);
-int32_t mi_msm_g2_xyzz(mi_ctx *ctx, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, void *out_xyzz_host);
+void mi_msm_state_free(mi_ctx *ctx);
+// Asynchronous MSM on slot `slot` (curve 1 = G1, 2 = G2; device pointers).  sort_slot < 0: sort the scalars
+// here; otherwise reuse the sort already enqueued on that slot (same scalars, other bases).  wait_ev (may be
+// null) orders the slot's stream after the producer of its inputs.  mi_msm_finish blocks on the slot and
+// returns the XYZZ result on the host.
+int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
+                       uint32_t flags, hipEvent_t wait_ev, bool timed);
+int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host);

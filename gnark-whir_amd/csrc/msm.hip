@@ -23,12 +23,6 @@ struct MsmKnobs {
 static MsmKnobs *knobs_of(mi_ctx *ctx) { return reinterpret_cast<MsmKnobs *>(ctx->msm_knobs); }
 __global__ void k_msm_hist(MsmShape s, const int16_t *digits, u32 *H);
 __global__ void k_msm_scatter(MsmShape s, const int16_t *digits, const u32 *S, u32 *sorted);
-void mi_msm_state_init(mi_ctx *ctx) {
-    new (ctx->msm_knobs) MsmKnobs();
-    // the c = 16 histogram / cursor image is 128 KiB of LDS (gfx950 allows 160 KiB per workgroup)
-    (void)hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
 
 // ---------------------------------------------------------------- kernels
 __global__ void k_msm_digits(MsmShape s, const Fr *scalars, int montgomery, int16_t *digits) {
@@ -135,21 +129,24 @@ __global__ void __launch_bounds__(256) k_scan_final(const u32 *in, size_t m, con
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = block_sums[gridDim.x];
 }
-static int32_t exclusive_scan(mi_ctx *ctx, const u32 *in, size_t m, u32 *out, DevBuf &tmp) {
+static int32_t exclusive_scan(mi_ctx *ctx, hipStream_t st, const u32 *in, size_t m, u32 *out, DevBuf &tmp) {
     u32 nblocks = (u32)((m + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (nblocks == 0) nblocks = 1;
     MI_TRY(mi_reserve(ctx, tmp, (size_t)(nblocks + 1) * 4));
     u32 *bs = (u32 *)tmp.p;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(256), 0, ctx->stream, in, m, bs);
-    hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, ctx->stream, bs, nblocks);
-    hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(256), 0, ctx->stream, in, m, bs, out);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(256), 0, st, in, m, bs);
+    hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, st, bs, nblocks);
+    hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(256), 0, st, in, m, bs, out);
     MI_CHECK_HIP(ctx, hipGetLastError());
     return MI_OK;
 }
 
 // ---------------------------------------------------------------- orchestration
-// workspace slots (ctx->ws): 4 digits, 5 H, 6 S, 7 sorted, 8 level arrays, 9/10 partial ping-pong,
-// 11 buckets, 12 scan temp, 13 window partials / sums
+// An MSM is enqueued asynchronously on the stream of a *slot* (ctx->msm[i]): sort stage, accumulate
+// stage, async copy of the <= 128 window sums into pinned host memory.  Nothing blocks the host until
+// mi_msm_finish.  Several slots run concurrently (prove.hip puts the five MSMs on five streams so the
+// latency-bound tails of one overlap the throughput-bound accumulation of another), and an accumulate
+// stage may reuse another slot's sort (pk.G1.B and pk.G2.B are multiplied by the same scalars).
 struct LevelArrays { u32 *start, *cnt, *items, *item_start; };
 
 static u32 auto_c(u32 n) {
@@ -160,33 +157,59 @@ static u32 auto_c(u32 n) {
     if (c > 16) c = 16;
     return (u32)c;
 }
+static MsmShape slot_shape(const MsmSlot &sl) { return msm_shape(sl.n, sl.c, sl.G); }
+
+void mi_msm_state_init(mi_ctx *ctx) {
+    new (ctx->msm_knobs) MsmKnobs();
+    // the c = 16 histogram / cursor image is 128 KiB of LDS (gfx950 allows 160 KiB per workgroup)
+    (void)hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (auto &sl : ctx->msm) {
+        (void)hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+        for (auto &e : sl.ev) (void)hipEventCreate(&e);
+        (void)hipHostMalloc(&sl.host_wsum, 128 * 256);
+    }
+}
+void mi_msm_state_free(mi_ctx *ctx) {
+    for (auto &sl : ctx->msm) {
+        if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
+        for (auto &e : sl.ev) if (e) (void)hipEventDestroy(e);
+        if (sl.host_wsum) (void)hipHostFree(sl.host_wsum);
+        for (auto &b : sl.buf) if (b.p) (void)hipFree(b.p);
+    }
+}
+
+// slot buffers
+enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_COUNT_ };
 
 // Runs levels of the item machinery over `nkeys` keys whose level-0 decomposition (start/cnt/items) is
-// already in cur.  first_affine: level 0 reads (pts, sorted); else level 0 reads partial_first.
+// already in cur.  Level 0 reads (pts, sorted) when pts != null, else partial_first.
 template <class F>
-static int32_t run_levels(mi_ctx *ctx, u32 nkeys, LevelArrays cur, LevelArrays nxt, u64 first_items_bound, u64 max_count, u32 L_first, u32 L_next,
-                          const Affine<F> *pts, const u32 *sorted, const XYZZ<F> *partial_first, XYZZ<F> *final_out, bool time_first) {
+static int32_t run_levels(mi_ctx *ctx, MsmSlot &sl, u32 nkeys, LevelArrays cur, LevelArrays nxt, u64 first_items_bound, u64 max_count,
+                          u32 L_first, u32 L_next, const Affine<F> *pts, const u32 *sorted, const XYZZ<F> *partial_first,
+                          XYZZ<F> *final_out, bool time_first) {
+    hipStream_t st = sl.stream;
     const XYZZ<F> *pin = partial_first;
     u64 items_bound = first_items_bound;
     u64 m = max_count;  // bound on entries of the largest key at this level
     u32 L = L_first;
     for (u32 level = 0;; level++) {
-        MI_TRY(exclusive_scan(ctx, cur.items, nkeys, cur.item_start, ctx->ws[12]));
-        DevBuf &pout_buf = ctx->ws[(level & 1) ? 10 : 9];
+        MI_TRY(exclusive_scan(ctx, st, cur.items, nkeys, cur.item_start, sl.buf[B_SCAN]));
+        DevBuf &pout_buf = sl.buf[(level & 1) ? B_PART1 : B_PART0];
         MI_TRY(mi_reserve(ctx, pout_buf, (items_bound + 1) * sizeof(XYZZ<F>)));
         XYZZ<F> *pout = (XYZZ<F> *)pout_buf.p;
         u32 grid = (u32)((items_bound + 63) / 64);
         if (grid == 0) grid = 1;
-        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[20], ctx->stream));
+        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
         if (level == 0 && pts)
-            hipLaunchKernelGGL(k_msm_accum_affine<F>, dim3(grid), dim3(64), 0, ctx->stream, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+            hipLaunchKernelGGL(k_msm_accum_affine<F>, dim3(grid), dim3(64), 0, st, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else
-            hipLaunchKernelGGL(k_msm_accum_xyzz<F>, dim3(grid), dim3(64), 0, ctx->stream, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+            hipLaunchKernelGGL(k_msm_accum_xyzz<F>, dim3(grid), dim3(64), 0, st, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         MI_CHECK_HIP(ctx, hipGetLastError());
-        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[21], ctx->stream));
+        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], st));
         u64 m_next = (m + L - 1) / L;  // entries of the largest key at the next level
         if (m_next <= 1) break;
-        hipLaunchKernelGGL(k_msm_prep_next, dim3((nkeys + 255) / 256), dim3(256), 0, ctx->stream, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt, nxt.items);
+        hipLaunchKernelGGL(k_msm_prep_next, dim3((nkeys + 255) / 256), dim3(256), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt, nxt.items);
         MI_CHECK_HIP(ctx, hipGetLastError());
         // items at the next level: every continuing key has >= 2 entries, so items <= entries/L + keys
         u64 nb = items_bound / L_next + (items_bound < nkeys ? items_bound : nkeys) + 1;
@@ -197,74 +220,108 @@ static int32_t run_levels(mi_ctx *ctx, u32 nkeys, LevelArrays cur, LevelArrays n
     return MI_OK;
 }
 
-template <class F>
-static int32_t msm_run(mi_ctx *ctx, const Affine<F> *pts, const Fr *scalars, size_t n_sz, u32 flags, XYZZ<F> *result_host, bool count_stats) {
-    if (n_sz == 0) { *result_host = XYZZ<F>::inf(); return MI_OK; }
-    if (n_sz > ((size_t)1 << 27)) MI_FAIL(ctx, MI_EINVAL, "msm: n > 2^27 pairs per device not supported (shard the points)");
-    const u32 n = (u32)n_sz;
+// sort stage on slot sl: digits + counting sort of (key -> point index | sign).  Records sl.ev[0].
+static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags) {
     MsmKnobs *kn = knobs_of(ctx);
-    const u32 c = kn->c ? kn->c : auto_c(n);
-    u32 G = kn->G ? kn->G : (n / 8192 > 64 ? 64 : (n / 8192 ? n / 8192 : 1));
-    const u32 L1 = kn->L1 ? kn->L1 : 32, L2 = kn->L2 ? kn->L2 : 16;
-    const MsmShape s = msm_shape(n, c, G);
-    const u32 seg = kn->seg ? kn->seg : (s.nbuckets >= 256 ? 8 : 2);
+    sl.n = n;
+    sl.c = kn->c ? kn->c : auto_c(n);
+    sl.G = kn->G ? kn->G : (n / 8192 > 64 ? 64 : (n / 8192 ? n / 8192 : 1));
+    const MsmShape s = slot_shape(sl);
     const u64 T_bound = (u64)s.nwin * n;
-
-    MI_TRY(mi_reserve(ctx, ctx->ws[4], T_bound * 2 + 64));
-    MI_TRY(mi_reserve(ctx, ctx->ws[5], ((size_t)s.nkeys * G + 1) * 4));
-    MI_TRY(mi_reserve(ctx, ctx->ws[6], ((size_t)s.nkeys * G + 1) * 4));
-    MI_TRY(mi_reserve(ctx, ctx->ws[7], (T_bound + 1) * 4));
-    MI_TRY(mi_reserve(ctx, ctx->ws[8], ((size_t)s.nkeys + 1) * 4 * 8));
-    MI_TRY(mi_reserve(ctx, ctx->ws[11], (size_t)s.nkeys * sizeof(XYZZ<F>)));
-    int16_t *digits = (int16_t *)ctx->ws[4].p;
-    u32 *H = (u32 *)ctx->ws[5].p, *S = (u32 *)ctx->ws[6].p, *sorted = (u32 *)ctx->ws[7].p;
-    u32 *la = (u32 *)ctx->ws[8].p;
-    const size_t stride = (size_t)s.nkeys + 1;
-    LevelArrays A{la, la + stride, la + 2 * stride, la + 3 * stride}, B{la + 4 * stride, la + 5 * stride, la + 6 * stride, la + 7 * stride};
-    XYZZ<F> *bucket = (XYZZ<F> *)ctx->ws[11].p;
-
-    // 1. digits
-    hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, s, scalars, (flags & MI_MSM_SCALARS_CANONICAL) ? 0 : 1, digits);
-    // 2. counting sort
-    const size_t lds_bytes = (size_t)s.nbuckets * 4;
-    hipLaunchKernelGGL(k_msm_hist, dim3(G, s.nwin), dim3(1024), lds_bytes, ctx->stream, s, digits, H);
-    MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(exclusive_scan(ctx, H, (size_t)s.nkeys * G, S, ctx->ws[12]));
-    hipLaunchKernelGGL(k_msm_scatter, dim3(G, s.nwin), dim3(1024), lds_bytes, ctx->stream, s, digits, S, sorted);
-    // 3. accumulate
-    MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * sizeof(XYZZ<F>), ctx->stream));
-    hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 255) / 256), dim3(256), 0, ctx->stream, s, S, L1, A.start, A.cnt, A.items);
-    MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(run_levels<F>(ctx, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, n, L1, L2, pts, sorted, nullptr, bucket, count_stats));
-    // 4. bucket reduce -> per-window partials -> window sums
-    const u32 tb = (s.nbuckets + seg - 1) / seg;
-    MI_TRY(mi_reserve(ctx, ctx->ws[13], ((size_t)s.nwin * tb + s.nwin + 1) * sizeof(XYZZ<F>)));
-    XYZZ<F> *P = (XYZZ<F> *)ctx->ws[13].p, *wsum = P + (size_t)s.nwin * tb;
-    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3((tb + 63) / 64, s.nwin), dim3(64), 0, ctx->stream, bucket, s.nbuckets, seg, tb, P);
-    hipLaunchKernelGGL(k_msm_prep_windows, dim3(1), dim3(128), 0, ctx->stream, s.nwin, tb, L2, A.start, A.cnt, A.items);
-    MI_CHECK_HIP(ctx, hipGetLastError());
     if (s.nwin > 128) MI_FAIL(ctx, MI_EINVAL, "msm: too many windows");
-    MI_TRY(run_levels<F>(ctx, s.nwin, A, B, (u64)s.nwin * ((tb + L2 - 1) / L2) + 1, tb, L2, L2, (const Affine<F> *)nullptr, nullptr, P, wsum, false));
-    // 5. window sums -> host, Horner
-    XYZZ<F> hw[128];
-    MI_CHECK_HIP(ctx, hipMemcpyAsync(hw, wsum, sizeof(XYZZ<F>) * s.nwin, hipMemcpyDeviceToHost, ctx->stream));
-    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *result_host = msm_combine_windows<F>(hw, s.nwin, s.c);
-    if (count_stats) {
-        float ms = 0;
-        MI_CHECK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[20], ctx->ev[21]));
-        ctx->stats.g1_accum_kernel_ms += ms;
-        ctx->stats.g1_accum_pairs += n;
-        ctx->stats.g1_accum_launches += 1;
-    }
+    MI_TRY(mi_reserve(ctx, sl.buf[B_DIGITS], T_bound * 2 + 64));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_H], ((size_t)s.nkeys * s.nslices + 1) * 4));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_S], ((size_t)s.nkeys * s.nslices + 1) * 4));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_SORTED], (T_bound + 1) * 4));
+    int16_t *digits = (int16_t *)sl.buf[B_DIGITS].p;
+    u32 *H = (u32 *)sl.buf[B_H].p, *S = (u32 *)sl.buf[B_S].p, *sorted = (u32 *)sl.buf[B_SORTED].p;
+    hipStream_t st = sl.stream;
+    hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, s, scalars, (flags & MI_MSM_SCALARS_CANONICAL) ? 0 : 1, digits);
+    const size_t lds_bytes = (size_t)s.nbuckets * 4;
+    hipLaunchKernelGGL(k_msm_hist, dim3(s.nslices, s.nwin), dim3(1024), lds_bytes, st, s, digits, H);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(exclusive_scan(ctx, st, H, (size_t)s.nkeys * s.nslices, S, sl.buf[B_SCAN]));
+    hipLaunchKernelGGL(k_msm_scatter, dim3(s.nslices, s.nwin), dim3(1024), lds_bytes, st, s, digits, S, sorted);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[0], st));
     return MI_OK;
 }
 
-int32_t mi_msm_g1_xyzz(mi_ctx *ctx, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, void *out_xyzz_host) {
-    return msm_run<Fp>(ctx, (const G1Aff *)pts_dev, (const Fr *)scalars_dev, n, flags, (G1X *)out_xyzz_host, true);
+// accumulate stage on slot acc, reading the sort of slot srt (may be the same slot)
+template <class F>
+static int32_t msm_accum_enqueue(mi_ctx *ctx, MsmSlot &srt, MsmSlot &acc, const Affine<F> *pts, bool timed) {
+    MsmKnobs *kn = knobs_of(ctx);
+    acc.n = srt.n; acc.c = srt.c; acc.G = srt.G;
+    const MsmShape s = slot_shape(srt);
+    const u32 n = s.n;
+    const u32 L1 = kn->L1 ? kn->L1 : 32, L2 = kn->L2 ? kn->L2 : 16;
+    const u32 seg = kn->seg ? kn->seg : (s.nbuckets >= 256 ? 8 : 2);
+    const u64 T_bound = (u64)s.nwin * n;
+    hipStream_t st = acc.stream;
+    if (&srt != &acc) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, srt.ev[0], 0));
+    MI_TRY(mi_reserve(ctx, acc.buf[B_LEVELS], ((size_t)s.nkeys + 1) * 4 * 8));
+    MI_TRY(mi_reserve(ctx, acc.buf[B_BUCKET], (size_t)s.nkeys * sizeof(XYZZ<F>)));
+    const u32 *S = (const u32 *)srt.buf[B_S].p, *sorted = (const u32 *)srt.buf[B_SORTED].p;
+    u32 *la = (u32 *)acc.buf[B_LEVELS].p;
+    const size_t stride = (size_t)s.nkeys + 1;
+    LevelArrays A{la, la + stride, la + 2 * stride, la + 3 * stride}, B{la + 4 * stride, la + 5 * stride, la + 6 * stride, la + 7 * stride};
+    XYZZ<F> *bucket = (XYZZ<F> *)acc.buf[B_BUCKET].p;
+    MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * sizeof(XYZZ<F>), st));
+    hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, S, L1, A.start, A.cnt, A.items);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(run_levels<F>(ctx, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, n, L1, L2, pts, sorted, nullptr, bucket, timed));
+    // bucket reduce -> per-window partials -> window sums -> pinned host memory
+    const u32 tb = (s.nbuckets + seg - 1) / seg;
+    MI_TRY(mi_reserve(ctx, acc.buf[B_WIN], ((size_t)s.nwin * tb + s.nwin + 1) * sizeof(XYZZ<F>)));
+    XYZZ<F> *P = (XYZZ<F> *)acc.buf[B_WIN].p, *wsum = P + (size_t)s.nwin * tb;
+    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3((tb + 63) / 64, s.nwin), dim3(64), 0, st, bucket, s.nbuckets, seg, tb, P);
+    hipLaunchKernelGGL(k_msm_prep_windows, dim3(1), dim3(128), 0, st, s.nwin, tb, L2, A.start, A.cnt, A.items);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(run_levels<F>(ctx, acc, s.nwin, A, B, (u64)s.nwin * ((tb + L2 - 1) / L2) + 1, tb, L2, L2, (const Affine<F> *)nullptr, nullptr, P, wsum, false));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(acc.host_wsum, wsum, sizeof(XYZZ<F>) * s.nwin, hipMemcpyDeviceToHost, st));
+    MI_CHECK_HIP(ctx, hipEventRecord(acc.ev[4], st));
+    acc.timed = timed;
+    acc.active = true;
+    return MI_OK;
 }
-int32_t mi_msm_g2_xyzz(mi_ctx *ctx, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, void *out_xyzz_host) {
-    return msm_run<Fp2>(ctx, (const G2Aff *)pts_dev, (const Fr *)scalars_dev, n, flags, (G2X *)out_xyzz_host, false);
+
+template <class F>
+static int32_t msm_finish(mi_ctx *ctx, MsmSlot &sl, XYZZ<F> *out) {
+    if (!sl.active) { *out = XYZZ<F>::inf(); return MI_OK; }
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(sl.stream));
+    const MsmShape s = slot_shape(sl);
+    *out = msm_combine_windows<F>((const XYZZ<F> *)sl.host_wsum, s.nwin, s.c);   // Horner on the host, <= 128 points
+    if (sl.timed) {
+        float ms = 0;
+        MI_CHECK_HIP(ctx, hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
+        ctx->stats.g1_accum_kernel_ms += ms;
+        ctx->stats.g1_accum_pairs += sl.n;
+        ctx->stats.g1_accum_launches += 1;
+    }
+    sl.active = false;
+    return MI_OK;
+}
+
+// internal entry points used by prove.hip (curve: 1 = G1, 2 = G2)
+int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
+                       uint32_t flags, hipEvent_t wait_ev, bool timed) {
+    if (slot < 0 || slot >= MI_MSM_SLOTS || sort_slot >= MI_MSM_SLOTS) return MI_EINVAL;
+    if (n > ((size_t)1 << 27)) MI_FAIL(ctx, MI_EINVAL, "msm: n > 2^27 pairs per device not supported (shard the points)");
+    MsmSlot &sl = ctx->msm[slot];
+    sl.active = false;
+    if (n == 0) return MI_OK;
+    if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
+    MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
+    MsmSlot &srt = sort_slot >= 0 ? ctx->msm[sort_slot] : sl;
+    if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags));
+    else if (srt.n != n) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
+    if (curve == 1) return msm_accum_enqueue<Fp>(ctx, srt, sl, (const G1Aff *)pts_dev, timed);
+    return msm_accum_enqueue<Fp2>(ctx, srt, sl, (const G2Aff *)pts_dev, timed);
+}
+int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host) {
+    if (slot < 0 || slot >= MI_MSM_SLOTS) return MI_EINVAL;
+    if (curve == 1) return msm_finish<Fp>(ctx, ctx->msm[slot], (G1X *)out_xyzz_host);
+    return msm_finish<Fp2>(ctx, ctx->msm[slot], (G2X *)out_xyzz_host);
 }
 
 template <class F, class JacT>
@@ -274,8 +331,21 @@ static void xyzz_to_jac_out(const XYZZ<F> &r, JacT *out) {
     else { Affine<F> a = xyzz_to_affine(r); j = Jac<F>{a.x, a.y, F::one()}; }
     std::memcpy(out, &j, sizeof(j));
 }
+// one MSM through slot 0, ordered after everything already queued on ctx->stream
+template <class F, class JacT>
+static int32_t msm_dev_entry(mi_ctx *ctx, int curve, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, JacT *out) {
+    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pts_dev, scalars_dev, n, flags, ctx->ev[0], curve == 1));
+    if (n) MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->msm[0].stream));
+    XYZZ<F> r;
+    MI_TRY(mi_msm_finish(ctx, 0, curve, &r));
+    if (n) MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.total_ms, ctx->ev[0], ctx->ev[1]));
+    xyzz_to_jac_out<F>(r, out);
+    return MI_OK;
+}
 template <class F, class AffT, class JacT>
-static int32_t msm_host_entry(mi_ctx *ctx, const AffT *pts, const mi_fr *scalars, size_t n, uint32_t flags, JacT *out, bool g1) {
+static int32_t msm_host_entry(mi_ctx *ctx, int curve, const AffT *pts, const mi_fr *scalars, size_t n, uint32_t flags, JacT *out) {
     if (!ctx || !out || ((!pts || !scalars) && n) || (flags & ~1u)) return MI_EINVAL;
     MI_TRY(mi_reserve(ctx, ctx->ws[2], n * sizeof(AffT) + 64));
     MI_TRY(mi_reserve(ctx, ctx->ws[3], n * sizeof(mi_fr) + 64));
@@ -283,11 +353,7 @@ static int32_t msm_host_entry(mi_ctx *ctx, const AffT *pts, const mi_fr *scalars
         MI_CHECK_HIP(ctx, hipMemcpyAsync(ctx->ws[2].p, pts, n * sizeof(AffT), hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipMemcpyAsync(ctx->ws[3].p, scalars, n * sizeof(mi_fr), hipMemcpyHostToDevice, ctx->stream));
     }
-    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
-    XYZZ<F> r;
-    MI_TRY(msm_run<F>(ctx, (const Affine<F> *)ctx->ws[2].p, (const Fr *)ctx->ws[3].p, n, flags, &r, g1));
-    xyzz_to_jac_out<F>(r, out);
-    return MI_OK;
+    return msm_dev_entry<F>(ctx, curve, ctx->ws[2].p, ctx->ws[3].p, n, flags, out);
 }
 
 extern "C" {
@@ -298,33 +364,17 @@ int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2,
     return MI_OK;
 }
 int32_t mi_msm_g1(mi_ctx *ctx, const mi_g1_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags, mi_g1_jac *out) {
-    return msm_host_entry<Fp>(ctx, pts, scalars, n, flags, out, true);
+    return msm_host_entry<Fp>(ctx, 1, pts, scalars, n, flags, out);
 }
 int32_t mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags, mi_g2_jac *out) {
-    return msm_host_entry<Fp2>(ctx, pts, scalars, n, flags, out, false);
+    return msm_host_entry<Fp2>(ctx, 2, pts, scalars, n, flags, out);
 }
 int32_t mi_msm_g1_dev(mi_ctx *ctx, const mi_g1_affine *pts_dev, const mi_fr *scalars_dev, size_t n, uint32_t flags, mi_g1_jac *out) {
     if (!ctx || !out || ((!pts_dev || !scalars_dev) && n) || (flags & ~1u)) return MI_EINVAL;
-    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
-    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    G1X r;
-    MI_TRY(msm_run<Fp>(ctx, (const G1Aff *)pts_dev, (const Fr *)scalars_dev, n, flags, &r, true));
-    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    MI_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.total_ms, ctx->ev[0], ctx->ev[1]));
-    xyzz_to_jac_out<Fp>(r, out);
-    return MI_OK;
+    return msm_dev_entry<Fp>(ctx, 1, pts_dev, scalars_dev, n, flags, out);
 }
 int32_t mi_msm_g2_dev(mi_ctx *ctx, const mi_g2_affine *pts_dev, const mi_fr *scalars_dev, size_t n, uint32_t flags, mi_g2_jac *out) {
     if (!ctx || !out || ((!pts_dev || !scalars_dev) && n) || (flags & ~1u)) return MI_EINVAL;
-    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
-    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    G2X r;
-    MI_TRY(msm_run<Fp2>(ctx, (const G2Aff *)pts_dev, (const Fr *)scalars_dev, n, flags, &r, false));
-    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
-    MI_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.total_ms, ctx->ev[0], ctx->ev[1]));
-    xyzz_to_jac_out<Fp2>(r, out);
-    return MI_OK;
+    return msm_dev_entry<Fp2>(ctx, 2, pts_dev, scalars_dev, n, flags, out);
 }
 }

@@ -10,6 +10,7 @@
 #include "curve.cuh"
 #include <cstring>
 #include <vector>
+#include <chrono>
 
 struct mi_pk {
     u32 log_n = 0, nb_public = 0;
@@ -107,72 +108,88 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wi
     const size_t N = (size_t)1 << pk->log_n;
     if (n_wires != pk->nb_wires || n_constraints > N) MI_FAIL(ctx, MI_EINVAL, "prove: witness size does not match the proving key");
     std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    const auto t_begin = std::chrono::steady_clock::now();
     hipEvent_t *ev = ctx->ev;
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-    // step 4: h = computeH(a, b, c)  (bit-reversed, like gnark leaves it)
+    // Stream plan: computeH on the caller's stream; MSM A, B1, B2, K, Z on slots 0..4 (own streams).  A, B and
+    // K depend only on W and start at once; B2 (G2) reuses B1's sort; Z waits for h.  The latency-bound tails
+    // (levels >= 2, bucket reduce, scans) of one MSM overlap the throughput-bound accumulation of the others.
+    MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));          // inputs are ready
+    // step 4: h = computeH(a, b, c)  (bit-reversed, like gnark leaves it) -- enqueued first: it heads the longest chain
     MI_TRY(mi_reserve(ctx, ctx->ws[14], N * sizeof(Fr)));
     Fr *h = (Fr *)ctx->ws[14].p;
     MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, c, n_constraints, (mi_fr *)h));
     MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
-    // step 5: wireValuesA / wireValuesB / K scalars by the static gather indices
-    size_t mx = pk->n_a > pk->n_b ? pk->n_a : pk->n_b;
-    if (pk->n_k > mx) mx = pk->n_k;
-    MI_TRY(mi_reserve(ctx, ctx->ws[15], (mx + 1) * sizeof(Fr)));
-    Fr *gath = (Fr *)ctx->ws[15].p;
-    auto gather = [&](const u32 *idx, size_t n) -> int32_t {
-        if (n) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, gath, (const Fr *)W, idx, n);
+    MI_TRY(mi_msm_enqueue(ctx, 4, -1, 1, pk->g1_z, h, N - 1, 0, ev[3], true));     // h[:N-1] against the bit-reversed pk.G1.Z
+    // step 5: wireValuesA / wireValuesB / K scalars by the static gather indices, each on its MSM's stream
+    auto gather = [&](int slot, int wsi, const u32 *idx, size_t n) -> int32_t {
+        MI_TRY(mi_reserve(ctx, ctx->ws[wsi], (n + 1) * sizeof(Fr)));
+        hipStream_t st = ctx->msm[slot].stream;
+        MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, ev[2], 0));
+        if (n) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Fr *)ctx->ws[wsi].p, (const Fr *)W, idx, n);
         MI_CHECK_HIP(ctx, hipGetLastError());
         return MI_OK;
     };
-    // step 7: the five MSMs (each call drains the stream when it downloads its window sums)
-    G1X msm_a, msm_b1, msm_k, msm_z;
-    G2X msm_b2;
-    MI_TRY(gather(pk->idx_a, pk->n_a));
-    MI_TRY(mi_msm_g1_xyzz(ctx, pk->g1_a, gath, pk->n_a, 0, &msm_a));
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[4], ctx->stream));
-    MI_TRY(gather(pk->idx_b, pk->n_b));
-    MI_TRY(mi_msm_g1_xyzz(ctx, pk->g1_b, gath, pk->n_b, 0, &msm_b1));
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[5], ctx->stream));
-    MI_TRY(mi_msm_g2_xyzz(ctx, pk->g2_b, gath, pk->n_b, 0, &msm_b2));
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[6], ctx->stream));
-    MI_TRY(gather(pk->idx_k, pk->n_k));
-    MI_TRY(mi_msm_g1_xyzz(ctx, pk->g1_k, gath, pk->n_k, 0, &msm_k));
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[7], ctx->stream));
-    MI_TRY(mi_msm_g1_xyzz(ctx, pk->g1_z, h, N - 1, 0, &msm_z));   // h[:N-1] against the bit-reversed pk.G1.Z
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[8], ctx->stream));
-    // steps 6 + 7 tail: blinding and assembly, O(1) point operations on the host
+    MI_TRY(gather(1, 17, pk->idx_b, pk->n_b));
+    MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, 0, nullptr, true));
+    MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, 0, nullptr, false));      // same scalars: shared sort
+    MI_TRY(gather(3, 18, pk->idx_k, pk->n_k));
+    MI_TRY(mi_msm_enqueue(ctx, 3, -1, 1, pk->g1_k, ctx->ws[18].p, pk->n_k, 0, nullptr, true));
+    MI_TRY(gather(0, 15, pk->idx_a, pk->n_a));
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->g1_a, ctx->ws[15].p, pk->n_a, 0, nullptr, true));
+    // step 6 while the GPU works: blinding multiples of delta on the host (O(1) points)
     Fr r, s;
     std::memcpy(&r, r_m, 32); std::memcpy(&s, s_m, 32);
     Fr rc = fe_from_mont(r), sc = fe_from_mont(s), krc = fe_from_mont(fe_neg(r * s));
+    G1X r_delta = host_scalar_mul<Fp>(pk->delta1, rc), s_delta = host_scalar_mul<Fp>(pk->delta1, sc), kr_delta = host_scalar_mul<Fp>(pk->delta1, krc);
+    G2X s_delta2 = host_scalar_mul<Fp2>(pk->delta2, sc);
+    // step 7: collect the five MSMs
+    G1X msm_a, msm_b1, msm_k, msm_z;
+    G2X msm_b2;
+    MI_TRY(mi_msm_finish(ctx, 0, 1, &msm_a));
+    MI_TRY(mi_msm_finish(ctx, 1, 1, &msm_b1));
+    const auto t_asm0 = std::chrono::steady_clock::now();
     G1X ar = msm_a;
     xyzz_madd(ar, pk->alpha1, false);
-    { G1X t = host_scalar_mul<Fp>(pk->delta1, rc); xyzz_add(ar, t); }
+    xyzz_add(ar, r_delta);
     G1X bs1 = msm_b1;
     xyzz_madd(bs1, pk->beta1, false);
-    { G1X t = host_scalar_mul<Fp>(pk->delta1, sc); xyzz_add(bs1, t); }
+    xyzz_add(bs1, s_delta);
+    G1Aff ar_aff = xyzz_to_affine(ar), bs1_aff = xyzz_to_affine(bs1);
+    G1X s_ar = host_scalar_mul<Fp>(ar_aff, sc), r_bs1 = host_scalar_mul<Fp>(bs1_aff, rc);   // overlaps the remaining MSMs
+    MI_TRY(mi_msm_finish(ctx, 3, 1, &msm_k));
+    MI_TRY(mi_msm_finish(ctx, 2, 2, &msm_b2));
+    MI_TRY(mi_msm_finish(ctx, 4, 1, &msm_z));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t_gpu_done = std::chrono::steady_clock::now();
     G1X krs = msm_k;
     xyzz_add(krs, msm_z);
-    { G1X t = host_scalar_mul<Fp>(pk->delta1, krc); xyzz_add(krs, t); }
-    G1Aff ar_aff = xyzz_to_affine(ar), bs1_aff = xyzz_to_affine(bs1);
-    { G1X t = host_scalar_mul<Fp>(ar_aff, sc); xyzz_add(krs, t); }
-    { G1X t = host_scalar_mul<Fp>(bs1_aff, rc); xyzz_add(krs, t); }
+    xyzz_add(krs, kr_delta);
+    xyzz_add(krs, s_ar);
+    xyzz_add(krs, r_bs1);
     G2X bs = msm_b2;
     xyzz_madd(bs, pk->beta2, false);
-    { G2X t = host_scalar_mul<Fp2>(pk->delta2, sc); xyzz_add(bs, t); }
+    xyzz_add(bs, s_delta2);
     G1Aff krs_aff = xyzz_to_affine(krs);
     G2Aff bs_aff = xyzz_to_affine(bs);
     std::memcpy(&out->ar, &ar_aff, 64); std::memcpy(&out->bs, &bs_aff, 128); std::memcpy(&out->krs, &krs_aff, 64);
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[9], ctx->stream));
-    MI_CHECK_HIP(ctx, hipEventSynchronize(ev[9]));
+    const auto t_end = std::chrono::steady_clock::now();
     mi_stats &st = ctx->stats;
+    auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+        return std::chrono::duration<float, std::milli>(y - x).count();
+    };
+    auto slot_ms = [&](int slot, float *dst) -> int32_t {
+        MI_CHECK_HIP(ctx, hipEventElapsedTime(dst, ctx->msm[slot].ev[3], ctx->msm[slot].ev[4]));
+        return MI_OK;
+    };
+    // per-phase spans overlap (five streams): they do not add up to total_ms
     MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.compute_h_ms, ev[2], ev[3]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_a_ms, ev[3], ev[4]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_b1_ms, ev[4], ev[5]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_b2_ms, ev[5], ev[6]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_k_ms, ev[6], ev[7]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.msm_z_ms, ev[7], ev[8]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.assemble_ms, ev[8], ev[9]));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.total_ms, ev[2], ev[9]));
+    if (pk->n_a) MI_TRY(slot_ms(0, &st.msm_a_ms));
+    if (pk->n_b) { MI_TRY(slot_ms(1, &st.msm_b1_ms)); MI_TRY(slot_ms(2, &st.msm_b2_ms)); }
+    if (pk->n_k) MI_TRY(slot_ms(3, &st.msm_k_ms));
+    if (N > 1) MI_TRY(slot_ms(4, &st.msm_z_ms));
+    st.assemble_ms = ms(t_gpu_done, t_end);     // host work left after the last MSM landed
+    st.filter_ms = ms(t_asm0, t_gpu_done);      // host blinding work hidden under the GPU
+    st.total_ms = ms(t_begin, t_end);
     if (stats) *stats = st;
     return MI_OK;
 }
@@ -192,6 +209,7 @@ int32_t mi_groth16_prove(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires,
     MI_TRY(mi_groth16_prove_dev(ctx, pk, (mi_fr *)base, n_wires, (mi_fr *)(base + wb), (mi_fr *)(base + wb + cb), (mi_fr *)(base + wb + 2 * cb),
                                 n_constraints, r, s, out, nullptr));
     MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.h2d_ms, ctx->ev[10], ctx->ev[11]));
+    ctx->stats.total_ms += ctx->stats.h2d_ms;
     if (stats) *stats = ctx->stats;
     return MI_OK;
 }
