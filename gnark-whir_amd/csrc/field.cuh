@@ -250,16 +250,24 @@ MI_HD Fp2 operator+(const Fp2 &x, const Fp2 &y) { return Fp2{x.a0 + y.a0, x.a1 +
 MI_HD Fp2 operator-(const Fp2 &x, const Fp2 &y) { return Fp2{x.a0 - y.a0, x.a1 - y.a1}; }
 MI_HD Fp2 fe_neg(const Fp2 &x) { return Fp2{fe_neg(x.a0), fe_neg(x.a1)}; }
 MI_HD Fp2 fe_dbl(const Fp2 &x) { return x + x; }
+// Fp products inside Fp2 go through ONE out-of-line copy of the multiplier on the device: a G2 mixed
+// addition is ~28 Fp products; fully inlined that is > 100 KB of straight-line code per kernel, more than the
+// instruction cache holds.  (The G1 path keeps its ~10 products inline.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) Fp fp_mul_call(Fp x, Fp y) { return x * y; }
+#else
+inline Fp fp_mul_call(const Fp &x, const Fp &y) { return x * y; }
+#endif
 // Karatsuba: 3 base multiplications
 MI_HD Fp2 operator*(const Fp2 &x, const Fp2 &y) {
-    Fp v0 = x.a0 * y.a0, v1 = x.a1 * y.a1;
-    Fp s = (x.a0 + x.a1) * (y.a0 + y.a1);
+    Fp v0 = fp_mul_call(x.a0, y.a0), v1 = fp_mul_call(x.a1, y.a1);
+    Fp s = fp_mul_call(x.a0 + x.a1, y.a0 + y.a1);
     return Fp2{v0 - v1, s - v0 - v1};
 }
 // (a0+a1)(a0-a1), 2 a0 a1 : 2 base multiplications
 MI_HD Fp2 fe_sqr(const Fp2 &x) {
-    Fp m = x.a0 * x.a1;
-    return Fp2{(x.a0 + x.a1) * (x.a0 - x.a1), m + m};
+    Fp m = fp_mul_call(x.a0, x.a1);
+    return Fp2{fp_mul_call(x.a0 + x.a1, x.a0 - x.a1), m + m};
 }
 MI_HD Fp2 fe_inv(const Fp2 &x) {
     Fp n = fe_inv(fe_sqr(x.a0) + fe_sqr(x.a1));

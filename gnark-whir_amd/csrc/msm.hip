@@ -4,7 +4,8 @@
 //
 // HBM layout per MSM call (all grow-only ctx workspaces, n pairs, nwin windows, K = nwin*2^(c-1) keys):
 //   digits  int16 [nwin][n]            window-major signed digits
-//   H, S    u32   [K][G] (+1)          per-(key, slice) histogram and its flat exclusive scan
+//   H       u32   [nwin][G][2^(c-1)]   per-(window, slice) bucket histogram, then its exclusive prefix along the slices
+//   keystart u32  [K+1]                exclusive scan of the per-key totals
 //   sorted  u32   [<= nwin*n]          point index | sign<<31, grouped by key
 //   start/cnt/items/item_start u32 [K] item decomposition of the current level (ping-pong)
 //   partial XYZZ  [items]              per-item partial sums (ping-pong between levels)
@@ -22,7 +23,7 @@ struct MsmKnobs {
 };
 static MsmKnobs *knobs_of(mi_ctx *ctx) { return reinterpret_cast<MsmKnobs *>(ctx->msm_knobs); }
 __global__ void k_msm_hist(MsmShape s, const int16_t *digits, u32 *H);
-__global__ void k_msm_scatter(MsmShape s, const int16_t *digits, const u32 *S, u32 *sorted);
+__global__ void k_msm_scatter(MsmShape s, const int16_t *digits, const u32 *keystart, const u32 *Hx, u32 *sorted);
 
 // ---------------------------------------------------------------- kernels
 __global__ void k_msm_digits(MsmShape s, const Fr *scalars, int montgomery, int16_t *digits) {
@@ -38,10 +39,14 @@ __global__ void __launch_bounds__(1024) k_msm_hist(MsmShape s, const int16_t *di
     __syncthreads();
     msm_hist_write(s, H, g, w, lds_u32, threadIdx.x, blockDim.x);
 }
-__global__ void __launch_bounds__(1024) k_msm_scatter(MsmShape s, const int16_t *digits, const u32 *S, u32 *sorted) {
+__global__ void k_msm_colsum(MsmShape s, u32 *H, u32 *total) {
+    u32 key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key < s.nkeys) msm_colsum_body(s, H, total, key);
+}
+__global__ void __launch_bounds__(1024) k_msm_scatter(MsmShape s, const int16_t *digits, const u32 *keystart, const u32 *Hx, u32 *sorted) {
     extern __shared__ u32 lds_u32[];
     const u32 g = blockIdx.x, w = blockIdx.y;
-    msm_scatter_init(s, S, g, w, lds_u32, threadIdx.x, blockDim.x);
+    msm_scatter_init(s, keystart, Hx, g, w, lds_u32, threadIdx.x, blockDim.x);
     __syncthreads();
     msm_scatter_move(s, digits, g, w, lds_u32, sorted, threadIdx.x, blockDim.x);
 }
@@ -231,17 +236,19 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
     if (s.nwin > 128) MI_FAIL(ctx, MI_EINVAL, "msm: too many windows");
     MI_TRY(mi_reserve(ctx, sl.buf[B_DIGITS], T_bound * 2 + 64));
     MI_TRY(mi_reserve(ctx, sl.buf[B_H], ((size_t)s.nkeys * s.nslices + 1) * 4));
-    MI_TRY(mi_reserve(ctx, sl.buf[B_S], ((size_t)s.nkeys * s.nslices + 1) * 4));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_S], ((size_t)s.nkeys * 2 + 2) * 4));
     MI_TRY(mi_reserve(ctx, sl.buf[B_SORTED], (T_bound + 1) * 4));
     int16_t *digits = (int16_t *)sl.buf[B_DIGITS].p;
-    u32 *H = (u32 *)sl.buf[B_H].p, *S = (u32 *)sl.buf[B_S].p, *sorted = (u32 *)sl.buf[B_SORTED].p;
+    u32 *H = (u32 *)sl.buf[B_H].p, *keystart = (u32 *)sl.buf[B_S].p, *total = keystart + s.nkeys + 1, *sorted = (u32 *)sl.buf[B_SORTED].p;
     hipStream_t st = sl.stream;
     hipLaunchKernelGGL(k_msm_digits, dim3((n + 255) / 256), dim3(256), 0, st, s, scalars, (flags & MI_MSM_SCALARS_CANONICAL) ? 0 : 1, digits);
     const size_t lds_bytes = (size_t)s.nbuckets * 4;
     hipLaunchKernelGGL(k_msm_hist, dim3(s.nslices, s.nwin), dim3(1024), lds_bytes, st, s, digits, H);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(exclusive_scan(ctx, st, H, (size_t)s.nkeys * s.nslices, S, sl.buf[B_SCAN]));
-    hipLaunchKernelGGL(k_msm_scatter, dim3(s.nslices, s.nwin), dim3(1024), lds_bytes, st, s, digits, S, sorted);
+    hipLaunchKernelGGL(k_msm_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, H, total);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
+    hipLaunchKernelGGL(k_msm_scatter, dim3(s.nslices, s.nwin), dim3(1024), lds_bytes, st, s, digits, keystart, H, sorted);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[0], st));
     return MI_OK;

@@ -7,8 +7,8 @@
 //
 //   1 digits   : scalar -> canonical -> nwin signed c-bit digits in [-2^(c-1), 2^(c-1)-1] (int16,
 //                window-major).  key = w * 2^(c-1) + |d| - 1 names a bucket.
-//   2 sort     : counting sort of (key -> point index | sign<<31): per-workgroup LDS histograms,
-//                one flat exclusive scan over [key][slice], LDS cursors for the scatter.  No global
+//   2 sort     : counting sort of (key -> point index | sign<<31): per-workgroup LDS histograms
+//                H[window][slice][bucket], column sums + one exclusive scan over the keys, LDS cursors for the scatter.  No global
 //                atomics; the order inside a bucket is irrelevant (the sum is canonical).
 //   3 accumulate, level 1: every bucket is cut into items of <= L entries; one thread sums one item
 //                with mixed XYZZ additions (uniform work per thread, whatever the skew of the scalars
@@ -81,13 +81,26 @@ MI_HD void msm_hist_count(const MsmShape &s, const int16_t *digits, u32 g, u32 w
         if (d) MI_LDS_ATOMIC_ADD(&lds[(d < 0 ? -d : d) - 1], 1u);
     }
 }
-// H[(key * G) + g], key = w * nbuckets + b : one flat exclusive scan gives every (key, slice) offset
+// H[w][g][b] (bucket fastest): every workgroup writes / reads whole contiguous rows
+MI_HD size_t msm_cell(const MsmShape &s, u32 w, u32 g, u32 b) { return ((size_t)w * s.nslices + g) * s.nbuckets + b; }
 MI_HD void msm_hist_write(const MsmShape &s, u32 *H, u32 g, u32 w, const u32 *lds, u32 tid, u32 nthr) {
-    for (u32 b = tid; b < s.nbuckets; b += nthr) H[((size_t)w * s.nbuckets + b) * s.nslices + g] = lds[b];
+    for (u32 b = tid; b < s.nbuckets; b += nthr) H[msm_cell(s, w, g, b)] = lds[b];
 }
-// ---- 2b. scatter: workgroup (g, w), LDS cursor[nbuckets] = scanned offsets of this slice
-MI_HD void msm_scatter_init(const MsmShape &s, const u32 *S, u32 g, u32 w, u32 *lds, u32 tid, u32 nthr) {
-    for (u32 b = tid; b < s.nbuckets; b += nthr) lds[b] = S[((size_t)w * s.nbuckets + b) * s.nslices + g];
+// column sums: thread = key (w, b).  H[w][g][b] <- sum_{g' < g} H[w][g'][b] (exclusive along the slices),
+// total[key] <- sum over all slices.  Neighbouring threads touch neighbouring words for every g.
+MI_HD void msm_colsum_body(const MsmShape &s, u32 *H, u32 *total, u32 key) {
+    u32 w = key / s.nbuckets, b = key % s.nbuckets, run = 0;
+    for (u32 g = 0; g < s.nslices; g++) {
+        size_t i = msm_cell(s, w, g, b);
+        u32 v = H[i];
+        H[i] = run;
+        run += v;
+    }
+    total[key] = run;
+}
+// ---- 2b. scatter: workgroup (g, w), LDS cursor[b] = keystart[key] + entries of earlier slices
+MI_HD void msm_scatter_init(const MsmShape &s, const u32 *keystart, const u32 *Hx, u32 g, u32 w, u32 *lds, u32 tid, u32 nthr) {
+    for (u32 b = tid; b < s.nbuckets; b += nthr) lds[b] = keystart[(size_t)w * s.nbuckets + b] + Hx[msm_cell(s, w, g, b)];
 }
 MI_HD void msm_scatter_move(const MsmShape &s, const int16_t *digits, u32 g, u32 w, u32 *lds, u32 *sorted, u32 tid, u32 nthr) {
     u32 begin, end;
@@ -102,9 +115,9 @@ MI_HD void msm_scatter_move(const MsmShape &s, const int16_t *digits, u32 g, u32
 }
 
 // ---- 3. item decomposition.  Per key: start (first entry), cnt (entries), items = ceil(cnt / L).
-// level 1 prep from the scanned histogram S (S has nkeys*G + 1 entries, last = total)
-MI_HD void msm_prep_level1(const MsmShape &s, const u32 *S, u32 L, u32 *start, u32 *cnt, u32 *items, u32 key) {
-    u32 a = S[(size_t)key * s.nslices], b = S[(size_t)(key + 1) * s.nslices];
+// level 1 prep from keystart = exclusive scan of the per-key totals (nkeys + 1 entries, last = grand total)
+MI_HD void msm_prep_level1(const MsmShape &s, const u32 *keystart, u32 L, u32 *start, u32 *cnt, u32 *items, u32 key) {
+    u32 a = keystart[key], b = keystart[key + 1];
     start[key] = a; cnt[key] = b - a; items[key] = (b - a + L - 1) / L;
 }
 // level k+1 prep from level k: keys that produced more than one item continue with their partials

@@ -21,7 +21,7 @@ struct NttState {
     Fr *g_lo = nullptr, *g_hi = nullptr, *gi_lo = nullptr, *gi_hi = nullptr, *ninv = nullptr;
     u32 tw_h = 0;
     // plan knobs (mi_debug_set_ntt_plan)
-    u32 log_e = 11, max_contig = 11, max_strided = 8;
+    u32 log_e = 11, max_contig = 11, max_strided = 8, threads = 1024;
 };
 static NttState *state_of(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= 256, "NttState lives in ctx->ntt_state");
@@ -54,7 +54,7 @@ __global__ void k_pow_table(Fr *out, u32 count, Fr base, Fr c, u32 shift) {
     out[j] = acc;
 }
 
-__global__ void __launch_bounds__(256) k_ntt_pass(Fr *dst, const Fr *src, NttPass p, NttTables t) {
+__global__ void __launch_bounds__(1024) k_ntt_pass(Fr *dst, const Fr *src, NttPass p, NttTables t) {
     extern __shared__ U4 lds[];
     const u64 tile = blockIdx.x;
     ntt_tile_load(p, t, src, tile, threadIdx.x, blockDim.x, lds);
@@ -161,7 +161,9 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
         u32 tiles = 1u << (log_n - p.log_r - p.log_c);
         size_t lds_bytes = (size_t)32 << (p.log_r + p.log_c);
         u32 E = 1u << (p.log_r + p.log_c);
-        u32 threads = E / 2 >= 256 ? 256 : (E / 2 >= 64 ? E / 2 : 64);
+        // one butterfly per thread per stage when the tile allows: 64 KiB of LDS admits two workgroups per CU,
+        // so 1024-thread workgroups are what fills the SIMDs (8 waves each) and hides the mad->addc chains
+        u32 threads = E / 2 >= st->threads ? st->threads : (E / 2 >= 64 ? E / 2 : 64);
         hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(threads), lds_bytes, ctx->stream, dst, cur_src, p, t);
         MI_CHECK_HIP(ctx, hipGetLastError());
         cur_src = dst;
@@ -208,6 +210,11 @@ int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, 
         return MI_EINVAL;
     NttState *st = state_of(ctx);
     st->log_e = log_e; st->max_contig = max_contig; st->max_strided = max_strided;
+    return MI_OK;
+}
+int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads) {
+    if (!ctx || threads < 64 || threads > 1024 || (threads & (threads - 1))) return MI_EINVAL;
+    state_of(ctx)->threads = threads;
     return MI_OK;
 }
 int32_t mi_ntt_dev(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t flags) {

@@ -148,12 +148,13 @@ static int emu_msm_t(void *out_v, const void *pts_v, const void *sc_v, u32 n, in
             for (u32 t = 0; t < nthr; t++) msm_hist_count(s, digits.data(), g, w, lds.data(), t, nthr);
             for (u32 t = 0; t < nthr; t++) msm_hist_write(s, H.data(), g, w, lds.data(), t, nthr);
         }
-    std::vector<u32> S;
-    excl_scan(H, S);
+    std::vector<u32> total(s.nkeys), S;
+    for (u32 k = 0; k < s.nkeys; k++) msm_colsum_body(s, H.data(), total.data(), k);
+    excl_scan(total, S);
     std::vector<u32> sorted(S.back() + 1);
     for (u32 w = 0; w < s.nwin; w++)
         for (u32 g = 0; g < G; g++) {
-            for (u32 t = 0; t < nthr; t++) msm_scatter_init(s, S.data(), g, w, lds.data(), t, nthr);
+            for (u32 t = 0; t < nthr; t++) msm_scatter_init(s, S.data(), H.data(), g, w, lds.data(), t, nthr);
             for (u32 t = 0; t < nthr; t++) msm_scatter_move(s, digits.data(), g, w, lds.data(), sorted.data(), t, nthr);
         }
     std::vector<u32> start(s.nkeys), cnt(s.nkeys), items(s.nkeys);
