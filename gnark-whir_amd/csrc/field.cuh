@@ -253,10 +253,10 @@ MI_HD Fp2 fe_dbl(const Fp2 &x) { return x + x; }
 // Fp products inside Fp2 go through ONE out-of-line copy of the multiplier on the device: a G2 mixed
 // addition is ~28 Fp products; fully inlined that is > 100 KB of straight-line code per kernel, more than the
 // instruction cache holds.  (The G1 path keeps its ~10 products inline.)
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_FP2_INLINE_MUL)
 __device__ __attribute__((noinline)) Fp fp_mul_call(Fp x, Fp y) { return x * y; }
 #else
-inline Fp fp_mul_call(const Fp &x, const Fp &y) { return x * y; }
+MI_HD Fp fp_mul_call(const Fp &x, const Fp &y) { return x * y; }
 #endif
 // Karatsuba: 3 base multiplications
 MI_HD Fp2 operator*(const Fp2 &x, const Fp2 &y) {

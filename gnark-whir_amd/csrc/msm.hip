@@ -63,15 +63,20 @@ __global__ void k_msm_prep_windows(u32 nwin, u32 tb, u32 L, u32 *start, u32 *cnt
     u32 w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < nwin) { start[w] = w * tb; cnt[w] = tb; items[w] = (tb + L - 1) / L; }
 }
+// Occupancy target per curve (measured with tools/bench_g2 on MI355X): the G1 mixed add needs ~60 VGPRs and runs
+// 8 waves/SIMD; the G2 one wants > 256 -- 2 waves/SIMD with the Fp multiplier out of line (480 B of scratch) is the
+// fastest point (2.6 G madd/s vs 2.0 at 1 wave and 1.5 at 4 waves).
+template <class F> struct AccumWaves { static constexpr int value = 1; };
+template <> struct AccumWaves<Fp2> { static constexpr int value = 2; };
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_accum_affine(const Affine<F> *pts, const u32 *sorted, const u32 *start, const u32 *cnt,
+__global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_affine(const Affine<F> *pts, const u32 *sorted, const u32 *start, const u32 *cnt,
                                                          const u32 *items, const u32 *item_start, u32 nkeys, u32 L,
                                                          XYZZ<F> *bucket, XYZZ<F> *partial_out) {
     u32 item = blockIdx.x * blockDim.x + threadIdx.x;
     msm_accum_affine_body<F>(pts, sorted, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
 }
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_accum_xyzz(const XYZZ<F> *partial_in, const u32 *start, const u32 *cnt, const u32 *items,
+__global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_xyzz(const XYZZ<F> *partial_in, const u32 *start, const u32 *cnt, const u32 *items,
                                                        const u32 *item_start, u32 nkeys, u32 L, XYZZ<F> *bucket, XYZZ<F> *partial_out) {
     u32 item = blockIdx.x * blockDim.x + threadIdx.x;
     msm_accum_xyzz_body<F>(partial_in, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);

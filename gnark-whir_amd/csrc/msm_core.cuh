@@ -135,14 +135,20 @@ MI_HD u32 msm_item_key(const u32 *item_start, u32 nkeys, u32 item) {
     }
     return lo;
 }
+// entries [b, e) of item j of a key: the key's cnt entries are cut into `nitems` items whose sizes differ by at most one
+// (35 entries at L = 32 become 18 + 17, not 32 + 3: neighbouring lanes then run similar trip counts)
+MI_HD void msm_item_range(u32 start, u32 cnt, u32 nitems, u32 j, u32 &b, u32 &e) {
+    u32 q = cnt / nitems, r = cnt % nitems;
+    b = start + j * q + (j < r ? j : r);
+    e = b + q + (j < r ? 1 : 0);
+}
 template <class F>
 MI_HD void msm_accum_affine_body(const Affine<F> *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
                                  const u32 *item_start, u32 nkeys, u32 L, XYZZ<F> *bucket, XYZZ<F> *partial_out, u32 item) {
     if (item >= item_start[nkeys]) return;
     u32 key = msm_item_key(item_start, nkeys, item);
-    u32 j = item - item_start[key];
-    u32 b = start[key] + j * L, e = start[key] + cnt[key];
-    if (b + L < e) e = b + L;
+    u32 b, e;
+    msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
     XYZZ<F> acc = XYZZ<F>::inf();
     for (u32 k = b; k < e; k++) {
         u32 v = sorted[k];
@@ -156,9 +162,8 @@ MI_HD void msm_accum_xyzz_body(const XYZZ<F> *partial_in, const u32 *start, cons
                                u32 nkeys, u32 L, XYZZ<F> *bucket, XYZZ<F> *partial_out, u32 item) {
     if (item >= item_start[nkeys]) return;
     u32 key = msm_item_key(item_start, nkeys, item);
-    u32 j = item - item_start[key];
-    u32 b = start[key] + j * L, e = start[key] + cnt[key];
-    if (b + L < e) e = b + L;
+    u32 b, e;
+    msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
     XYZZ<F> acc = partial_in[b];
     for (u32 k = b + 1; k < e; k++) xyzz_add(acc, partial_in[k]);
     if (items[key] == 1) bucket[key] = acc; else partial_out[item] = acc;

@@ -15,8 +15,8 @@ log_n = 23
 n = 1 << log_n
 if "ntt" in which:
     x = ctx.gen_scalars(n, 1, 0)
-    for threads in (256, 512, 1024):
-        for (log_e, mc, ms) in ((11, 11, 8), (11, 11, 6), (12, 11, 8), (12, 12, 11) if False else (11, 9, 8), (10, 10, 7)):
+    for threads in (128, 256, 512):
+        for (log_e, mc, ms) in ((10, 10, 7), (10, 10, 5), (9, 9, 7), (9, 9, 5), (8, 8, 8), (10, 8, 8), (11, 10, 7)):
             assert lib.mi_debug_set_ntt_threads(ctx.h, threads) == 0
             if lib.mi_debug_set_ntt_plan(ctx.h, log_e, mc, ms) != 0:
                 continue
@@ -27,7 +27,7 @@ if "ntt" in which:
                     best = min(best, ctx.stats()["ntt_kernel_ms"])
             out[f"ntt_t{threads}_e{log_e}_c{mc}_s{ms}"] = best
             print("ntt", threads, log_e, mc, ms, best, flush=True)
-    lib.mi_debug_set_ntt_plan(ctx.h, 11, 11, 8); lib.mi_debug_set_ntt_threads(ctx.h, 1024)
+    lib.mi_debug_set_ntt_plan(ctx.h, 10, 10, 7); lib.mi_debug_set_ntt_threads(ctx.h, 256)
     x.free()
 if "msm" in which:
     pts = ctx.gen_g1(n, 11)
