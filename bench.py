@@ -136,6 +136,16 @@ def main():
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         g1_pairs_per_proof = na + nb + nk + (N - 1)
         g1_msm_ms = last["msm_a_ms"] + last["msm_b1_ms"] + last["msm_k_ms"] + last["msm_z_ms"]
+        # HBM traffic of the dominant kernel: from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/r01_pmc_bench_traffic.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB units).  The guide's x2
+        # FETCH_SIZE correction is for wide coalesced streams; this kernel gathers 64-B points, so the raw sum is reported.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")))
+            kname = "void k_msm_accum_affine<Fe<FpParams> >"
+            traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
+        except Exception:
+            traffic = None
         line = {
             "metric": "Groth16 proofs/sec for WHIR-verifier circuit (2^20 poly); G1 MSM pts/sec",
             "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -148,7 +158,7 @@ def main():
             "g1_msm_pts_per_s": g1_pairs_per_proof / (g1_msm_ms * 1e-3),
             "phase_ms": {k: last[k] for k in ("compute_h_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "msm_k_ms", "msm_z_ms", "assemble_ms", "total_ms")},
             "roofline": {"kernel": "k_msm_accum_affine<Fp> (G1 level-1 bucket accumulate)", "bound": "hbm", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:

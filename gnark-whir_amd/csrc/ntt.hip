@@ -21,9 +21,9 @@ struct NttState {
     Fr *g_lo = nullptr, *g_hi = nullptr, *gi_lo = nullptr, *gi_hi = nullptr, *ninv = nullptr;
     u32 tw_h = 0;
     // plan knobs (mi_debug_set_ntt_plan)
-    // defaults from the tools/tune.py sweep at N = 2^23: 2^10-element tiles (32 KiB of LDS, 5 workgroups per CU),
-    // 256 threads, radices 2^7 * 2^6 * 2^10: 1.53 ms per transform vs 1.99 ms for 2^11 tiles
-    u32 log_e = 10, max_contig = 10, max_strided = 7, threads = 256;
+    // defaults from the tools/tune.py sweep at N = 2^23: 2^9-element tiles (16 KiB of LDS, 8 workgroups of 256
+    // threads per CU), radices 2^7 * 2^7 * 2^9: 1.46 ms per transform vs 1.99 ms for 2^11 tiles
+    u32 log_e = 9, max_contig = 9, max_strided = 7, threads = 256;
 };
 static NttState *state_of(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= 256, "NttState lives in ctx->ntt_state");

@@ -83,7 +83,7 @@ def test_ntt_small_tiles_multi_pass(ctx):
             for flags in range(8):
                 assert np.array_equal(ctx.ntt(a, log_n, flags), cref.ntt(a, log_n, flags)), (log_e, flags)
     finally:
-        assert lib.mi_debug_set_ntt_plan(ctx.h, 10, 10, 7) == 0
+        assert lib.mi_debug_set_ntt_plan(ctx.h, 9, 9, 7) == 0
 
 
 def test_ntt_roundtrip_and_linearity_at_scale(ctx):

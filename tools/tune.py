@@ -27,7 +27,7 @@ if "ntt" in which:
                     best = min(best, ctx.stats()["ntt_kernel_ms"])
             out[f"ntt_t{threads}_e{log_e}_c{mc}_s{ms}"] = best
             print("ntt", threads, log_e, mc, ms, best, flush=True)
-    lib.mi_debug_set_ntt_plan(ctx.h, 10, 10, 7); lib.mi_debug_set_ntt_threads(ctx.h, 256)
+    lib.mi_debug_set_ntt_plan(ctx.h, 9, 9, 7); lib.mi_debug_set_ntt_threads(ctx.h, 256)
     x.free()
 if "msm" in which:
     pts = ctx.gen_g1(n, 11)
