@@ -177,7 +177,7 @@ void mi_msm_state_init(mi_ctx *ctx) {
     for (auto &sl : ctx->msm) {
         (void)hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
         for (auto &e : sl.ev) (void)hipEventCreate(&e);
-        (void)hipHostMalloc(&sl.host_wsum, 128 * 256);
+        (void)hipHostMalloc(&sl.host_wsum, 128 * 256 + 64);
     }
 }
 void mi_msm_state_free(mi_ctx *ctx) {
@@ -291,6 +291,8 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, MsmSlot &srt, MsmSlot &acc, const 
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(run_levels<F>(ctx, acc, s.nwin, A, B, (u64)s.nwin * ((tb + L2 - 1) / L2) + 1, tb, L2, L2, (const Affine<F> *)nullptr, nullptr, P, wsum, false));
     MI_CHECK_HIP(ctx, hipMemcpyAsync(acc.host_wsum, wsum, sizeof(XYZZ<F>) * s.nwin, hipMemcpyDeviceToHost, st));
+    // number of sorted entries (= mixed additions of level 1) for the stats: keystart[nkeys]
+    MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)acc.host_wsum + 128 * 256, (const u32 *)srt.buf[B_S].p + s.nkeys, 4, hipMemcpyDeviceToHost, st));
     MI_CHECK_HIP(ctx, hipEventRecord(acc.ev[4], st));
     acc.timed = timed;
     acc.active = true;
@@ -309,6 +311,7 @@ static int32_t msm_finish(mi_ctx *ctx, MsmSlot &sl, XYZZ<F> *out) {
         ctx->stats.g1_accum_kernel_ms += ms;
         ctx->stats.g1_accum_pairs += sl.n;
         ctx->stats.g1_accum_launches += 1;
+        ctx->stats.g1_accum_entries += *(const u32 *)((const char *)sl.host_wsum + 128 * 256);
     }
     sl.active = false;
     return MI_OK;

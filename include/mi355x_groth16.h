@@ -101,6 +101,7 @@ typedef struct mi_stats {
     float ntt_kernel_ms;            /* summed duration of NTT pass launches                   */
     uint64_t ntt_elems;             /* elements transformed (N per size-N transform)          */
     uint32_t ntt_launches;
+    uint64_t g1_accum_entries;      /* non-zero digits = mixed additions those launches performed     */
 } mi_stats;
 
 /* ---- lifecycle ---- */

@@ -171,3 +171,17 @@ def test_prove_rejects_mismatched_inputs(ctx):
     with pytest.raises(B.MiError):
         ctx.prove(pkh, z["W"][:-1], z["a"], z["b"], z["c"], z["r"], z["s"])
     ctx.pk_free(pkh)
+
+
+def test_msm_sharding_identity_at_2p26(ctx):
+    """maximum single-GPU size of BASELINE configs[2]/[4] (2^26 pairs): the two halves add up to the whole"""
+    B = load_binding()
+    n = 1 << 26
+    pts = ctx.gen_g1(n, 21); s = ctx.gen_scalars(n, 22, 1)
+    whole = ctx.msm_g1_dev(pts.ptr, s.ptr, n)
+    h = n // 2 + 12345
+    lo = ctx.msm_g1_dev(pts.ptr, s.ptr, h); hi = ctx.msm_g1_dev(pts.ptr + 64 * h, s.ptr + 32 * h, n - h)
+    assert np.array_equal(B.g1_sum(np.stack([lo, hi])), whole)
+    assert whole[8:].any()
+    for d in (pts, s):
+        d.free()
