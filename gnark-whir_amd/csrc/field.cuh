@@ -166,6 +166,33 @@ MI_HD void mac96_first(u64 &acc, u32 a, u32 b) {
 
 // Montgomery product x*y/R mod p: product scanning (column-wise, "FIPS") over 32-bit limbs with a
 // 96-bit accumulator.  Column k collects x_i*y_(k-i) and m_i*p_(k-i); m_k makes the column's low word 0.
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "mont_cols.inc"   // generated: one asm block per column (tools/gen_mont_cols.py)
+#define MI_MONT_LO(k)                                   \
+    mont_col##k<P>(acc, c, x, y, m);                    \
+    m[k] = (u32)acc * P::inv;                           \
+    mac96_k(acc, c, m[k], P::p[0]);                     \
+    acc = (acc >> 32) | ((u64)c << 32);                 \
+    c = 0;
+#define MI_MONT_HI(k)                                   \
+    mont_col##k<P>(acc, c, x, y, m);                    \
+    r.l[k - 8] = (u32)acc;                              \
+    acc = (acc >> 32) | ((u64)c << 32);                 \
+    c = 0;
+template <class P>
+MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
+    u64 acc = 0;
+    u32 c = 0;
+    u32 m[8];
+    Fe<P> r;
+    MI_MONT_LO(0) MI_MONT_LO(1) MI_MONT_LO(2) MI_MONT_LO(3) MI_MONT_LO(4) MI_MONT_LO(5) MI_MONT_LO(6) MI_MONT_LO(7)
+    MI_MONT_HI(8) MI_MONT_HI(9) MI_MONT_HI(10) MI_MONT_HI(11) MI_MONT_HI(12) MI_MONT_HI(13) MI_MONT_HI(14)
+    r.l[7] = (u32)acc;   // column 15 is empty for 8-limb operands; p < 2^254 keeps the result < 2p < 2^256
+    return fe_reduce_once(r);
+}
+#undef MI_MONT_LO
+#undef MI_MONT_HI
+#else
 template <class P>
 MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
     u64 acc = 0;
@@ -195,9 +222,10 @@ MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
         acc = (acc >> 32) | ((u64)c << 32);
         c = 0;
     }
-    r.l[7] = (u32)acc;   // column 15 is empty for 8-limb operands; p < 2^254 keeps the result < 2p < 2^256
+    r.l[7] = (u32)acc;
     return fe_reduce_once(r);
 }
+#endif
 template <class P>
 MI_HD Fe<P> fe_sqr(const Fe<P> &x) { return x * x; }
 
