@@ -89,6 +89,103 @@ MI_HD u32 fe_add_raw(Fe<P> &z, const Fe<P> &x, const Fe<P> &y) {
     }
     return (u32)c;
 }
+// Device carry chains are written out (v_add_co/v_addc_co, v_sub_co/v_subb_co + v_cndmask): hipcc lowers the
+// portable u64 formulation below to ~80-90 VALU instructions per modular add/sub (64-bit adds, sign-extension
+// shifts, pair moves) against 24-25 here.  The host build (tests) keeps the portable code.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI_L8(v) "v"(v.l[0]), "v"(v.l[1]), "v"(v.l[2]), "v"(v.l[3]), "v"(v.l[4]), "v"(v.l[5]), "v"(v.l[6]), "v"(v.l[7])
+#define MI_O8(v) "=&v"(v.l[0]), "=&v"(v.l[1]), "=&v"(v.l[2]), "=&v"(v.l[3]), "=&v"(v.l[4]), "=&v"(v.l[5]), "=&v"(v.l[6]), "=&v"(v.l[7])
+// the modulus limbs sit in VGPRs here: a VOP2 carry-in (vcc) already uses the one constant-bus read gfx9 allows
+#define MI_P8 "v"(P::p[0]), "v"(P::p[1]), "v"(P::p[2]), "v"(P::p[3]), "v"(P::p[4]), "v"(P::p[5]), "v"(P::p[6]), "v"(P::p[7])
+// if x >= p: x -= p   (x < 2p)
+template <class P>
+MI_HD Fe<P> fe_reduce_once(const Fe<P> &x) {
+    Fe<P> z;   // operands: %0-7 z, %8-15 x, %16-23 p
+    asm("v_subrev_co_u32_e32 %0, vcc, %16, %8\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, %17, %9, vcc\n\t"
+        "v_subbrev_co_u32_e32 %2, vcc, %18, %10, vcc\n\t"
+        "v_subbrev_co_u32_e32 %3, vcc, %19, %11, vcc\n\t"
+        "v_subbrev_co_u32_e32 %4, vcc, %20, %12, vcc\n\t"
+        "v_subbrev_co_u32_e32 %5, vcc, %21, %13, vcc\n\t"
+        "v_subbrev_co_u32_e32 %6, vcc, %22, %14, vcc\n\t"
+        "v_subbrev_co_u32_e32 %7, vcc, %23, %15, vcc\n\t"
+        "v_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
+        "v_cndmask_b32_e32 %1, %1, %9, vcc\n\t"
+        "v_cndmask_b32_e32 %2, %2, %10, vcc\n\t"
+        "v_cndmask_b32_e32 %3, %3, %11, vcc\n\t"
+        "v_cndmask_b32_e32 %4, %4, %12, vcc\n\t"
+        "v_cndmask_b32_e32 %5, %5, %13, vcc\n\t"
+        "v_cndmask_b32_e32 %6, %6, %14, vcc\n\t"
+        "v_cndmask_b32_e32 %7, %7, %15, vcc"
+        : MI_O8(z) : MI_L8(x), MI_P8 : "vcc");
+    return z;
+}
+template <class P>
+MI_HD Fe<P> operator+(const Fe<P> &x, const Fe<P> &y) {
+    Fe<P> z, t;   // %0-7 z, %8-15 t, %16-23 x, %24-31 y, %32-39 p.   t = x + y (no carry out: p < 2^254); z = t - p; pick
+    asm("v_add_co_u32_e32 %8, vcc, %16, %24\n\t"
+        "v_addc_co_u32_e32 %9, vcc, %17, %25, vcc\n\t"
+        "v_addc_co_u32_e32 %10, vcc, %18, %26, vcc\n\t"
+        "v_addc_co_u32_e32 %11, vcc, %19, %27, vcc\n\t"
+        "v_addc_co_u32_e32 %12, vcc, %20, %28, vcc\n\t"
+        "v_addc_co_u32_e32 %13, vcc, %21, %29, vcc\n\t"
+        "v_addc_co_u32_e32 %14, vcc, %22, %30, vcc\n\t"
+        "v_addc_co_u32_e32 %15, vcc, %23, %31, vcc\n\t"
+        "v_subrev_co_u32_e32 %0, vcc, %32, %8\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, %33, %9, vcc\n\t"
+        "v_subbrev_co_u32_e32 %2, vcc, %34, %10, vcc\n\t"
+        "v_subbrev_co_u32_e32 %3, vcc, %35, %11, vcc\n\t"
+        "v_subbrev_co_u32_e32 %4, vcc, %36, %12, vcc\n\t"
+        "v_subbrev_co_u32_e32 %5, vcc, %37, %13, vcc\n\t"
+        "v_subbrev_co_u32_e32 %6, vcc, %38, %14, vcc\n\t"
+        "v_subbrev_co_u32_e32 %7, vcc, %39, %15, vcc\n\t"
+        "v_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
+        "v_cndmask_b32_e32 %1, %1, %9, vcc\n\t"
+        "v_cndmask_b32_e32 %2, %2, %10, vcc\n\t"
+        "v_cndmask_b32_e32 %3, %3, %11, vcc\n\t"
+        "v_cndmask_b32_e32 %4, %4, %12, vcc\n\t"
+        "v_cndmask_b32_e32 %5, %5, %13, vcc\n\t"
+        "v_cndmask_b32_e32 %6, %6, %14, vcc\n\t"
+        "v_cndmask_b32_e32 %7, %7, %15, vcc"
+        : MI_O8(z), MI_O8(t) : MI_L8(x), MI_L8(y), MI_P8 : "vcc");
+    return z;
+}
+template <class P>
+MI_HD Fe<P> operator-(const Fe<P> &x, const Fe<P> &y) {
+    Fe<P> z, t;   // %0-7 z, %8-15 t, %16 mask, %17-24 x, %25-32 y, %33-40 p.   z = x - y; mask = borrow ? ~0 : 0; z += p & mask
+    u32 mask;
+    asm("v_sub_co_u32_e32 %0, vcc, %17, %25\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %18, %26, vcc\n\t"
+        "v_subb_co_u32_e32 %2, vcc, %19, %27, vcc\n\t"
+        "v_subb_co_u32_e32 %3, vcc, %20, %28, vcc\n\t"
+        "v_subb_co_u32_e32 %4, vcc, %21, %29, vcc\n\t"
+        "v_subb_co_u32_e32 %5, vcc, %22, %30, vcc\n\t"
+        "v_subb_co_u32_e32 %6, vcc, %23, %31, vcc\n\t"
+        "v_subb_co_u32_e32 %7, vcc, %24, %32, vcc\n\t"
+        "v_cndmask_b32_e64 %16, 0, -1, vcc\n\t"
+        "v_and_b32_e32 %8, %33, %16\n\t"
+        "v_and_b32_e32 %9, %34, %16\n\t"
+        "v_and_b32_e32 %10, %35, %16\n\t"
+        "v_and_b32_e32 %11, %36, %16\n\t"
+        "v_and_b32_e32 %12, %37, %16\n\t"
+        "v_and_b32_e32 %13, %38, %16\n\t"
+        "v_and_b32_e32 %14, %39, %16\n\t"
+        "v_and_b32_e32 %15, %40, %16\n\t"
+        "v_add_co_u32_e32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %1, %9, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %10, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %3, %11, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %4, %12, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %5, %13, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %6, %14, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %7, %15, vcc"
+        : MI_O8(z), MI_O8(t), "=&v"(mask) : MI_L8(x), MI_L8(y), MI_P8 : "vcc");
+    return z;
+}
+#undef MI_L8
+#undef MI_O8
+#undef MI_P8
+#else
 // if x >= p: x -= p   (x < 2p)
 template <class P>
 MI_HD Fe<P> fe_reduce_once(const Fe<P> &x) {
@@ -115,6 +212,7 @@ MI_HD Fe<P> operator-(const Fe<P> &x, const Fe<P> &y) {
     for (int i = 0; i < 8; i++) z.l[i] = borrow ? e.l[i] : d.l[i];
     return z;
 }
+#endif
 template <class P>
 MI_HD Fe<P> fe_neg(const Fe<P> &x) {
     Fe<P> d;
