@@ -72,14 +72,17 @@ template <class F>
 __global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_affine(const Affine<F> *pts, const u32 *sorted, const u32 *start, const u32 *cnt,
                                                          const u32 *items, const u32 *item_start, u32 nkeys, u32 L,
                                                          XYZZ<F> *bucket, XYZZ<F> *partial_out) {
-    u32 item = blockIdx.x * blockDim.x + threadIdx.x;
-    msm_accum_affine_body<F>(pts, sorted, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
+    // grid-stride over the items: the grid is sized from a host-side bound, the real count lives on the device
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
+        msm_accum_affine_body<F>(pts, sorted, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
 }
 template <class F>
 __global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_xyzz(const XYZZ<F> *partial_in, const u32 *start, const u32 *cnt, const u32 *items,
                                                        const u32 *item_start, u32 nkeys, u32 L, XYZZ<F> *bucket, XYZZ<F> *partial_out) {
-    u32 item = blockIdx.x * blockDim.x + threadIdx.x;
-    msm_accum_xyzz_body<F>(partial_in, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
+        msm_accum_xyzz_body<F>(partial_in, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
 }
 template <class F>
 __global__ void __launch_bounds__(64) k_msm_bucket_reduce(const XYZZ<F> *bucket, u32 nbuckets, u32 seg, u32 tb, XYZZ<F> *out) {
@@ -208,7 +211,11 @@ static int32_t run_levels(mi_ctx *ctx, MsmSlot &sl, u32 nkeys, LevelArrays cur, 
         DevBuf &pout_buf = sl.buf[(level & 1) ? B_PART1 : B_PART0];
         MI_TRY(mi_reserve(ctx, pout_buf, (items_bound + 1) * sizeof(XYZZ<F>)));
         XYZZ<F> *pout = (XYZZ<F> *)pout_buf.p;
+        // persistent-style grid: at most 32 single-wave workgroups per CU (8 waves per SIMD), grid-stride inside.  Levels that turn out to
+        // be (nearly) empty -- the bound is a worst case -- then cost a few microseconds instead of a full dispatch.
         u32 grid = (u32)((items_bound + 63) / 64);
+        const u32 grid_cap = (u32)ctx->cu_count * 32;
+        if (grid > grid_cap) grid = grid_cap;
         if (grid == 0) grid = 1;
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
         if (level == 0 && pts)
@@ -266,7 +273,7 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, MsmSlot &srt, MsmSlot &acc, const 
     acc.n = srt.n; acc.c = srt.c; acc.G = srt.G;
     const MsmShape s = slot_shape(srt);
     const u32 n = s.n;
-    const u32 L1 = kn->L1 ? kn->L1 : 32, L2 = kn->L2 ? kn->L2 : 16;
+    const u32 L1 = kn->L1 ? kn->L1 : 16, L2 = kn->L2 ? kn->L2 : 8;   // tools/tune.py sweep, N = 2^23
     const u32 seg = kn->seg ? kn->seg : (s.nbuckets >= 256 ? 8 : 2);
     const u64 T_bound = (u64)s.nwin * n;
     hipStream_t st = acc.stream;

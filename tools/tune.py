@@ -34,7 +34,7 @@ if "msm" in which:
     for dist in (0, 1):
         s = ctx.gen_scalars(n, 12, dist)
         for (c, L1, L2, seg, G) in ((0, 0, 0, 0, 0), (16, 16, 16, 8, 64), (16, 64, 16, 8, 64), (16, 32, 32, 8, 64), (16, 32, 8, 8, 64),
-                                    (16, 32, 16, 4, 64), (16, 32, 16, 16, 64), (16, 32, 16, 8, 32), (16, 32, 16, 8, 128), (15, 32, 16, 8, 64), (14, 32, 16, 8, 64)):
+                                    (16, 32, 16, 4, 64), (16, 32, 16, 16, 64), (16, 32, 4, 8, 64), (16, 32, 4, 4, 64), (16, 16, 8, 8, 64), (16, 16, 4, 4, 64)):
             assert lib.mi_debug_set_msm_plan(ctx.h, c, L1, L2, seg, G) == 0
             best, acc = 1e9, 1e9
             for _ in range(2):
@@ -44,11 +44,17 @@ if "msm" in which:
             print("msm", dist, c, L1, L2, seg, G, best, acc, flush=True)
         s.free()
     lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0)
+if "g2" in which:
     p2 = ctx.gen_g2(n // 2, 13); s2 = ctx.gen_scalars(n // 2, 14, 1)
-    for _ in range(2):
-        ctx.msm_g2_dev(p2.ptr, s2.ptr, n // 2)
-        print("msm_g2 whir 2^22", ctx.stats()["total_ms"], flush=True)
-    out["msm_g2_whir_2p22"] = ctx.stats()["total_ms"]
+    for (c, L1, L2, seg, G) in ((0, 0, 0, 0, 0), (16, 32, 8, 8, 64), (16, 32, 4, 8, 64), (16, 32, 4, 4, 64), (16, 32, 8, 4, 64), (16, 16, 8, 8, 64), (16, 16, 4, 4, 64), (16, 32, 2, 4, 64)):
+        assert lib.mi_debug_set_msm_plan(ctx.h, c, L1, L2, seg, G) == 0
+        best = 1e9
+        for _ in range(2):
+            ctx.msm_g2_dev(p2.ptr, s2.ptr, n // 2)
+            best = min(best, ctx.stats()["total_ms"])
+        out[f"g2_c{c}_L{L1}_{L2}_seg{seg}"] = best
+        print("msm_g2 whir 2^22", c, L1, L2, seg, G, best, flush=True)
+    lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/tune.json", "w"), indent=1)
 ctx.close()
