@@ -17,6 +17,7 @@
 #include "msm_core.cuh"
 #include <cstring>
 #include <new>
+#include <type_traits>
 
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
@@ -68,6 +69,68 @@ __global__ void k_msm_prep_windows(u32 nwin, u32 tb, u32 L, u32 *start, u32 *cnt
 // fastest point (2.6 G madd/s vs 2.0 at 1 wave and 1.5 at 4 waves).
 template <class F> struct AccumWaves { static constexpr int value = 1; };
 template <> struct AccumWaves<Fp2> { static constexpr int value = 2; };
+// G2 level-1 accumulation with the XYZZ accumulator resident in LDS ([word][lane] image, 16 KiB per 64-lane
+// workgroup): only the operands of the current step live in VGPRs, so the kernel needs no scratch (the register
+// version spilled 480 B per lane -- 9.5 GB of scratch writes per launch in the PMC pass).
+struct LdsAccG2 {
+    u32 *base;   // &lds[0][lane]
+    MI_D Fp2 ld(int comp) const {
+        Fp2 v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v.a0.l[i] = base[(comp * 16 + i) * 64]; v.a1.l[i] = base[(comp * 16 + 8 + i) * 64]; }
+        return v;
+    }
+    MI_D void st(int comp, const Fp2 &v) const {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { base[(comp * 16 + i) * 64] = v.a0.l[i]; base[(comp * 16 + 8 + i) * 64] = v.a1.l[i]; }
+    }
+    MI_D G2X load() const { return G2X{ld(0), ld(1), ld(2), ld(3)}; }
+    MI_D void store(const G2X &a) const { st(0, a.x); st(1, a.y); st(2, a.zz); st(3, a.zzz); }
+};
+// acc += (+/-) q  (madd-2008-s, same special cases as xyzz_madd); inf tracks "accumulator is the point at infinity"
+MI_D void xyzz_madd_lds(const LdsAccG2 &A, bool &inf, const G2Aff &q, bool negate) {
+    if (q.is_inf()) return;
+    Fp2 qy = negate ? fe_neg(q.y) : q.y;
+    if (inf) { A.st(0, q.x); A.st(1, qy); A.st(2, Fp2::one()); A.st(3, Fp2::one()); inf = false; return; }
+    Fp2 U2 = q.x * A.ld(2);
+    Fp2 S2 = qy * A.ld(3);
+    Fp2 x = A.ld(0);
+    Fp2 Pp = U2 - x;
+    Fp2 R = S2 - A.ld(1);
+    if (Pp.is_zero()) {   // rare: doubling or cancellation -> generic path through registers
+        G2X acc = A.load();
+        xyzz_madd(acc, q, negate);
+        inf = acc.is_inf();
+        A.store(acc);
+        return;
+    }
+    Fp2 PP = fe_sqr(Pp);
+    Fp2 PPP = Pp * PP;
+    Fp2 Q = x * PP;
+    A.st(2, A.ld(2) * PP);
+    A.st(3, A.ld(3) * PPP);
+    Fp2 X3 = fe_sqr(R) - PPP - fe_dbl(Q);
+    A.st(0, X3);
+    A.st(1, R * (Q - X3) - A.ld(1) * PPP);
+}
+__global__ void __launch_bounds__(64, 2) k_msm_accum_affine_g2_lds(const G2Aff *pts, const u32 *sorted, const u32 *start, const u32 *cnt,
+                                                                   const u32 *items, const u32 *item_start, u32 nkeys, u32 L,
+                                                                   G2X *bucket, G2X *partial_out) {
+    __shared__ u32 lds[64 * 64];
+    const LdsAccG2 A{&lds[threadIdx.x]};
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+        u32 key = msm_item_key(item_start, nkeys, item), b, e;
+        msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
+        bool inf = true;
+        for (u32 k = b; k < e; k++) {
+            u32 v = sorted[k];
+            xyzz_madd_lds(A, inf, pts[v & 0x7fffffffu], (v >> 31) != 0);
+        }
+        G2X acc = inf ? G2X::inf() : A.load();
+        if (items[key] == 1) bucket[key] = acc; else partial_out[item] = acc;
+    }
+}
 template <class F>
 __global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_affine(const Affine<F> *pts, const u32 *sorted, const u32 *start, const u32 *cnt,
                                                          const u32 *items, const u32 *item_start, u32 nkeys, u32 L,
@@ -218,8 +281,12 @@ static int32_t run_levels(mi_ctx *ctx, MsmSlot &sl, u32 nkeys, LevelArrays cur, 
         if (grid > grid_cap) grid = grid_cap;
         if (grid == 0) grid = 1;
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
-        if (level == 0 && pts)
-            hipLaunchKernelGGL(k_msm_accum_affine<F>, dim3(grid), dim3(64), 0, st, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+        if (level == 0 && pts) {
+            if constexpr (std::is_same<F, Fp2>::value)
+                hipLaunchKernelGGL(k_msm_accum_affine_g2_lds, dim3(grid), dim3(64), 0, st, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+            else
+                hipLaunchKernelGGL(k_msm_accum_affine<F>, dim3(grid), dim3(64), 0, st, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+        }
         else
             hipLaunchKernelGGL(k_msm_accum_xyzz<F>, dim3(grid), dim3(64), 0, st, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         MI_CHECK_HIP(ctx, hipGetLastError());

@@ -185,3 +185,16 @@ def test_msm_sharding_identity_at_2p26(ctx):
     assert whole[8:].any()
     for d in (pts, s):
         d.free()
+
+
+def test_msm_g2_repeated_and_opposite_points(ctx):
+    """buckets that see P + P (doubling) and P + (-P) (cancellation) on the G2 path"""
+    n = 400
+    pts = cref.gen_g2(n, 321); sc = cref.gen_scalars(n, 322, 1)
+    for i in range(0, 60, 3):
+        pts[i + 1] = pts[i]; sc[i + 1] = sc[i]                                   # same point, same scalar: doubling in a bucket
+        pts[i + 2] = g2_arr([P.g2_neg(g2_pts(pts[i:i + 1])[0])])[0]; sc[i + 2] = sc[i]   # opposite point: cancellation
+    pts[77] = 0
+    assert _jac_eq(ctx.msm_g2(pts, sc), cref.msm_g2(pts, sc))
+    allsame = np.repeat(pts[:1], 64, axis=0); ones = fr_arr([1] * 64)
+    assert g2_from_jac(ctx.msm_g2(allsame, ones)) == P.g2_mul(g2_pts(pts[:1])[0], 64)

@@ -15,6 +15,59 @@ __global__ void __launch_bounds__(64, WAVES) k_madd(XYZZ<F> *acc_io, const Affin
     for (int i = 0; i < n; i++) xyzz_madd(acc, pts[(t * 7 + (size_t)i * 131) % npts], false);
     acc_io[t] = acc;
 }
+// G2 variant with the XYZZ accumulator resident in LDS ([word][lane] image): only the operands of the current
+// step live in VGPRs.
+#ifndef LDSW
+#define LDSW 2
+#endif
+struct LdsAcc {
+    u32 *base;   // &lds[0][lane]
+    MI_D Fp2 ld(int comp) const {
+        Fp2 v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v.a0.l[i] = base[(comp * 16 + i) * 64]; v.a1.l[i] = base[(comp * 16 + 8 + i) * 64]; }
+        return v;
+    }
+    MI_D void st(int comp, const Fp2 &v) const {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { base[(comp * 16 + i) * 64] = v.a0.l[i]; base[(comp * 16 + 8 + i) * 64] = v.a1.l[i]; }
+    }
+};
+MI_D void madd_lds(const LdsAcc &A, bool &inf, const G2Aff &q) {
+    if (q.is_inf()) return;
+    if (inf) { A.st(0, q.x); A.st(1, q.y); A.st(2, Fp2::one()); A.st(3, Fp2::one()); inf = false; return; }
+    Fp2 U2 = q.x * A.ld(2);
+    Fp2 S2 = q.y * A.ld(3);
+    Fp2 x = A.ld(0);
+    Fp2 Pp = U2 - x;
+    Fp2 R = S2 - A.ld(1);
+    if (Pp.is_zero()) {   // rare: doubling or cancellation -> generic path through registers
+        G2X acc{A.ld(0), A.ld(1), A.ld(2), A.ld(3)};
+        xyzz_madd(acc, q, false);
+        if (acc.is_inf()) inf = true;
+        A.st(0, acc.x); A.st(1, acc.y); A.st(2, acc.zz); A.st(3, acc.zzz);
+        return;
+    }
+    Fp2 PP = fe_sqr(Pp);
+    Fp2 PPP = Pp * PP;
+    Fp2 Q = x * PP;
+    A.st(2, A.ld(2) * PP);
+    A.st(3, A.ld(3) * PPP);
+    Fp2 X3 = fe_sqr(R) - PPP - fe_dbl(Q);
+    A.st(0, X3);
+    Fp2 Y3 = R * (Q - X3) - A.ld(1) * PPP;
+    A.st(1, Y3);
+}
+__global__ void __launch_bounds__(64, LDSW) k_madd_lds(G2X *acc_io, const G2Aff *pts, int n, int npts) {
+    __shared__ u32 lds[64 * 64];
+    size_t t = (size_t)blockIdx.x * 64 + threadIdx.x;
+    LdsAcc A{&lds[threadIdx.x]};
+    G2X a0 = acc_io[t];
+    A.st(0, a0.x); A.st(1, a0.y); A.st(2, a0.zz); A.st(3, a0.zzz);
+    bool inf = a0.is_inf();
+    for (int i = 0; i < n; i++) madd_lds(A, inf, pts[(t * 7 + (size_t)i * 131) % npts]);
+    acc_io[t] = G2X{A.ld(0), A.ld(1), A.ld(2), A.ld(3)};
+}
 template <class F>
 __global__ void k_init(XYZZ<F> *acc, Affine<F> *pts, size_t nacc, int npts, const Affine<F> base) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,5 +113,25 @@ int main() {
     g2.y.a0 = L(0x4ce6cc0166fa7daaull, 0xe3d1e7690c43d37bull, 0x4aab71808dcb408full, 0x12c85ea5db8c6debull);
     g2.y.a1 = L(0x55acdadcd122975bull, 0xbc4b313370b38ef3ull, 0xec9e99ad690c3395ull, 0x090689d0585ff075ull);
     run<Fp2>("G2", g2);
+    {   // LDS-accumulator variant, checked against the register variant
+        const int npts = 4096, n = 48;
+        const size_t nthreads = (size_t)256 * 32 * 64;
+        G2X *acc, *acc2; G2Aff *pts;
+        hipMalloc(&acc, nthreads * sizeof(G2X)); hipMalloc(&acc2, nthreads * sizeof(G2X)); hipMalloc(&pts, npts * sizeof(G2Aff));
+        hipLaunchKernelGGL(k_init<Fp2>, dim3((unsigned)(nthreads / 256)), dim3(256), 0, 0, acc, pts, nthreads, npts, g2);
+        hipLaunchKernelGGL(k_init<Fp2>, dim3((unsigned)(nthreads / 256)), dim3(256), 0, 0, acc2, pts, nthreads, npts, g2);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipLaunchKernelGGL(k_madd<Fp2>, dim3((unsigned)(nthreads / 64)), dim3(64), 0, 0, acc2, pts, n, npts);
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k_madd_lds, dim3((unsigned)(nthreads / 64)), dim3(64), 0, 0, acc, pts, n, npts);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        std::vector<G2X> h1(4096), h2(4096);
+        hipMemcpy(h1.data(), acc, 4096 * sizeof(G2X), hipMemcpyDeviceToHost); hipMemcpy(h2.data(), acc2, 4096 * sizeof(G2X), hipMemcpyDeviceToHost);
+        int bad = 0;
+        for (int i = 0; i < 4096; i++) { G2Aff a = xyzz_to_affine(h1[i]), b = xyzz_to_affine(h2[i]); if (!(a.x == b.x) || !(a.y == b.y)) bad++; }
+        printf("G2 LDS-acc waves=%d : %.3f ms -> %.2f G madd/s  mismatches=%d\n", LDSW, ms, nthreads * (double)n / ms / 1e6, bad);
+    }
     return 0;
 }
