@@ -191,6 +191,12 @@ int32_t mi_bench_modmul_dev(mi_ctx *ctx, int field, size_t n_threads, uint32_t i
  * each thread runs 8 independent chains x iters steps */
 int32_t mi_bench_valu_dev(mi_ctx *ctx, int kind, size_t n_threads, uint32_t iters,
                           void *scratch_dev, float *ms_out);
+/* tuning / test knobs (0 = automatic).  NTT: tile = 2^log_e elements, radix caps of the contiguous and the
+ * strided passes, threads per workgroup.  MSM: window bits c (2..16), item sizes of level 1 / later levels,
+ * bucket-reduce segment, slices per window.  Tests use them to force multi-pass / multi-level paths at small n. */
+int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, uint32_t max_strided);
+int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads);
+int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G);
 /* raw device memory helpers so hosts without a HIP binding (ctypes, cgo) can stage data */
 int32_t mi_dev_alloc(mi_ctx *ctx, size_t bytes, void **out_dev);
 int32_t mi_dev_free(mi_ctx *ctx, void *dev);
