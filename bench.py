@@ -69,7 +69,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
