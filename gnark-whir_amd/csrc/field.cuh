@@ -10,9 +10,12 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__)
+#if defined(__HIPCC__) && defined(__HIP_DEVICE_COMPILE__)
 #define MI_HD __host__ __device__ __forceinline__
 #define MI_D __device__ __forceinline__
+#elif defined(__HIPCC__)   // host pass of a .hip file: same functions, ordinary inlining (forced inlining of the whole
+#define MI_HD __host__ __device__ inline   // curve arithmetic into the host-side assembly code took minutes to compile)
+#define MI_D __device__ inline
 #else
 #define MI_HD inline
 #define MI_D inline

@@ -15,9 +15,9 @@
 // figure reported for it is the algorithmic 96 B (160 B) per pair of SURVEY 8d over its duration.
 #include "ctx.h"
 #include "msm_core.cuh"
+#include "msm_curve_ops.h"
 #include <cstring>
 #include <new>
-#include <type_traits>
 
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
@@ -64,95 +64,6 @@ __global__ void k_msm_prep_windows(u32 nwin, u32 tb, u32 L, u32 *start, u32 *cnt
     u32 w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < nwin) { start[w] = w * tb; cnt[w] = tb; items[w] = (tb + L - 1) / L; }
 }
-// Occupancy target per curve (measured with tools/bench_g2 on MI355X): the G1 mixed add needs ~60 VGPRs and runs
-// 8 waves/SIMD; the G2 one wants > 256 -- 2 waves/SIMD with the Fp multiplier out of line (480 B of scratch) is the
-// fastest point (2.6 G madd/s vs 2.0 at 1 wave and 1.5 at 4 waves).
-template <class F> struct AccumWaves { static constexpr int value = 1; };
-template <> struct AccumWaves<Fp2> { static constexpr int value = 2; };
-// G2 level-1 accumulation with the XYZZ accumulator resident in LDS ([word][lane] image, 16 KiB per 64-lane
-// workgroup): only the operands of the current step live in VGPRs, so the kernel needs no scratch (the register
-// version spilled 480 B per lane -- 9.5 GB of scratch writes per launch in the PMC pass).
-struct LdsAccG2 {
-    u32 *base;   // &lds[0][lane]
-    MI_D Fp2 ld(int comp) const {
-        Fp2 v;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { v.a0.l[i] = base[(comp * 16 + i) * 64]; v.a1.l[i] = base[(comp * 16 + 8 + i) * 64]; }
-        return v;
-    }
-    MI_D void st(int comp, const Fp2 &v) const {
-#pragma unroll
-        for (int i = 0; i < 8; i++) { base[(comp * 16 + i) * 64] = v.a0.l[i]; base[(comp * 16 + 8 + i) * 64] = v.a1.l[i]; }
-    }
-    MI_D G2X load() const { return G2X{ld(0), ld(1), ld(2), ld(3)}; }
-    MI_D void store(const G2X &a) const { st(0, a.x); st(1, a.y); st(2, a.zz); st(3, a.zzz); }
-};
-// acc += (+/-) q  (madd-2008-s, same special cases as xyzz_madd); inf tracks "accumulator is the point at infinity"
-MI_D void xyzz_madd_lds(const LdsAccG2 &A, bool &inf, const G2Aff &q, bool negate) {
-    if (q.is_inf()) return;
-    Fp2 qy = negate ? fe_neg(q.y) : q.y;
-    if (inf) { A.st(0, q.x); A.st(1, qy); A.st(2, Fp2::one()); A.st(3, Fp2::one()); inf = false; return; }
-    Fp2 U2 = q.x * A.ld(2);
-    Fp2 S2 = qy * A.ld(3);
-    Fp2 x = A.ld(0);
-    Fp2 Pp = U2 - x;
-    Fp2 R = S2 - A.ld(1);
-    if (Pp.is_zero()) {   // rare: doubling or cancellation -> generic path through registers
-        G2X acc = A.load();
-        xyzz_madd(acc, q, negate);
-        inf = acc.is_inf();
-        A.store(acc);
-        return;
-    }
-    Fp2 PP = fe_sqr(Pp);
-    Fp2 PPP = Pp * PP;
-    Fp2 Q = x * PP;
-    A.st(2, A.ld(2) * PP);
-    A.st(3, A.ld(3) * PPP);
-    Fp2 X3 = fe_sqr(R) - PPP - fe_dbl(Q);
-    A.st(0, X3);
-    A.st(1, R * (Q - X3) - A.ld(1) * PPP);
-}
-__global__ void __launch_bounds__(64, 2) k_msm_accum_affine_g2_lds(const G2Aff *pts, const u32 *sorted, const u32 *start, const u32 *cnt,
-                                                                   const u32 *items, const u32 *item_start, u32 nkeys, u32 L,
-                                                                   G2X *bucket, G2X *partial_out) {
-    __shared__ u32 lds[64 * 64];
-    const LdsAccG2 A{&lds[threadIdx.x]};
-    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
-    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
-        u32 key = msm_item_key(item_start, nkeys, item), b, e;
-        msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
-        bool inf = true;
-        for (u32 k = b; k < e; k++) {
-            u32 v = sorted[k];
-            xyzz_madd_lds(A, inf, pts[v & 0x7fffffffu], (v >> 31) != 0);
-        }
-        G2X acc = inf ? G2X::inf() : A.load();
-        if (items[key] == 1) bucket[key] = acc; else partial_out[item] = acc;
-    }
-}
-template <class F>
-__global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_affine(const Affine<F> *pts, const u32 *sorted, const u32 *start, const u32 *cnt,
-                                                         const u32 *items, const u32 *item_start, u32 nkeys, u32 L,
-                                                         XYZZ<F> *bucket, XYZZ<F> *partial_out) {
-    // grid-stride over the items: the grid is sized from a host-side bound, the real count lives on the device
-    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
-    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
-        msm_accum_affine_body<F>(pts, sorted, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
-}
-template <class F>
-__global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_xyzz(const XYZZ<F> *partial_in, const u32 *start, const u32 *cnt, const u32 *items,
-                                                       const u32 *item_start, u32 nkeys, u32 L, XYZZ<F> *bucket, XYZZ<F> *partial_out) {
-    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
-    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
-        msm_accum_xyzz_body<F>(partial_in, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
-}
-template <class F>
-__global__ void __launch_bounds__(64) k_msm_bucket_reduce(const XYZZ<F> *bucket, u32 nbuckets, u32 seg, u32 tb, XYZZ<F> *out) {
-    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < tb) msm_bucket_reduce_body<F>(bucket, nbuckets, seg, out, blockIdx.y, t);
-}
-
 // ---------------------------------------------------------------- exclusive scan of u32 (out has m+1 entries, out[m] = total)
 static constexpr u32 SCAN_PER_THREAD = 16, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_PER_THREAD * SCAN_THREADS;
 __device__ u32 block_exclusive_scan_256(u32 v, u32 *lds, u32 *total) {
@@ -260,20 +171,19 @@ enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCA
 
 // Runs levels of the item machinery over `nkeys` keys whose level-0 decomposition (start/cnt/items) is
 // already in cur.  Level 0 reads (pts, sorted) when pts != null, else partial_first.
-template <class F>
-static int32_t run_levels(mi_ctx *ctx, MsmSlot &sl, u32 nkeys, LevelArrays cur, LevelArrays nxt, u64 first_items_bound, u64 max_count,
-                          u32 L_first, u32 L_next, const Affine<F> *pts, const u32 *sorted, const XYZZ<F> *partial_first,
-                          XYZZ<F> *final_out, bool time_first) {
+static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 nkeys, LevelArrays cur, LevelArrays nxt, u64 first_items_bound,
+                          u64 max_count, u32 L_first, u32 L_next, const void *pts, const u32 *sorted, const void *partial_first,
+                          void *final_out, bool time_first) {
     hipStream_t st = sl.stream;
-    const XYZZ<F> *pin = partial_first;
+    const void *pin = partial_first;
     u64 items_bound = first_items_bound;
     u64 m = max_count;  // bound on entries of the largest key at this level
     u32 L = L_first;
     for (u32 level = 0;; level++) {
         MI_TRY(exclusive_scan(ctx, st, cur.items, nkeys, cur.item_start, sl.buf[B_SCAN]));
         DevBuf &pout_buf = sl.buf[(level & 1) ? B_PART1 : B_PART0];
-        MI_TRY(mi_reserve(ctx, pout_buf, (items_bound + 1) * sizeof(XYZZ<F>)));
-        XYZZ<F> *pout = (XYZZ<F> *)pout_buf.p;
+        MI_TRY(mi_reserve(ctx, pout_buf, (items_bound + 1) * ops.xyzz_bytes));
+        void *pout = pout_buf.p;
         // persistent-style grid: at most 32 single-wave workgroups per CU (8 waves per SIMD), grid-stride inside.  Levels that turn out to
         // be (nearly) empty -- the bound is a worst case -- then cost a few microseconds instead of a full dispatch.
         u32 grid = (u32)((items_bound + 63) / 64);
@@ -281,14 +191,8 @@ static int32_t run_levels(mi_ctx *ctx, MsmSlot &sl, u32 nkeys, LevelArrays cur, 
         if (grid > grid_cap) grid = grid_cap;
         if (grid == 0) grid = 1;
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
-        if (level == 0 && pts) {
-            if constexpr (std::is_same<F, Fp2>::value)
-                hipLaunchKernelGGL(k_msm_accum_affine_g2_lds, dim3(grid), dim3(64), 0, st, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
-            else
-                hipLaunchKernelGGL(k_msm_accum_affine<F>, dim3(grid), dim3(64), 0, st, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
-        }
-        else
-            hipLaunchKernelGGL(k_msm_accum_xyzz<F>, dim3(grid), dim3(64), 0, st, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+        if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+        else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         MI_CHECK_HIP(ctx, hipGetLastError());
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], st));
         u64 m_next = (m + L - 1) / L;  // entries of the largest key at the next level
@@ -334,8 +238,7 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
 }
 
 // accumulate stage on slot acc, reading the sort of slot srt (may be the same slot)
-template <class F>
-static int32_t msm_accum_enqueue(mi_ctx *ctx, MsmSlot &srt, MsmSlot &acc, const Affine<F> *pts, bool timed) {
+static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &srt, MsmSlot &acc, const void *pts, bool timed) {
     MsmKnobs *kn = knobs_of(ctx);
     acc.n = srt.n; acc.c = srt.c; acc.G = srt.G;
     const MsmShape s = slot_shape(srt);
@@ -346,25 +249,25 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, MsmSlot &srt, MsmSlot &acc, const 
     hipStream_t st = acc.stream;
     if (&srt != &acc) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, srt.ev[0], 0));
     MI_TRY(mi_reserve(ctx, acc.buf[B_LEVELS], ((size_t)s.nkeys + 1) * 4 * 8));
-    MI_TRY(mi_reserve(ctx, acc.buf[B_BUCKET], (size_t)s.nkeys * sizeof(XYZZ<F>)));
+    MI_TRY(mi_reserve(ctx, acc.buf[B_BUCKET], (size_t)s.nkeys * ops.xyzz_bytes));
     const u32 *S = (const u32 *)srt.buf[B_S].p, *sorted = (const u32 *)srt.buf[B_SORTED].p;
     u32 *la = (u32 *)acc.buf[B_LEVELS].p;
     const size_t stride = (size_t)s.nkeys + 1;
     LevelArrays A{la, la + stride, la + 2 * stride, la + 3 * stride}, B{la + 4 * stride, la + 5 * stride, la + 6 * stride, la + 7 * stride};
-    XYZZ<F> *bucket = (XYZZ<F> *)acc.buf[B_BUCKET].p;
-    MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * sizeof(XYZZ<F>), st));
+    void *bucket = acc.buf[B_BUCKET].p;
+    MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * ops.xyzz_bytes, st));
     hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, S, L1, A.start, A.cnt, A.items);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(run_levels<F>(ctx, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, n, L1, L2, pts, sorted, nullptr, bucket, timed));
+    MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, n, L1, L2, pts, sorted, nullptr, bucket, timed));
     // bucket reduce -> per-window partials -> window sums -> pinned host memory
     const u32 tb = (s.nbuckets + seg - 1) / seg;
-    MI_TRY(mi_reserve(ctx, acc.buf[B_WIN], ((size_t)s.nwin * tb + s.nwin + 1) * sizeof(XYZZ<F>)));
-    XYZZ<F> *P = (XYZZ<F> *)acc.buf[B_WIN].p, *wsum = P + (size_t)s.nwin * tb;
-    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3((tb + 63) / 64, s.nwin), dim3(64), 0, st, bucket, s.nbuckets, seg, tb, P);
+    MI_TRY(mi_reserve(ctx, acc.buf[B_WIN], ((size_t)s.nwin * tb + s.nwin + 1) * ops.xyzz_bytes));
+    char *P = (char *)acc.buf[B_WIN].p, *wsum = P + (size_t)s.nwin * tb * ops.xyzz_bytes;
+    ops.bucket_reduce(st, (tb + 63) / 64, s.nwin, bucket, s.nbuckets, seg, tb, P);
     hipLaunchKernelGGL(k_msm_prep_windows, dim3(1), dim3(128), 0, st, s.nwin, tb, L2, A.start, A.cnt, A.items);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(run_levels<F>(ctx, acc, s.nwin, A, B, (u64)s.nwin * ((tb + L2 - 1) / L2) + 1, tb, L2, L2, (const Affine<F> *)nullptr, nullptr, P, wsum, false));
-    MI_CHECK_HIP(ctx, hipMemcpyAsync(acc.host_wsum, wsum, sizeof(XYZZ<F>) * s.nwin, hipMemcpyDeviceToHost, st));
+    MI_TRY(run_levels(ctx, ops, acc, s.nwin, A, B, (u64)s.nwin * ((tb + L2 - 1) / L2) + 1, tb, L2, L2, nullptr, nullptr, P, wsum, false));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync(acc.host_wsum, wsum, ops.xyzz_bytes * s.nwin, hipMemcpyDeviceToHost, st));
     // number of sorted entries (= mixed additions of level 1) for the stats: keystart[nkeys]
     MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)acc.host_wsum + 128 * 256, (const u32 *)srt.buf[B_S].p + s.nkeys, 4, hipMemcpyDeviceToHost, st));
     MI_CHECK_HIP(ctx, hipEventRecord(acc.ev[4], st));
@@ -373,12 +276,11 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, MsmSlot &srt, MsmSlot &acc, const 
     return MI_OK;
 }
 
-template <class F>
-static int32_t msm_finish(mi_ctx *ctx, MsmSlot &sl, XYZZ<F> *out) {
-    if (!sl.active) { *out = XYZZ<F>::inf(); return MI_OK; }
+static int32_t msm_finish(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, void *out) {
+    if (!sl.active) { ops.combine_windows(nullptr, 0, 0, out); return MI_OK; }   // zero windows -> infinity
     MI_CHECK_HIP(ctx, hipStreamSynchronize(sl.stream));
     const MsmShape s = slot_shape(sl);
-    *out = msm_combine_windows<F>((const XYZZ<F> *)sl.host_wsum, s.nwin, s.c);   // Horner on the host, <= 128 points
+    ops.combine_windows(sl.host_wsum, s.nwin, s.c, out);   // Horner on the host, <= 128 points
     if (sl.timed) {
         float ms = 0;
         MI_CHECK_HIP(ctx, hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
@@ -404,13 +306,11 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     MsmSlot &srt = sort_slot >= 0 ? ctx->msm[sort_slot] : sl;
     if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags));
     else if (srt.n != n) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
-    if (curve == 1) return msm_accum_enqueue<Fp>(ctx, srt, sl, (const G1Aff *)pts_dev, timed);
-    return msm_accum_enqueue<Fp2>(ctx, srt, sl, (const G2Aff *)pts_dev, timed);
+    return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed);
 }
 int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host) {
     if (slot < 0 || slot >= MI_MSM_SLOTS) return MI_EINVAL;
-    if (curve == 1) return msm_finish<Fp>(ctx, ctx->msm[slot], (G1X *)out_xyzz_host);
-    return msm_finish<Fp2>(ctx, ctx->msm[slot], (G2X *)out_xyzz_host);
+    return msm_finish(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), ctx->msm[slot], out_xyzz_host);
 }
 
 template <class F, class JacT>

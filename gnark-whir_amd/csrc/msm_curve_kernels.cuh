@@ -1,0 +1,54 @@
+// Point kernels of the MSM, templated on the coordinate field; included by msm_g1.hip (F = Fp) and msm_g2.hip (F = Fp2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "msm_core.cuh"
+#include "msm_curve_ops.h"
+
+// Occupancy target per curve (measured with tools/bench_g2 on MI355X): the G1 mixed add needs ~60 VGPRs and runs
+// 8 waves/SIMD; the G2 one wants > 256 -- 2 waves/SIMD with the Fp multiplier out of line (480 B of scratch) is the
+// fastest point (2.6 G madd/s vs 2.0 at 1 wave and 1.5 at 4 waves).
+template <class F> struct AccumWaves { static constexpr int value = 1; };
+template <> struct AccumWaves<Fp2> { static constexpr int value = 2; };
+template <class F>
+__global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_affine(const Affine<F> *pts, const u32 *sorted, const u32 *start, const u32 *cnt,
+                                                         const u32 *items, const u32 *item_start, u32 nkeys, u32 L,
+                                                         XYZZ<F> *bucket, XYZZ<F> *partial_out) {
+    // grid-stride over the items: the grid is sized from a host-side bound, the real count lives on the device
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
+        msm_accum_affine_body<F>(pts, sorted, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
+}
+template <class F>
+__global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_xyzz(const XYZZ<F> *partial_in, const u32 *start, const u32 *cnt, const u32 *items,
+                                                       const u32 *item_start, u32 nkeys, u32 L, XYZZ<F> *bucket, XYZZ<F> *partial_out) {
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
+        msm_accum_xyzz_body<F>(partial_in, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_bucket_reduce(const XYZZ<F> *bucket, u32 nbuckets, u32 seg, u32 tb, XYZZ<F> *out) {
+    u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < tb) msm_bucket_reduce_body<F>(bucket, nbuckets, seg, out, blockIdx.y, t);
+}
+
+
+template <class F>
+static void launch_accum_affine(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
+                                const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout) {
+    hipLaunchKernelGGL(k_msm_accum_affine<F>, dim3(grid), dim3(64), 0, st, (const Affine<F> *)pts, sorted, start, cnt, items, item_start, nkeys, L,
+                       (XYZZ<F> *)bucket, (XYZZ<F> *)pout);
+}
+template <class F>
+static void launch_accum_xyzz(hipStream_t st, unsigned grid, const void *pin, const u32 *start, const u32 *cnt, const u32 *items, const u32 *item_start,
+                              u32 nkeys, u32 L, void *bucket, void *pout) {
+    hipLaunchKernelGGL(k_msm_accum_xyzz<F>, dim3(grid), dim3(64), 0, st, (const XYZZ<F> *)pin, start, cnt, items, item_start, nkeys, L,
+                       (XYZZ<F> *)bucket, (XYZZ<F> *)pout);
+}
+template <class F>
+static void launch_bucket_reduce(hipStream_t st, unsigned grid_x, unsigned nwin, const void *bucket, u32 nbuckets, u32 seg, u32 tb, void *out) {
+    hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(grid_x, nwin), dim3(64), 0, st, (const XYZZ<F> *)bucket, nbuckets, seg, tb, (XYZZ<F> *)out);
+}
+template <class F>
+static void host_combine_windows(const void *wsum, u32 nwin, u32 c, void *out) {
+    *(XYZZ<F> *)out = nwin ? msm_combine_windows<F>((const XYZZ<F> *)wsum, nwin, c) : XYZZ<F>::inf();
+}

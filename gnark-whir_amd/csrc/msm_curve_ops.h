@@ -1,0 +1,20 @@
+// Per-curve entry points of the MSM (kernel launchers + the host-side window combine).  msm.hip holds the curve-
+// independent orchestration (sort, item levels, streams); msm_g1.hip / msm_g2.hip instantiate the point kernels, so the
+// two heavy translation units build in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+struct MsmCurveOps {
+    size_t xyzz_bytes;   // sizeof(XYZZ<F>): 128 (G1) / 256 (G2)
+    void (*accum_affine)(hipStream_t st, unsigned grid, const void *pts, const uint32_t *sorted, const uint32_t *start, const uint32_t *cnt,
+                         const uint32_t *items, const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out);
+    void (*accum_xyzz)(hipStream_t st, unsigned grid, const void *partial_in, const uint32_t *start, const uint32_t *cnt, const uint32_t *items,
+                       const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out);
+    void (*bucket_reduce)(hipStream_t st, unsigned grid_x, unsigned nwin, const void *bucket, uint32_t nbuckets, uint32_t seg, uint32_t tb, void *out);
+    // total = sum_w 2^(c*w) * wsum[w] on the host; nwin == 0 yields the point at infinity
+    void (*combine_windows)(const void *host_wsum, uint32_t nwin, uint32_t c, void *out_xyzz);
+};
+const MsmCurveOps &msm_g1_ops();   // msm_g1.hip
+const MsmCurveOps &msm_g2_ops();   // msm_g2.hip
