@@ -21,6 +21,7 @@ EXPORTS = [
     "mi_g2_compress", "mi_proof_write", "mi_g1_sum", "mi_g2_sum", "mi_gen_scalars_dev", "mi_gen_g1_dev",
     "mi_gen_g2_dev", "mi_field_op_dev", "mi_g1_add_dev", "mi_g2_add_dev", "mi_bench_modmul_dev", "mi_bench_valu_dev",
     "mi_dev_alloc", "mi_dev_free", "mi_dev_upload", "mi_dev_download", "mi_dev_sync",
+    "mi_pedersen_pk_load", "mi_pedersen_pk_free", "mi_pedersen_commit", "mi_pedersen_prove_knowledge", "mi_pedersen_fold",
 ]
 
 
@@ -248,6 +249,21 @@ class Context:
                                                C.c_size_t(a.shape[0]), _p(r), _p(s), _p(out), C.byref(st)))
         return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
 
+    # ---- BSB22 Pedersen key
+    def pedersen_pk_load(self, basis, basis_exp_sigma):
+        basis, bes = _u64(basis), _u64(basis_exp_sigma); h = C.c_void_p()
+        self._ck(self.lib.mi_pedersen_pk_load(self.h, _p(basis), _p(bes), C.c_size_t(basis.shape[0]), C.byref(h)))
+        return h
+
+    def pedersen_pk_free(self, pk):
+        self._ck(self.lib.mi_pedersen_pk_free(self.h, pk))
+
+    def pedersen_commit(self, pk, values, knowledge=False):
+        values = _u64(values); out = np.zeros(8, np.uint64)
+        f = self.lib.mi_pedersen_prove_knowledge if knowledge else self.lib.mi_pedersen_commit
+        self._ck(f(self.h, pk, _p(values), C.c_size_t(values.shape[0]), _p(out)))
+        return out
+
     def stats(self):
         st = Stats(); self._ck(self.lib.mi_get_stats(self.h, C.byref(st))); return st.as_dict()
 
@@ -266,6 +282,12 @@ def g1_compress(p):
 
 def g2_compress(p):
     buf = np.zeros(64, np.uint8); load().mi_g2_compress(_p(_u64(p)), _p(buf)); return bytes(buf)
+
+
+def pedersen_fold(points, challenge):
+    points = _u64(points); out = np.zeros(8, np.uint64)
+    assert load().mi_pedersen_fold(_p(points), C.c_size_t(points.shape[0]), _p(_u64(challenge)), _p(out)) == 0
+    return out
 
 
 def g1_sum(parts):

@@ -87,7 +87,72 @@ static int32_t pk_load_common(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, boo
 template <class F>
 static XYZZ<F> host_scalar_mul(const Affine<F> &p, const Fr &k_canon) { return xyzz_mul_256(XYZZ<F>::from_affine(p), k_canon.l); }
 
+// ---------------------------------------------------------------- BSB22 Pedersen key
+struct mi_pedersen_pk {
+    void *basis = nullptr, *basis_exp_sigma = nullptr;
+    size_t n = 0;
+};
+static int32_t pedersen_msm(mi_ctx *ctx, const void *bases_dev, size_t key_n, const mi_fr *values, size_t n, mi_g1_affine *out) {
+    if (!ctx || !out || (!values && n)) return MI_EINVAL;
+    if (n > key_n) MI_FAIL(ctx, MI_EINVAL, "pedersen: more values than basis points");   // gnark: "must have as many values as basis elements"
+    MI_TRY(mi_reserve(ctx, ctx->ws[19], n * sizeof(mi_fr) + 64));
+    if (n) MI_CHECK_HIP(ctx, hipMemcpyAsync(ctx->ws[19].p, values, n * sizeof(mi_fr), hipMemcpyHostToDevice, ctx->stream));
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[14], ctx->stream));
+    MI_TRY(mi_msm_enqueue(ctx, 5, -1, 1, bases_dev, ctx->ws[19].p, n, 0, ctx->ev[14], false));
+    G1X r;
+    MI_TRY(mi_msm_finish(ctx, 5, 1, &r));
+    G1Aff a = xyzz_to_affine(r);
+    std::memcpy(out, &a, sizeof(a));
+    return MI_OK;
+}
+
 extern "C" {
+int32_t mi_pedersen_pk_load(mi_ctx *ctx, const mi_g1_affine *basis, const mi_g1_affine *basis_exp_sigma, size_t n, mi_pedersen_pk **out) {
+    if (!ctx || !out || ((!basis || !basis_exp_sigma) && n)) return MI_EINVAL;
+    *out = nullptr;
+    mi_pedersen_pk *pk = new (std::nothrow) mi_pedersen_pk();
+    if (!pk) return MI_ENOMEM;
+    pk->n = n;
+    int32_t rc = upload(ctx, &pk->basis, basis, n * 64);
+    if (rc == MI_OK) rc = upload(ctx, &pk->basis_exp_sigma, basis_exp_sigma, n * 64);
+    if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pedersen key upload failed"; rc = MI_EHIP; }
+    if (rc != MI_OK) { mi_pedersen_pk_free(ctx, pk); return rc; }
+    *out = pk;
+    return MI_OK;
+}
+int32_t mi_pedersen_pk_free(mi_ctx *ctx, mi_pedersen_pk *pk) {
+    if (!ctx || !pk) return MI_EINVAL;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (pk->basis) (void)hipFree(pk->basis);
+    if (pk->basis_exp_sigma) (void)hipFree(pk->basis_exp_sigma);
+    delete pk;
+    return MI_OK;
+}
+int32_t mi_pedersen_commit(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n, mi_g1_affine *commitment) {
+    if (!pk) return MI_EINVAL;
+    return pedersen_msm(ctx, pk->basis, pk->n, values, n, commitment);
+}
+int32_t mi_pedersen_prove_knowledge(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n, mi_g1_affine *pok) {
+    if (!pk) return MI_EINVAL;
+    return pedersen_msm(ctx, pk->basis_exp_sigma, pk->n, values, n, pok);
+}
+// sum_i challenge^i * points[i] on the host (a handful of points: one per commitment)
+int32_t mi_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *challenge, mi_g1_affine *out) {
+    if ((!points && n) || !challenge || !out) return MI_EINVAL;
+    Fr ch, pw = Fr::one();
+    std::memcpy(&ch, challenge, 32);
+    G1X acc = G1X::inf();
+    for (size_t i = 0; i < n; i++) {
+        G1Aff p;
+        std::memcpy(&p, &points[i], sizeof(p));
+        G1X t = host_scalar_mul<Fp>(p, fe_from_mont(pw));
+        xyzz_add(acc, t);
+        pw = pw * ch;
+    }
+    G1Aff a = xyzz_to_affine(acc);
+    std::memcpy(out, &a, sizeof(a));
+    return MI_OK;
+}
 int32_t mi_pk_load(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out) {
     if (d && (!d->g1_a && d->n_g1_a)) return MI_EINVAL;
     return pk_load_common(ctx, d, out, false);

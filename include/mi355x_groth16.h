@@ -163,6 +163,21 @@ void mi_g2_compress(const mi_g2_affine *p, uint8_t out[64]);
 size_t mi_proof_write(const mi_proof_out *proof, const mi_g1_affine *commitments,
                       uint32_t n_commitments, const mi_g1_affine *commitment_pok, uint8_t *out);
 
+/* ---- BSB22 Pedersen commitment key: replaces gnark-crypto ecc/bn254/fr/pedersen ProvingKey.Commit /
+ * ProveKnowledge / Fold, which gnark's prover calls because the WHIR circuit uses lookups
+ * (/root/reference/utilities/utilities.go:189 logderivlookup.New; mtUtilities.go:452 uints.New).  Commit runs INSIDE the
+ * solve (hint override), so it is a synchronous low-latency call; the SHA-256 hash-to-field of the commitment stays in Go.
+ *   Commit(values)          = sum_i values[i] * Basis[i]
+ *   ProveKnowledge(values)  = sum_i values[i] * BasisExpSigma[i]
+ *   Fold(points, challenge) = sum_i challenge^i * points[i]          (pedersen.Fold / FoldCommitments)            ---- */
+typedef struct mi_pedersen_pk mi_pedersen_pk;
+int32_t mi_pedersen_pk_load(mi_ctx *ctx, const mi_g1_affine *basis, const mi_g1_affine *basis_exp_sigma, size_t n,
+                            mi_pedersen_pk **out);                       /* uploads once, device-resident */
+int32_t mi_pedersen_pk_free(mi_ctx *ctx, mi_pedersen_pk *pk);
+int32_t mi_pedersen_commit(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n, mi_g1_affine *commitment);
+int32_t mi_pedersen_prove_knowledge(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n, mi_g1_affine *pok);
+int32_t mi_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *challenge, mi_g1_affine *out); /* host */
+
 /* ---- partial-sum combine for the point-sharded MSM (SURVEY section 8e option i): adds n
  * Jacobian partial results (e.g. all-gathered from the ranks), host side ---- */
 int32_t mi_g1_sum(const mi_g1_jac *parts, size_t n, mi_g1_jac *out);

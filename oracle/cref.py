@@ -127,6 +127,18 @@ def msm_g2(pts, sc, flags=0, naive=False):
     return out
 
 
+def pedersen_msm(bases, values):
+    out = np.zeros(8, np.uint64); bases, values = u64(bases), u64(values)
+    assert lib().ref_pedersen_msm(_p(bases), _p(values), C.c_size_t(values.shape[0]), _p(out)) == 0
+    return out
+
+
+def pedersen_fold(points, challenge):
+    out = np.zeros(8, np.uint64); points = u64(points)
+    assert lib().ref_pedersen_fold(_p(points), C.c_size_t(points.shape[0]), _p(u64(challenge)), _p(out)) == 0
+    return out
+
+
 def g1_sum(parts):
     out = np.zeros(12, np.uint64)
     parts = u64(parts)

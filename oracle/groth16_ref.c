@@ -385,6 +385,27 @@ int32_t ref_g1_sum(const mi_g1_jac *parts, size_t n, mi_g1_jac *out) {
     norm_g1(out, &acc); return MI_OK;
 }
 
+/* ---------------------------------------------------------------- BSB22 Pedersen key (gnark-crypto ecc/bn254/fr/pedersen by behaviour; SURVEY 8f N1;
+ * triggered by /root/reference/utilities/utilities.go:189).  Commit / ProveKnowledge are MultiExps over Basis / BasisExpSigma;
+ * Fold = sum_i challenge^i * points[i]. */
+int32_t ref_pedersen_msm(const mi_g1_affine *bases, const mi_fr *values, size_t n, mi_g1_affine *out) {
+    ref_init();
+    mi_g1_jac j; ref_msm_g1(bases, values, n, 0, &j);
+    g1_jac_to_aff((g1_aff *)out, (const g1_jac *)&j);
+    return MI_OK;
+}
+int32_t ref_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *challenge, mi_g1_affine *out) {
+    ref_init();
+    fe pw = FR.one; g1_jac acc; g1_jac_set_inf(&acc);
+    for (size_t i = 0; i < n; i++) {
+        fe k; fe_from_mont(&k, &pw, &FR);
+        g1_jac p, t; g1_jac_from_aff(&p, (const g1_aff *)&points[i]); g1_jac_scalar_mul(&t, &p, k.l); g1_jac_add(&acc, &acc, &t);
+        fe_mul(&pw, &pw, (const fe *)challenge, &FR);
+    }
+    g1_jac_to_aff((g1_aff *)out, &acc);
+    return MI_OK;
+}
+
 /* ---------------------------------------------------------------- groth16.Prove after the solve (gnark prove.go by behaviour) */
 int32_t ref_groth16_prove(const mi_pk_desc *pk, const mi_fr *W, size_t n_wires,
                           const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,

@@ -595,6 +595,21 @@ def trapdoor_check(cs: ToyR1CS, td: ToyTrapdoor, exps, proof, r: int, s: int) ->
     return (ar * bs - td.alpha * td.beta - pub - krs * td.delta) % R_MOD == 0
 
 
+# --------------------------------------------------------------------------- BSB22 Pedersen (gnark-crypto fr/pedersen by behaviour)
+def pedersen_commit(basis, values):
+    """ProvingKey.Commit: sum_i values[i] * Basis[i]  (ProveKnowledge: the same over BasisExpSigma)"""
+    return msm_naive(F1, basis[: len(values)], values)
+
+
+def pedersen_fold(points, challenge):
+    """pedersen.Fold: sum_i challenge^i * points[i]"""
+    acc, pw = None, 1
+    for pt in points:
+        acc = g1_add(acc, g1_mul(pt, pw))
+        pw = (pw * challenge) % R_MOD
+    return acc
+
+
 # --------------------------------------------------------------------------- gnark-crypto point encoding (SURVEY 8a a12)
 M_COMPRESSED_SMALLEST = 0b10 << 6
 M_COMPRESSED_LARGEST = 0b11 << 6

@@ -62,3 +62,10 @@ def test_host_partial_sum_combine_matches_oracle():
     p2 = cref.gen_g2(4, 8); s2 = cref.gen_scalars(4, 9, 0)
     parts2 = np.stack([cref.msm_g2(p2[:2], s2[:2]), cref.msm_g2(p2[2:], s2[2:])])
     assert np.array_equal(B.g2_sum(parts2), cref.msm_g2(p2, s2))
+
+
+def test_host_pedersen_fold_matches_oracle():
+    B = load_binding()
+    pts = cref.gen_g1(4, 81); ch = cref.gen_scalars(1, 82, 0)[0]
+    assert np.array_equal(B.pedersen_fold(pts, ch), cref.pedersen_fold(pts, ch))
+    assert np.array_equal(B.pedersen_fold(pts[:1], ch), pts[0])          # challenge^0 = 1

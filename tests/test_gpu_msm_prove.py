@@ -198,3 +198,31 @@ def test_msm_g2_repeated_and_opposite_points(ctx):
     assert _jac_eq(ctx.msm_g2(pts, sc), cref.msm_g2(pts, sc))
     allsame = np.repeat(pts[:1], 64, axis=0); ones = fr_arr([1] * 64)
     assert g2_from_jac(ctx.msm_g2(allsame, ones)) == P.g2_mul(g2_pts(pts[:1])[0], 64)
+
+
+@pytest.mark.parametrize("n", [1, 300, 5000, 70000])
+def test_pedersen_commit_and_pok_vs_oracle(ctx, n):
+    """BSB22 Pedersen Commit / ProveKnowledge through the device-resident key"""
+    B = load_binding()
+    basis = cref.gen_g1(n + 5, 500 + n); bes = cref.gen_g1(n + 5, 600 + n); vals = cref.gen_scalars(n, 700 + n, 1)
+    pk = ctx.pedersen_pk_load(basis, bes)
+    assert np.array_equal(ctx.pedersen_commit(pk, vals), cref.pedersen_msm(basis, vals))
+    assert np.array_equal(ctx.pedersen_commit(pk, vals, knowledge=True), cref.pedersen_msm(bes, vals))
+    with pytest.raises(B.MiError):
+        ctx.pedersen_commit(pk, cref.gen_scalars(n + 6, 1, 0))      # more values than basis points
+    ctx.pedersen_pk_free(pk)
+
+
+def test_proof_with_commitment_is_196_bytes_and_matches_oracle(ctx):
+    """the WHIR circuit's proof carries one BSB22 commitment + its PoK: Ar | Bs | Krs | 1 | commitment | pok = 196 bytes"""
+    B = load_binding()
+    z, pk = _load_toy()
+    pkh = ctx.pk_load(pk)
+    proof, _ = ctx.prove(pkh, z["W"], z["a"], z["b"], z["c"], z["r"], z["s"])
+    basis = cref.gen_g1(40, 1); bes = cref.gen_g1(40, 2); vals = cref.gen_scalars(40, 3, 1)
+    ppk = ctx.pedersen_pk_load(basis, bes)
+    com = ctx.pedersen_commit(ppk, vals); pok = B.pedersen_fold(ctx.pedersen_commit(ppk, vals, knowledge=True).reshape(1, 8), cref.gen_scalars(1, 4, 0)[0])
+    got = B.proof_write(proof["raw"], commitments=com.reshape(1, 8).copy(), pok=pok.copy())
+    want_pok = cref.pedersen_fold(cref.pedersen_msm(bes, vals).reshape(1, 8), cref.gen_scalars(1, 4, 0)[0])
+    assert len(got) == 196 and got == cref.proof_write(proof["raw"], commitments=cref.pedersen_msm(basis, vals).reshape(1, 8).copy(), pok=want_pok.copy())
+    ctx.pedersen_pk_free(ppk); ctx.pk_free(pkh)

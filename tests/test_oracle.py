@@ -230,3 +230,11 @@ def test_golden_npz_fixtures_reproduce_with_c_oracle():
     assert np.array_equal(h, z["h"])
     assert np.array_equal(got["ar"], z["ar"]) and np.array_equal(got["bs"], z["bs"]) and np.array_equal(got["krs"], z["krs"])
     assert cref.proof_write(got["raw"]) == bytes(z["proof_bytes"])
+
+
+def test_pedersen_commit_and_fold_match_python():
+    """BSB22 commitment = MultiExp over the Pedersen basis; Fold = sum challenge^i * P_i"""
+    basis = cref.gen_g1(50, 71); vals = cref.gen_scalars(37, 72, 1)
+    assert g1_pts(cref.pedersen_msm(basis, vals)) == [P.pedersen_commit(g1_pts(basis), fr_vals(vals))]
+    pts = cref.gen_g1(3, 73); ch = cref.gen_scalars(1, 74, 0)[0]
+    assert g1_pts(cref.pedersen_fold(pts, ch)) == [P.pedersen_fold(g1_pts(pts), fr_vals(ch)[0])]
