@@ -21,6 +21,7 @@ EXPORTS = [
     "mi_g2_compress", "mi_proof_write", "mi_g1_sum", "mi_g2_sum", "mi_gen_scalars_dev", "mi_gen_g1_dev",
     "mi_gen_g2_dev", "mi_field_op_dev", "mi_g1_add_dev", "mi_g2_add_dev", "mi_bench_modmul_dev", "mi_bench_valu_dev",
     "mi_dev_alloc", "mi_dev_free", "mi_dev_upload", "mi_dev_download", "mi_dev_sync",
+    "mi_batch_scalar_mul_g1", "mi_batch_scalar_mul_g1_dev", "mi_batch_scalar_mul_g2", "mi_batch_scalar_mul_g2_dev",
     "mi_pedersen_pk_load", "mi_pedersen_pk_free", "mi_pedersen_commit", "mi_pedersen_prove_knowledge", "mi_pedersen_fold",
 ]
 
@@ -248,6 +249,17 @@ class Context:
             self._ck(self.lib.mi_groth16_prove(self.h, pkh, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c),
                                                C.c_size_t(a.shape[0]), _p(r), _p(s), _p(out), C.byref(st)))
         return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
+
+    # ---- fixed-base batch scalar multiplication
+    def batch_scalar_mul(self, base, scalars, g2=False):
+        base, scalars = _u64(base), _u64(scalars); out = np.zeros((scalars.shape[0], 16 if g2 else 8), np.uint64)
+        f = self.lib.mi_batch_scalar_mul_g2 if g2 else self.lib.mi_batch_scalar_mul_g1
+        self._ck(f(self.h, _p(base), _p(scalars), C.c_size_t(scalars.shape[0]), _p(out)))
+        return out
+
+    def batch_scalar_mul_dev(self, base, scalars_ptr, n, out_ptr, g2=False):
+        f = self.lib.mi_batch_scalar_mul_g2_dev if g2 else self.lib.mi_batch_scalar_mul_g1_dev
+        self._ck(f(self.h, _p(_u64(base)), _p(scalars_ptr), C.c_size_t(n), _p(out_ptr)))
 
     # ---- BSB22 Pedersen key
     def pedersen_pk_load(self, basis, basis_exp_sigma):

@@ -178,6 +178,15 @@ int32_t mi_pedersen_commit(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values,
 int32_t mi_pedersen_prove_knowledge(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n, mi_g1_affine *pok);
 int32_t mi_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *challenge, mi_g1_affine *out); /* host */
 
+/* ---- fixed-base batch scalar multiplication: replaces gnark-crypto ecc/bn254
+ * BatchScalarMultiplicationG1 / G2, the bulk of groth16.Setup (/root/reference/mt.go:448: every pk / vk point is
+ * scalar * generator).  out[i] = scalars[i] * base, affine.  Windowed table of the base built on the device, one
+ * thread per scalar. ---- */
+int32_t mi_batch_scalar_mul_g1(mi_ctx *ctx, const mi_g1_affine *base, const mi_fr *scalars, size_t n, mi_g1_affine *out);
+int32_t mi_batch_scalar_mul_g1_dev(mi_ctx *ctx, const mi_g1_affine *base, const mi_fr *scalars_dev, size_t n, mi_g1_affine *out_dev);
+int32_t mi_batch_scalar_mul_g2(mi_ctx *ctx, const mi_g2_affine *base, const mi_fr *scalars, size_t n, mi_g2_affine *out);
+int32_t mi_batch_scalar_mul_g2_dev(mi_ctx *ctx, const mi_g2_affine *base, const mi_fr *scalars_dev, size_t n, mi_g2_affine *out_dev);
+
 /* ---- partial-sum combine for the point-sharded MSM (SURVEY section 8e option i): adds n
  * Jacobian partial results (e.g. all-gathered from the ranks), host side ---- */
 int32_t mi_g1_sum(const mi_g1_jac *parts, size_t n, mi_g1_jac *out);

@@ -139,6 +139,13 @@ def pedersen_fold(points, challenge):
     return out
 
 
+def batch_scalar_mul(base, scalars, g2=False):
+    scalars = u64(scalars); out = np.zeros((scalars.shape[0], 16 if g2 else 8), np.uint64)
+    f = lib().ref_batch_scalar_mul_g2 if g2 else lib().ref_batch_scalar_mul_g1
+    assert f(_p(u64(base)), _p(scalars), C.c_size_t(scalars.shape[0]), _p(out)) == 0
+    return out
+
+
 def g1_sum(parts):
     out = np.zeros(12, np.uint64)
     parts = u64(parts)

@@ -406,6 +406,28 @@ int32_t ref_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *cha
     return MI_OK;
 }
 
+/* ---------------------------------------------------------------- BatchScalarMultiplicationG1/G2 (gnark-crypto ecc/bn254 by behaviour; groth16.Setup, mt.go:448) */
+int32_t ref_batch_scalar_mul_g1(const mi_g1_affine *base, const mi_fr *scalars, size_t n, mi_g1_affine *out) {
+    ref_init();
+    g1_jac b; g1_jac_from_aff(&b, (const g1_aff *)base);
+#pragma omp parallel for
+    for (size_t i = 0; i < n; i++) {
+        fe k; fe_from_mont(&k, (const fe *)&scalars[i], &FR);
+        g1_jac r; g1_jac_scalar_mul(&r, &b, k.l); g1_jac_to_aff((g1_aff *)&out[i], &r);
+    }
+    return MI_OK;
+}
+int32_t ref_batch_scalar_mul_g2(const mi_g2_affine *base, const mi_fr *scalars, size_t n, mi_g2_affine *out) {
+    ref_init();
+    g2_jac b; g2_jac_from_aff(&b, (const g2_aff *)base);
+#pragma omp parallel for
+    for (size_t i = 0; i < n; i++) {
+        fe k; fe_from_mont(&k, (const fe *)&scalars[i], &FR);
+        g2_jac r; g2_jac_scalar_mul(&r, &b, k.l); g2_jac_to_aff((g2_aff *)&out[i], &r);
+    }
+    return MI_OK;
+}
+
 /* ---------------------------------------------------------------- groth16.Prove after the solve (gnark prove.go by behaviour) */
 int32_t ref_groth16_prove(const mi_pk_desc *pk, const mi_fr *W, size_t n_wires,
                           const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,

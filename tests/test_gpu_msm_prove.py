@@ -226,3 +226,17 @@ def test_proof_with_commitment_is_196_bytes_and_matches_oracle(ctx):
     want_pok = cref.pedersen_fold(cref.pedersen_msm(bes, vals).reshape(1, 8), cref.gen_scalars(1, 4, 0)[0])
     assert len(got) == 196 and got == cref.proof_write(proof["raw"], commitments=cref.pedersen_msm(basis, vals).reshape(1, 8).copy(), pok=want_pok.copy())
     ctx.pedersen_pk_free(ppk); ctx.pk_free(pkh)
+
+
+def test_batch_scalar_mul_vs_oracle(ctx):
+    """fixed-base batch scalar multiplication (groth16.Setup's BatchScalarMultiplicationG1/G2)"""
+    n = 20000
+    sc = cref.gen_scalars(n, 95, 0); sc[0] = 0; sc[1] = fr_arr([1])[0]; sc[2] = fr_arr([P.R_MOD - 1])[0]; sc[3:40] = cref.gen_scalars(37, 96, 1)
+    base = cref.gen_g1(1, 97)[0]
+    assert np.array_equal(ctx.batch_scalar_mul(base, sc), cref.batch_scalar_mul(base, sc))
+    gen = g1_arr([P.G1_GEN])[0]
+    assert np.array_equal(ctx.batch_scalar_mul(gen, sc[:500]), cref.batch_scalar_mul(gen, sc[:500]))
+    b2 = cref.gen_g2(1, 98)[0]
+    assert np.array_equal(ctx.batch_scalar_mul(b2, sc[:3000], g2=True), cref.batch_scalar_mul(b2, sc[:3000], g2=True))
+    # a toy Setup row: the points of pk.G1.Z are zdt * tau^i * G1 -> consecutive quotients are tau
+    assert ctx.batch_scalar_mul(gen, sc[:0]).shape == (0, 8)

@@ -238,3 +238,12 @@ def test_pedersen_commit_and_fold_match_python():
     assert g1_pts(cref.pedersen_msm(basis, vals)) == [P.pedersen_commit(g1_pts(basis), fr_vals(vals))]
     pts = cref.gen_g1(3, 73); ch = cref.gen_scalars(1, 74, 0)[0]
     assert g1_pts(cref.pedersen_fold(pts, ch)) == [P.pedersen_fold(g1_pts(pts), fr_vals(ch)[0])]
+
+
+def test_batch_scalar_mul_matches_python():
+    """BatchScalarMultiplicationG1/G2 (the bulk of groth16.Setup)"""
+    sc = cref.gen_scalars(12, 91, 1); sc[0] = 0; sc[1] = fr_arr([1])[0]; sc[2] = fr_arr([P.R_MOD - 1])[0]
+    out = cref.batch_scalar_mul(g1_arr([P.G1_GEN])[0], sc)
+    assert g1_pts(out) == [P.g1_mul(P.G1_GEN, v) for v in fr_vals(sc)]
+    out2 = cref.batch_scalar_mul(g2_arr([P.G2_GEN])[0], sc[:5], g2=True)
+    assert g2_pts(out2) == [P.g2_mul(P.G2_GEN, v) for v in fr_vals(sc[:5])]
