@@ -44,6 +44,7 @@ type ProvingKey struct {
 	once sync.Once
 	ctx  *C.mi_ctx
 	dev  *C.mi_pk
+	ped  []*C.mi_pedersen_pk
 	err  error
 }
 
@@ -115,13 +116,15 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 			vals[j].SetBigInt(v)
 		}
 		privateCommittedValues[i] = vals
-		var jac C.mi_g1_jac
-		basis := pk.CommitmentKeys[i].Basis
-		if rc := C.mi_msm_g1(pk.ctx, (*C.mi_g1_affine)(unsafe.Pointer(&basis[0])), (*C.mi_fr)(unsafe.Pointer(&vals[0])),
-			C.size_t(len(vals)), 0, &jac); rc != C.MI_OK {
+		// device-resident Pedersen key (mi_pedersen_pk_load once per key, see pedersenKey below)
+		ppk, err := pk.pedersenKey(i)
+		if err != nil {
+			return err
+		}
+		if rc := C.mi_pedersen_commit(pk.ctx, ppk, (*C.mi_fr)(unsafe.Pointer(&vals[0])), C.size_t(len(vals)),
+			(*C.mi_g1_affine)(unsafe.Pointer(&proof.Commitments[i]))); rc != C.MI_OK {
 			return status(pk.ctx, rc)
 		}
-		proof.Commitments[i].FromJacobian((*bn254.G1Jac)(unsafe.Pointer(&jac)))
 		// challenge = HashToField(commitment || public committed), DST "bsb22-commitment" (stays in Go)
 		hashed, err := fr.Hash(proof.Commitments[i].Marshal(), []byte(constraint.CommitmentDst), 1)
 		if err != nil {
@@ -167,6 +170,22 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 	proof.Bs = *(*bn254.G2Affine)(unsafe.Pointer(&out.bs))
 	proof.Krs = *(*bn254.G1Affine)(unsafe.Pointer(&out.krs))
 	return proof, nil
+}
+
+// pedersenKey uploads CommitmentKeys[i].Basis / BasisExpSigma once (mi_pedersen_pk_load).
+func (pk *ProvingKey) pedersenKey(i int) (*C.mi_pedersen_pk, error) {
+	if pk.ped == nil {
+		pk.ped = make([]*C.mi_pedersen_pk, len(pk.CommitmentKeys))
+	}
+	if pk.ped[i] == nil {
+		k := &pk.CommitmentKeys[i]
+		rc := C.mi_pedersen_pk_load(pk.ctx, (*C.mi_g1_affine)(unsafe.Pointer(&k.Basis[0])),
+			(*C.mi_g1_affine)(unsafe.Pointer(&k.BasisExpSigma[0])), C.size_t(len(k.Basis)), &pk.ped[i])
+		if err := status(pk.ctx, rc); err != nil {
+			return nil, err
+		}
+	}
+	return pk.ped[i], nil
 }
 
 func log2(n uint64) int { k := 0; for (uint64(1) << k) < n { k++ }; return k }
