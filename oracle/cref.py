@@ -214,3 +214,13 @@ def limbs_to_int(row) -> int:
 
 def int_to_limbs(x: int):
     return [(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def g1_scalar_mul(p, k_canonical_int):
+    out = np.zeros(8, np.uint64); k = np.array(int_to_limbs(k_canonical_int), dtype=np.uint64)
+    lib().ref_g1_scalar_mul(_p(out), _p(u64(p)), _p(k)); return out
+
+
+def g2_scalar_mul(p, k_canonical_int):
+    out = np.zeros(16, np.uint64); k = np.array(int_to_limbs(k_canonical_int), dtype=np.uint64)
+    lib().ref_g2_scalar_mul(_p(out), _p(u64(p)), _p(k)); return out

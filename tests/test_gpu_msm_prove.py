@@ -240,3 +240,44 @@ def test_batch_scalar_mul_vs_oracle(ctx):
     assert np.array_equal(ctx.batch_scalar_mul(b2, sc[:3000], g2=True), cref.batch_scalar_mul(b2, sc[:3000], g2=True))
     # a toy Setup row: the points of pk.G1.Z are zdt * tau^i * G1 -> consecutive quotients are tau
     assert ctx.batch_scalar_mul(gen, sc[:0]).shape == (0, 8)
+
+
+def test_full_size_prove_equals_composition_of_primitives(ctx):
+    """BASELINE configs[1] size (N = 2^23, WHIR scalar mix): the fused multi-stream prove must equal the proof assembled
+    from the separately tested primitives (computeH, four G1 MSMs, one G2 MSM run one by one on the same device arrays)
+    plus O(1) point operations done by the oracle."""
+    B = load_binding()
+    log_n = 23
+    N = 1 << log_n
+    nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
+    rng = np.random.default_rng(7)
+    inf_a = (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8); inf_b = (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
+    na, nb, nk = int((inf_a == 0).sum()), int((inf_b == 0).sum()), nb_wires - nb_public
+    g1a, g1b, g1k, g1z, g2b = ctx.gen_g1(na, 1), ctx.gen_g1(nb, 2), ctx.gen_g1(nk, 3), ctx.gen_g1(N, 4), ctx.gen_g2(nb, 5)
+    small = cref.gen_g1(3, 6); small2 = cref.gen_g2(2, 7)
+    pk = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk),
+          "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb), "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0],
+          "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b}
+    pkh = ctx.pk_load(pk, device_points=True)
+    W = ctx.gen_scalars(nb_wires, 8, 1); a = ctx.gen_scalars(n_constraints, 9, 1); b = ctx.gen_scalars(n_constraints, 10, 0)
+    c = ctx.alloc(32 * n_constraints); ctx.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)
+    r, s = cref.gen_scalars(2, 11, 0)
+    proof, _ = ctx.prove(pkh, W.ptr, a.ptr, b.ptr, c.ptr, r, s, device=True, n_wires=nb_wires, n_constraints=n_constraints)
+    # the same proof from the primitives, one at a time
+    h = ctx.alloc(32 * N); ctx.compute_h_dev(log_n, a.ptr, b.ptr, c.ptr, n_constraints, h.ptr)
+    Wh = W.download((nb_wires, 4))
+    wa, wb, wk = ctx.to_dev(Wh[inf_a == 0]), ctx.to_dev(Wh[inf_b == 0]), ctx.to_dev(Wh[nb_public:])
+    m_a, m_b1, m_k = ctx.msm_g1_dev(g1a.ptr, wa.ptr, na), ctx.msm_g1_dev(g1b.ptr, wb.ptr, nb), ctx.msm_g1_dev(g1k.ptr, wk.ptr, nk)
+    m_z, m_b2 = ctx.msm_g1_dev(g1z.ptr, h.ptr, N - 1), ctx.msm_g2_dev(g2b.ptr, wb.ptr, nb)
+    rc, sc = fr_vals(r)[0], fr_vals(s)[0]
+    aff = lambda j: j[:8]
+    add = lambda x, y: cref.g1_add(x.reshape(1, 8), y.reshape(1, 8))[0]
+    ar = add(add(aff(m_a), small[0]), cref.g1_scalar_mul(small[2], rc))
+    bs1 = add(add(aff(m_b1), small[1]), cref.g1_scalar_mul(small[2], sc))
+    krs = add(add(aff(m_k), aff(m_z)), cref.g1_scalar_mul(small[2], (-rc * sc) % P.R_MOD))
+    krs = add(add(krs, cref.g1_scalar_mul(ar, sc)), cref.g1_scalar_mul(bs1, rc))
+    bs = cref.g2_add(cref.g2_add(m_b2[:16].reshape(1, 16), small2[0].reshape(1, 16)), cref.g2_scalar_mul(small2[1], sc).reshape(1, 16))[0]
+    assert np.array_equal(proof["ar"], ar) and np.array_equal(proof["krs"], krs) and np.array_equal(proof["bs"], bs)
+    ctx.pk_free(pkh)
+    for d in (g1a, g1b, g1k, g1z, g2b, W, a, b, c, h, wa, wb, wk):
+        d.free()
