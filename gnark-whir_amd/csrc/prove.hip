@@ -19,10 +19,17 @@ struct mi_pk {
     u64 n_a = 0, n_b = 0, n_k = 0, n_z = 0;
     bool owns_points = false;
     u32 *idx_a = nullptr, *idx_b = nullptr, *idx_k = nullptr;  // wire index of every A / B / K point
+    // pk.G1.A and pk.G1.K re-expanded to one slot per wire (zero = infinity where the wire has no point): both are multiplied
+    // by W itself, so ONE sort of W serves both MSMs and neither needs a gather (prove.hip, step 5)
+    G1Aff *a_full = nullptr, *k_full = nullptr;
     G1Aff alpha1, beta1, delta1;
     G2Aff beta2, delta2;
 };
 
+__global__ void k_expand_points(G1Aff *full, const G1Aff *compact, const u32 *idx, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) full[idx[i]] = compact[i];
+}
 __global__ void k_gather_fr(Fr *out, const Fr *W, const u32 *idx, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = W[idx[i]];
@@ -77,8 +84,21 @@ static int32_t pk_load_common(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, boo
     if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_a, ia.data(), ia.size() * 4);
     if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_b, ib.data(), ib.size() * 4);
     if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_k, ik.data(), ik.size() * 4);
+    // expanded per-wire copies of A and K
+    auto expand = [&](G1Aff **full, const void *compact, const u32 *idx, size_t n) -> int32_t {
+        const size_t bytes = (size_t)d->nb_wires * sizeof(G1Aff);
+        MI_CHECK_HIP(ctx, hipMalloc((void **)full, bytes ? bytes : 64));
+        MI_CHECK_HIP(ctx, hipMemsetAsync(*full, 0, bytes, ctx->stream));
+        if (n) hipLaunchKernelGGL(k_expand_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, *full, (const G1Aff *)compact, idx, n);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+        return MI_OK;
+    };
+    if (rc == MI_OK) rc = expand(&pk->a_full, pk->g1_a, pk->idx_a, pk->n_a);
+    if (rc == MI_OK) rc = expand(&pk->k_full, pk->g1_k, pk->idx_k, pk->n_k);
     if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pk upload sync failed"; rc = MI_EHIP; }
     if (rc != MI_OK) { mi_pk_free(ctx, pk); return rc; }
+    // the compact A and K copies are not needed any more when the library owns them
+    if (pk->owns_points) { (void)hipFree(pk->g1_a); (void)hipFree(pk->g1_k); pk->g1_a = pk->g1_k = nullptr; }
     *out = pk;
     return MI_OK;
 }
@@ -162,7 +182,7 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
     if (!ctx || !pk) return MI_EINVAL;
     (void)hipStreamSynchronize(ctx->stream);
     if (pk->owns_points) for (void *p : {pk->g1_a, pk->g1_b, pk->g1_k, pk->g1_z, pk->g2_b}) if (p) (void)hipFree(p);
-    for (void *p : {(void *)pk->idx_a, (void *)pk->idx_b, (void *)pk->idx_k}) if (p) (void)hipFree(p);
+    for (void *p : {(void *)pk->idx_a, (void *)pk->idx_b, (void *)pk->idx_k, (void *)pk->a_full, (void *)pk->k_full}) if (p) (void)hipFree(p);
     delete pk;
     return MI_OK;
 }
@@ -197,10 +217,10 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wi
     MI_TRY(gather(1, 17, pk->idx_b, pk->n_b));
     MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, 0, nullptr, true));
     MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, 0, nullptr, false));      // same scalars: shared sort
-    MI_TRY(gather(3, 18, pk->idx_k, pk->n_k));
-    MI_TRY(mi_msm_enqueue(ctx, 3, -1, 1, pk->g1_k, ctx->ws[18].p, pk->n_k, 0, nullptr, true));
-    MI_TRY(gather(0, 15, pk->idx_a, pk->n_a));
-    MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->g1_a, ctx->ws[15].p, pk->n_a, 0, nullptr, true));
+    // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
+    // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, 0, ev[2], true));
+    MI_TRY(mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, 0, nullptr, true));
     // step 6 while the GPU works: blinding multiples of delta on the host (O(1) points)
     Fr r, s;
     std::memcpy(&r, r_m, 32); std::memcpy(&s, s_m, 32);
@@ -248,9 +268,9 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wi
     };
     // per-phase spans overlap (five streams): they do not add up to total_ms
     MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.compute_h_ms, ev[2], ev[3]));
-    if (pk->n_a) MI_TRY(slot_ms(0, &st.msm_a_ms));
+    if (pk->nb_wires) MI_TRY(slot_ms(0, &st.msm_a_ms));
     if (pk->n_b) { MI_TRY(slot_ms(1, &st.msm_b1_ms)); MI_TRY(slot_ms(2, &st.msm_b2_ms)); }
-    if (pk->n_k) MI_TRY(slot_ms(3, &st.msm_k_ms));
+    if (pk->nb_wires) MI_TRY(slot_ms(3, &st.msm_k_ms));
     if (N > 1) MI_TRY(slot_ms(4, &st.msm_z_ms));
     st.assemble_ms = ms(t_gpu_done, t_end);     // host work left after the last MSM landed
     st.filter_ms = ms(t_asm0, t_gpu_done);      // host blinding work hidden under the GPU
