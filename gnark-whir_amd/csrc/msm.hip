@@ -347,7 +347,7 @@ static int32_t msm_host_entry(mi_ctx *ctx, int curve, const AffT *pts, const mi_
 
 extern "C" {
 int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G) {
-    if (!ctx || c == 1 || c > 16 || G > 1024) return MI_EINVAL;
+    if (!ctx || c == 1 || c > 16 || G > 1024 || L1 == 1 || L2 == 1) return MI_EINVAL;   // items of one entry would never shrink a level
     MsmKnobs *k = knobs_of(ctx);
     k->c = c; k->L1 = L1; k->L2 = L2; k->seg = seg; k->G = G;
     return MI_OK;
