@@ -16,9 +16,10 @@
 
 struct NttState {
     u32 log_n = 0xffffffffu;
-    Fr *small_f = nullptr, *small_i = nullptr;          // N independent
+    Fr *small_f = nullptr, *small_i = nullptr, *tw64k_f = nullptr, *tw64k_i = nullptr;   // N independent
     Fr *tw_lo_f = nullptr, *tw_hi_f = nullptr, *tw_lo_i = nullptr, *tw_hi_i = nullptr;
     Fr *g_lo = nullptr, *g_hi = nullptr, *gi_lo = nullptr, *gi_hi = nullptr, *ninv = nullptr;
+    Fr *g_hi_n = nullptr, *gi_hi_nd = nullptr;   // computeH-internal: g^(j 2^h) / N  and  g^-(j 2^h) / N * den
     u32 tw_h = 0;
     // plan knobs (mi_debug_set_ntt_plan)
     // defaults from the tools/tune.py sweep at N = 2^23: 2^9-element tiles (16 KiB of LDS, 8 workgroups of 256
@@ -37,7 +38,7 @@ void mi_ntt_state_init(mi_ctx *ctx) {
 }
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
-    Fr **all[] = {&st->small_f, &st->small_i, &st->tw_lo_f, &st->tw_hi_f, &st->tw_lo_i, &st->tw_hi_i,
+    Fr **all[] = {&st->small_f, &st->small_i, &st->tw64k_f, &st->tw64k_i, &st->g_hi_n, &st->gi_hi_nd, &st->tw_lo_f, &st->tw_hi_f, &st->tw_lo_i, &st->tw_hi_i,
                   &st->g_lo, &st->g_hi, &st->gi_lo, &st->gi_hi, &st->ninv};
     for (Fr **p : all) if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
@@ -68,11 +69,11 @@ __global__ void __launch_bounds__(1024) k_ntt_pass(Fr *dst, const Fr *src, NttPa
     ntt_tile_store(p, t, dst, tile, threadIdx.x, blockDim.x, lds);
 }
 
-// a[i] = (a[i]*b[i] - c[i]) * den      (computeH's pointwise step)
-__global__ void k_h_pointwise(Fr *a, const Fr *b, const Fr *c, Fr den, size_t n) {
+// a[i] = a[i]*b[i] - c[i]      (computeH's pointwise step; its den factor is folded into the last transform)
+__global__ void k_h_pointwise(Fr *a, const Fr *b, const Fr *c, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    a[i] = (a[i] * b[i] - c[i]) * den;
+    a[i] = a[i] * b[i] - c[i];
 }
 
 static Fr host_fr_from_u64x4(u64 a, u64 b, u64 c, u64 d) {
@@ -101,6 +102,9 @@ static int32_t ensure_tables(mi_ctx *ctx, u32 log_n) {
         Fr w2048 = domain_generator(11);
         MI_TRY(build_table(ctx, &st->small_f, 1024, w2048, Fr::one(), 0));
         MI_TRY(build_table(ctx, &st->small_i, 1024, fe_inv(w2048), Fr::one(), 0));
+        Fr w64k = domain_generator(16);
+        MI_TRY(build_table(ctx, &st->tw64k_f, 65536, w64k, Fr::one(), 0));
+        MI_TRY(build_table(ctx, &st->tw64k_i, 65536, fe_inv(w64k), Fr::one(), 0));
     }
     if (st->log_n == log_n) return MI_OK;
     Fr w = domain_generator(log_n), wi = fe_inv(w);
@@ -120,12 +124,21 @@ static int32_t ensure_tables(mi_ctx *ctx, u32 log_n) {
     MI_TRY(build_table(ctx, &st->gi_lo, nlo, gi, Fr::one(), 0));
     MI_TRY(build_table(ctx, &st->gi_hi, nhi, gi, ninv, h));
     MI_TRY(build_table(ctx, &st->ninv, 1, Fr::one(), ninv, 0));
+    // computeH folds the 1/N of FFTInverse(a|b|c) into the coset shift of the next transform and den = 1/(g^N - 1) into the
+    // last inverse transform's scaling (both are linear): 4 of its 121 products per element disappear
+    Fr gn = g;
+    for (u32 k = 0; k < log_n; k++) gn = fe_sqr(gn);
+    Fr den = fe_inv(gn - Fr::one());
+    MI_TRY(build_table(ctx, &st->g_hi_n, nhi, g, ninv, h));
+    MI_TRY(build_table(ctx, &st->gi_hi_nd, nhi, gi, ninv * den, h));
     st->log_n = log_n;
     return MI_OK;
 }
 
 // One transform of size 2^log_n: dst <- NTT(src[0..n_valid) zero padded).  dst == src allowed.
-static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log_n, u32 flags) {
+// variant (computeH only): 1 = inverse without the 1/N scaling; 2 = forward coset with 1/N folded into the shift tables;
+// 3 = inverse coset with den folded into its scaling.  0 = exactly fft.Domain's FFT / FFTInverse.
+static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log_n, u32 flags, u32 variant = 0) {
     NttState *st = state_of(ctx);
     MI_TRY(ensure_tables(ctx, log_n));
     const bool inverse = flags & MI_NTT_INVERSE, coset = flags & MI_NTT_COSET, dit = flags & MI_NTT_DIT;
@@ -134,10 +147,11 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
     t.tw_lo = inverse ? st->tw_lo_i : st->tw_lo_f;
     t.tw_hi = inverse ? st->tw_hi_i : st->tw_hi_f;
     t.tw_h = st->tw_h;
+    t.tw_64k = inverse ? st->tw64k_i : st->tw64k_f;
     u32 load_scale = 0, store_scale = 0;
-    if (coset && !inverse) { t.sc_lo = st->g_lo; t.sc_hi = st->g_hi; load_scale = dit ? 1 : 2; }
-    else if (coset && inverse) { t.sc_lo = st->gi_lo; t.sc_hi = st->gi_hi; store_scale = dit ? 4 : 3; }
-    else if (inverse) { t.sc_lo = st->ninv; t.sc_hi = st->ninv; store_scale = 5; }
+    if (coset && !inverse) { t.sc_lo = st->g_lo; t.sc_hi = variant == 2 ? st->g_hi_n : st->g_hi; load_scale = dit ? 1 : 2; }
+    else if (coset && inverse) { t.sc_lo = st->gi_lo; t.sc_hi = variant == 3 ? st->gi_hi_nd : st->gi_hi; store_scale = dit ? 4 : 3; }
+    else if (inverse && variant != 1) { t.sc_lo = st->ninv; t.sc_hi = st->ninv; store_scale = 5; }
 
     NttPlan pl = ntt_make_plan(log_n, st->max_contig, st->max_strided);
     // log_s of pass i (DIF order): product of later radices
@@ -186,21 +200,19 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
     MI_TRY(mi_reserve(ctx, ctx->ws[1], n * sizeof(Fr)));
     Fr *A = (Fr *)h_out, *B = (Fr *)ctx->ws[0].p, *C = (Fr *)ctx->ws[1].p;
     // 1. a,b,c <- FFTInverse(., DIF)  (zero padding fused into the first pass's load)
-    MI_TRY(ntt_run(ctx, A, (const Fr *)a, (u32)n_constraints, log_n, MI_NTT_INVERSE));
-    MI_TRY(ntt_run(ctx, B, (const Fr *)b, (u32)n_constraints, log_n, MI_NTT_INVERSE));
-    MI_TRY(ntt_run(ctx, C, (const Fr *)c, (u32)n_constraints, log_n, MI_NTT_INVERSE));
+    //    (their 1/N is applied by the coset shift of step 2 instead: same values, one product per element less)
+    MI_TRY(ntt_run(ctx, A, (const Fr *)a, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
+    MI_TRY(ntt_run(ctx, B, (const Fr *)b, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
+    MI_TRY(ntt_run(ctx, C, (const Fr *)c, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
     // 2. a,b,c <- FFT(., DIT, OnCoset)
-    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET));
-    MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET));
-    MI_TRY(ntt_run(ctx, C, C, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET));
-    // 3. a <- (a*b - c) / (g^n - 1)
-    Fr g = fe_from_u32<FrParams>(5), gn = g;
-    for (u32 k = 0; k < log_n; k++) gn = fe_sqr(gn);
-    Fr den = fe_inv(gn - Fr::one());
-    hipLaunchKernelGGL(k_h_pointwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, B, C, den, n);
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2));
+    MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2));
+    MI_TRY(ntt_run(ctx, C, C, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2));
+    // 3. a <- a*b - c          (the factor den = 1/(g^n - 1) rides in the scaling of step 4)
+    hipLaunchKernelGGL(k_h_pointwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, B, C, n);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    // 4. h <- FFTInverse(a, DIF, OnCoset), left bit-reversed like gnark
-    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET));
+    // 4. h <- FFTInverse(a, DIF, OnCoset) * den, left bit-reversed like gnark
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3));
     return MI_OK;
 }
 

@@ -30,6 +30,7 @@ struct NttTables {
     const Fr *tw_hi;    // tw_hi[j] = w_N^(j * 2^tw_h)
     const Fr *sc_lo;    // scale tables: sc_lo[j] = g^j, sc_hi[j] = const * g^(j * 2^tw_h)  (g = 5 or 1/5)
     const Fr *sc_hi;
+    const Fr *tw_64k;   // tw_64k[j] = w_65536^j, j < 65536: blocks of M <= 2^16 read their inter-pass twiddle directly (no product)
     u32 tw_h;
 };
 
@@ -41,7 +42,8 @@ struct NttPass {
     u32 dit;        // 0: DIF butterflies + post twiddle; 1: pre twiddle + DIT butterflies
     u32 twiddle;    // apply the inter-pass twiddle (0 on the pass with S == 1)
     u32 scale;      // 0 none; 1 load * sc[bitrev_N(i)]; 2 load * sc[i]; 3 store * sc[bitrev_N(i)];
-                    // 4 store * sc[i]; 5 store * sc_hi[0] (constant)
+                    // 4 store * sc[i]; 5 store * sc_hi[0] (constant).  Constant factors (1/N, and inside computeH
+                    // the 1/N of the preceding inverse transform or den) ride in sc_hi for free
     u32 n_valid;    // loads at global index >= n_valid read as zero (fused zero padding)
 };
 
@@ -84,8 +86,10 @@ MI_HD Fr lds_get(const U4 *lds, u32 plane_elems, u32 slot) {
 // inter-pass twiddle of (rho, lo): w_M^(lo * bitrev_R(rho)) = w_N^((lo * bitrev_R(rho)) << (log_n - log_m))
 MI_HD Fr ntt_interpass_twiddle(const NttPass &p, const NttTables &t, u32 rho, u64 g) {
     u32 lo = (u32)(g & (((u64)1 << p.log_s) - 1));
-    u32 e = (lo * bitrev_u32(rho, p.log_r)) << (p.log_n - p.log_r - p.log_s);
-    return pow_from_tables(t.tw_lo, t.tw_hi, t.tw_h, e);
+    u32 x = lo * bitrev_u32(rho, p.log_r);                      // exponent of w_M, x < M
+    const u32 log_m = p.log_r + p.log_s;
+    if (t.tw_64k && log_m <= 16) return t.tw_64k[x << (16 - log_m)];   // w_M^x = w_65536^(x * 65536/M)
+    return pow_from_tables(t.tw_lo, t.tw_hi, t.tw_h, x << (p.log_n - log_m));
 }
 
 // phase 1: global -> LDS (+ fused zero padding, coset pre-scale, DIT pre-twiddle)

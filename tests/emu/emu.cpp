@@ -71,7 +71,15 @@ extern "C" int emu_ntt(void *data_v, uint32_t log_n, uint32_t flags, uint32_t lo
     for (u32 j = 0; j < 1024; j++) small[j] = fr_pow_u64(w2048, j);
     for (u32 j = 0; j < nlo; j++) { twlo[j] = fr_pow_u64(w, j); sclo[j] = fr_pow_u64(g, j); }
     for (u32 j = 0; j < nhi; j++) { twhi[j] = fr_pow_u64(w, (u64)j << h); schi[j] = fr_pow_u64(g, (u64)j << h); if (inverse) schi[j] = schi[j] * ninv; }
-    NttTables t{small.data(), twlo.data(), twhi.data(), sclo.data(), schi.data(), h};
+    NttTables t{small.data(), twlo.data(), twhi.data(), sclo.data(), schi.data(), nullptr, h};
+    std::vector<Fr> tw64k;
+    if (log_n % 2 == 0) {   // exercise the direct-table path on half of the sizes
+        Fr w64k = root; for (int k = 16; k < 28; k++) w64k = fe_sqr(w64k);
+        if (inverse) w64k = fe_inv(w64k);
+        tw64k.resize(65536); tw64k[0] = Fr::one();
+        for (u32 j = 1; j < 65536; j++) tw64k[j] = tw64k[j - 1] * w64k;
+        t.tw_64k = tw64k.data();
+    }
     std::vector<Fr> nv(1, ninv);
     u32 load_scale = 0, store_scale = 0;
     if (coset && !inverse) load_scale = dit ? 1 : 2;
