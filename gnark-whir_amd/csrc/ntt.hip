@@ -99,9 +99,9 @@ static int32_t build_table(mi_ctx *ctx, Fr **slot, u32 count, const Fr &base, co
 static int32_t ensure_tables(mi_ctx *ctx, u32 log_n) {
     NttState *st = state_of(ctx);
     if (!st->small_f) {
-        Fr w2048 = domain_generator(11);
-        MI_TRY(build_table(ctx, &st->small_f, 1024, w2048, Fr::one(), 0));
-        MI_TRY(build_table(ctx, &st->small_i, 1024, fe_inv(w2048), Fr::one(), 0));
+        Fr w4096 = domain_generator(12);
+        MI_TRY(build_table(ctx, &st->small_f, 2048, w4096, Fr::one(), 0));
+        MI_TRY(build_table(ctx, &st->small_i, 2048, fe_inv(w4096), Fr::one(), 0));
         Fr w64k = domain_generator(16);
         MI_TRY(build_table(ctx, &st->tw64k_f, 65536, w64k, Fr::one(), 0));
         MI_TRY(build_table(ctx, &st->tw64k_i, 65536, fe_inv(w64k), Fr::one(), 0));
@@ -220,7 +220,7 @@ static void stats_begin(mi_ctx *ctx) { std::memset(&ctx->stats, 0, sizeof(ctx->s
 
 extern "C" {
 int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, uint32_t max_strided) {
-    if (!ctx || log_e < 1 || log_e > 12 || max_contig < 1 || max_contig > 11 || max_contig > log_e || max_strided < 1 || max_strided > log_e)
+    if (!ctx || log_e < 1 || log_e > 12 || max_contig < 1 || max_contig > 12 || max_contig > log_e || max_strided < 1 || max_strided > 12 || max_strided > log_e)
         return MI_EINVAL;
     NttState *st = state_of(ctx);
     st->log_e = log_e; st->max_contig = max_contig; st->max_strided = max_strided;

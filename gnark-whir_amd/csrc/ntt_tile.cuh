@@ -25,7 +25,7 @@
 struct U4 { u32 x, y, z, w; };  // 16-byte LDS slot (uint4 without pulling hip headers into host builds)
 
 struct NttTables {
-    const Fr *small;    // small[j] = w_2048^j, j < 1024  (in-tile butterfly twiddles for every radix <= 2^11)
+    const Fr *small;    // small[j] = w_4096^j, j < 2048  (in-tile butterfly twiddles for every radix <= 2^12)
     const Fr *tw_lo;    // tw_lo[j] = w_N^j,          j < 2^tw_h
     const Fr *tw_hi;    // tw_hi[j] = w_N^(j * 2^tw_h)
     const Fr *sc_lo;    // scale tables: sc_lo[j] = g^j, sc_hi[j] = const * g^(j * 2^tw_h)  (g = 5 or 1/5)
@@ -124,8 +124,8 @@ MI_HD void ntt_tile_stage(const NttPass &p, const NttTables &t, u32 stage, u32 t
         u32 r1 = r0 + d;
         u32 s0 = ntt_lds_slot(p, r0, col), s1 = ntt_lds_slot(p, r1, col);
         Fr x = lds_get(lds, E, s0), y = lds_get(lds, E, s1);
-        // twiddle w_(2d)^j = w_2048^(j * 1024/d)
-        const Fr &w = t.small[j << (10 - log_d)];
+        // twiddle w_(2d)^j = w_4096^(j * 2048/d)
+        const Fr &w = t.small[j << (11 - log_d)];
         if (p.dit) {
             if (j) y = y * w;
             lds_put(lds, E, s0, x + y);

@@ -61,14 +61,14 @@ extern "C" int emu_ntt(void *data_v, uint32_t log_n, uint32_t flags, uint32_t lo
     Fr *data = (Fr *)data_v;
     const bool inverse = flags & 1, coset = flags & 2, dit = flags & 4;
     Fr root = fr_from_u64x4(0x9bd61b6e725b19f0ull, 0x402d111e41112ed4ull, 0x00e0a7eb8ef62abcull, 0x2a3c09f0a58a7e85ull);
-    Fr w2048 = root; for (int k = 11; k < 28; k++) w2048 = fe_sqr(w2048);
+    Fr w2048 = root; for (int k = 12; k < 28; k++) w2048 = fe_sqr(w2048);   // w_4096 (name kept)
     Fr w = root; for (u32 k = log_n; k < 28; k++) w = fe_sqr(w);
     if (inverse) { w = fe_inv(w); w2048 = fe_inv(w2048); }
     Fr g = fe_from_u32<FrParams>(5); if (inverse) g = fe_inv(g);
     Fr nn = Fr::zero(); nn.l[0] = 1u << log_n; Fr ninv = fe_inv(fe_to_mont(nn));
     u32 h = (log_n + 1) / 2, nlo = 1u << h, nhi = 1u << (log_n - h);
-    std::vector<Fr> small(1024), twlo(nlo), twhi(nhi), sclo(nlo), schi(nhi);
-    for (u32 j = 0; j < 1024; j++) small[j] = fr_pow_u64(w2048, j);
+    std::vector<Fr> small(2048), twlo(nlo), twhi(nhi), sclo(nlo), schi(nhi);
+    for (u32 j = 0; j < 2048; j++) small[j] = fr_pow_u64(w2048, j);
     for (u32 j = 0; j < nlo; j++) { twlo[j] = fr_pow_u64(w, j); sclo[j] = fr_pow_u64(g, j); }
     for (u32 j = 0; j < nhi; j++) { twhi[j] = fr_pow_u64(w, (u64)j << h); schi[j] = fr_pow_u64(g, (u64)j << h); if (inverse) schi[j] = schi[j] * ninv; }
     NttTables t{small.data(), twlo.data(), twhi.data(), sclo.data(), schi.data(), nullptr, h};

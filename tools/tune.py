@@ -15,8 +15,8 @@ log_n = 23
 n = 1 << log_n
 if "ntt" in which:
     x = ctx.gen_scalars(n, 1, 0)
-    for threads in (128, 256, 512):
-        for (log_e, mc, ms) in ((10, 10, 7), (10, 10, 5), (9, 9, 7), (9, 9, 5), (8, 8, 8), (10, 8, 8), (11, 10, 7)):
+    for threads in (256,):
+        for (log_e, mc, ms) in ((9, 9, 7), (12, 11, 12), (12, 12, 11), (11, 11, 11), (10, 10, 10), (11, 9, 7)):
             assert lib.mi_debug_set_ntt_threads(ctx.h, threads) == 0
             if lib.mi_debug_set_ntt_plan(ctx.h, log_e, mc, ms) != 0:
                 continue
