@@ -22,7 +22,8 @@
  *     DEVICE pointers (hipMalloc'ed, 32-byte aligned) and never touch host memory.
  *   - the caller owns every buffer; the library keeps no caller pointer after return
  *     (cgo rule).  mi_ctx / mi_pk are opaque library-owned handles.
- *   - one mi_ctx drives one GPU.  Calls on one ctx are serialised on its HIP stream.
+ *   - one mi_ctx drives one GPU.  Calls on one ctx must not overlap (no internal locking); inside a call the library
+ *     fans work out over its own HIP streams and joins them before returning.
  */
 #ifndef MI355X_GROTH16_H
 #define MI355X_GROTH16_H
@@ -89,7 +90,12 @@ typedef struct mi_proof_out {
     mi_g1_affine krs;
 } mi_proof_out;
 
-/* Per-phase device times in milliseconds, measured with HIP events on the ctx stream. */
+/* Per-phase times in milliseconds.  The prove path runs computeH on the ctx stream and the five MSMs on five library
+ * streams, so the compute_h / msm_* spans (HIP events on their own streams) OVERLAP and do not add up to total_ms.
+ *   h2d_ms       host-pointer entry points only: upload of W, a, b, c
+ *   filter_ms    host blinding work (r*delta, s*delta, s*Ar, r*Bs1 ...) done while the GPU is still busy
+ *   assemble_ms  host work left after the last MSM landed (final additions, conversion to affine)
+ *   total_ms     wall clock of the call (host clock) */
 typedef struct mi_stats {
     float h2d_ms, compute_h_ms, filter_ms;
     float msm_a_ms, msm_b1_ms, msm_k_ms, msm_z_ms, msm_b2_ms;
