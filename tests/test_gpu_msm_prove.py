@@ -281,3 +281,24 @@ def test_full_size_prove_equals_composition_of_primitives(ctx):
     ctx.pk_free(pkh)
     for d in (g1a, g1b, g1k, g1z, g2b, W, a, b, c, h, wa, wb, wk):
         d.free()
+
+
+@pytest.mark.parametrize("log_n,nb_wires,nb_public,n_constraints,ia,ib", [
+    (0, 1, 1, 1, 0, 0),          # a single constraint, only the ONE wire: every MSM but Z... is trivial, Z has 0 points
+    (1, 3, 3, 2, 100, 100),      # no private wires, every A and B point at infinity
+    (3, 9, 2, 5, 0, 100),        # B empty: Bs = beta + s*delta
+    (5, 40, 7, 32, 100, 0),      # A empty, full domain of constraints
+    (9, 300, 300, 512, 30, 30),  # K empty (all wires public)
+])
+def test_prove_degenerate_shapes_vs_oracle(ctx, log_n, nb_wires, nb_public, n_constraints, ia, ib):
+    """empty / all-infinity / public-only shapes: the fused path must still equal the oracle byte for byte"""
+    B = load_binding()
+    pk = synthetic_pk(log_n, nb_wires, nb_public, 4000 + log_n, inf_a_pct=ia, inf_b_pct=ib)
+    W = cref.gen_scalars(nb_wires, 1, 1)
+    a = cref.gen_scalars(n_constraints, 2, 1); b = cref.gen_scalars(n_constraints, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    pkh = ctx.pk_load(pk)
+    got, _ = ctx.prove(pkh, W, a, b, c, r, s)
+    want = cref.prove(pk, W, a, b, c, r, s)
+    assert B.proof_write(got["raw"]) == cref.proof_write(want["raw"])
+    ctx.pk_free(pkh)
