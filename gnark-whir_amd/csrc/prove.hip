@@ -187,8 +187,14 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
     return MI_OK;
 }
 
-int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
-                             size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, mi_proof_out *out, mi_stats *stats) {
+}  // extern "C"
+
+// Host-pointer inputs of mi_groth16_prove (null for the device-pointer entry point).
+struct HostInputs { const mi_fr *W, *a, *b, *c; };
+
+// W, a, b, c: device buffers (for host inputs: staging areas the uploads below fill).
+static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                            size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, mi_proof_out *out, mi_stats *stats, const HostInputs *host) {
     if (!ctx || !pk || !W || !a || !b || !c || !r_m || !s_m || !out) return MI_EINVAL;
     const size_t N = (size_t)1 << pk->log_n;
     if (n_wires != pk->nb_wires || n_constraints > N) MI_FAIL(ctx, MI_EINVAL, "prove: witness size does not match the proving key");
@@ -198,29 +204,50 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wi
     // Stream plan: computeH on the caller's stream; MSM A, B1, B2, K, Z on slots 0..4 (own streams).  A, B and
     // K depend only on W and start at once; B2 (G2) reuses B1's sort; Z waits for h.  The latency-bound tails
     // (levels >= 2, bucket reduce, scans) of one MSM overlap the throughput-bound accumulation of the others.
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));          // inputs are ready
-    // step 4: h = computeH(a, b, c)  (bit-reversed, like gnark leaves it) -- enqueued first: it heads the longest chain
     MI_TRY(mi_reserve(ctx, ctx->ws[14], N * sizeof(Fr)));
     Fr *h = (Fr *)ctx->ws[14].p;
-    MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, c, n_constraints, (mi_fr *)h));
-    MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
-    MI_TRY(mi_msm_enqueue(ctx, 4, -1, 1, pk->g1_z, h, N - 1, 0, ev[3], true));     // h[:N-1] against the bit-reversed pk.G1.Z
-    // step 5: wireValuesA / wireValuesB / K scalars by the static gather indices, each on its MSM's stream
-    auto gather = [&](int slot, int wsi, const u32 *idx, size_t n) -> int32_t {
-        MI_TRY(mi_reserve(ctx, ctx->ws[wsi], (n + 1) * sizeof(Fr)));
-        hipStream_t st = ctx->msm[slot].stream;
-        MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, ev[2], 0));
-        if (n) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (Fr *)ctx->ws[wsi].p, (const Fr *)W, idx, n);
-        MI_CHECK_HIP(ctx, hipGetLastError());
-        return MI_OK;
+    // step 4: h = computeH(a, b, c)  (bit-reversed, like gnark leaves it), then the Z MSM over h[:N-1] against the bit-reversed pk.G1.Z
+    auto enqueue_h_and_z = [&]() -> int32_t {
+        MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, c, n_constraints, (mi_fr *)h));
+        MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+        return mi_msm_enqueue(ctx, 4, -1, 1, pk->g1_z, h, N - 1, 0, ev[3], true);
     };
-    MI_TRY(gather(1, 17, pk->idx_b, pk->n_b));
-    MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, 0, nullptr, true));
-    MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, 0, nullptr, false));      // same scalars: shared sort
-    // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
-    // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
-    MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, 0, ev[2], true));
-    MI_TRY(mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, 0, nullptr, true));
+    // step 5 + the wire MSMs: they depend on W only (ev[2] = "W is on the device")
+    auto enqueue_wire_msms = [&]() -> int32_t {
+        // wireValuesB by the static gather indices, on its MSM's stream; B2 (G2) shares B1's sort (same scalars)
+        MI_TRY(mi_reserve(ctx, ctx->ws[17], (pk->n_b + 1) * sizeof(Fr)));
+        hipStream_t st = ctx->msm[1].stream;
+        MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, ev[2], 0));
+        if (pk->n_b) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((pk->n_b + 255) / 256)), dim3(256), 0, st, (Fr *)ctx->ws[17].p, (const Fr *)W, pk->idx_b, pk->n_b);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, 0, nullptr, true));
+        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, 0, nullptr, false));
+        // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
+        // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
+        MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, 0, ev[2], true));
+        return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, 0, nullptr, true);
+    };
+    // Stream plan: computeH on the caller's stream; MSM A, B1, B2, K, Z on slots 0..4 (own streams).  The latency-bound
+    // tails (levels >= 2, bucket reduce, scans) of one MSM overlap the throughput-bound accumulation of the others.
+    if (!host) {
+        // inputs already in HBM: computeH heads the longest chain (h -> Z MSM), so it is enqueued first
+        MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+        MI_TRY(enqueue_h_and_z());
+        MI_TRY(enqueue_wire_msms());
+    } else {
+        // inputs in host memory (the cgo path): upload W, start the wire MSMs, and upload a, b, c WHILE they run; the
+        // PCIe time of a, b, c (3/4 of the bytes) disappears behind the MSMs instead of preceding the whole proof
+        const size_t wb = n_wires * sizeof(mi_fr), cb = n_constraints * sizeof(mi_fr);
+        MI_CHECK_HIP(ctx, hipEventRecord(ev[10], ctx->stream));
+        MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)W, host->W, wb, hipMemcpyHostToDevice, ctx->stream));
+        MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+        MI_TRY(enqueue_wire_msms());
+        MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)a, host->a, cb, hipMemcpyHostToDevice, ctx->stream));
+        MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)b, host->b, cb, hipMemcpyHostToDevice, ctx->stream));
+        MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)c, host->c, cb, hipMemcpyHostToDevice, ctx->stream));
+        MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
+        MI_TRY(enqueue_h_and_z());
+    }
     // step 6 while the GPU works: blinding multiples of delta on the host (O(1) points)
     Fr r, s;
     std::memcpy(&r, r_m, 32); std::memcpy(&s, s_m, 32);
@@ -267,7 +294,8 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wi
         return MI_OK;
     };
     // per-phase spans overlap (five streams): they do not add up to total_ms
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.compute_h_ms, ev[2], ev[3]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.compute_h_ms, host ? ev[11] : ev[2], ev[3]));
+    if (host) MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.h2d_ms, ev[10], ev[11]));   // span of the uploads (overlaps the wire MSMs)
     if (pk->nb_wires) MI_TRY(slot_ms(0, &st.msm_a_ms));
     if (pk->n_b) { MI_TRY(slot_ms(1, &st.msm_b1_ms)); MI_TRY(slot_ms(2, &st.msm_b2_ms)); }
     if (pk->nb_wires) MI_TRY(slot_ms(3, &st.msm_k_ms));
@@ -279,23 +307,19 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wi
     return MI_OK;
 }
 
+extern "C" {
+int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                             size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats) {
+    return prove_common(ctx, pk, W, n_wires, a, b, c, n_constraints, r, s, out, stats, nullptr);
+}
 int32_t mi_groth16_prove(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                          size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats) {
     if (!ctx || !pk || !W || !a || !b || !c || !r || !s || !out) return MI_EINVAL;
     const size_t wb = n_wires * 32, cb = n_constraints * 32;
     MI_TRY(mi_reserve(ctx, ctx->ws[16], wb + 3 * cb + 128));
     char *base = (char *)ctx->ws[16].p;
-    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[10], ctx->stream));
-    MI_CHECK_HIP(ctx, hipMemcpyAsync(base, W, wb, hipMemcpyHostToDevice, ctx->stream));
-    MI_CHECK_HIP(ctx, hipMemcpyAsync(base + wb, a, cb, hipMemcpyHostToDevice, ctx->stream));
-    MI_CHECK_HIP(ctx, hipMemcpyAsync(base + wb + cb, b, cb, hipMemcpyHostToDevice, ctx->stream));
-    MI_CHECK_HIP(ctx, hipMemcpyAsync(base + wb + 2 * cb, c, cb, hipMemcpyHostToDevice, ctx->stream));
-    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[11], ctx->stream));
-    MI_TRY(mi_groth16_prove_dev(ctx, pk, (mi_fr *)base, n_wires, (mi_fr *)(base + wb), (mi_fr *)(base + wb + cb), (mi_fr *)(base + wb + 2 * cb),
-                                n_constraints, r, s, out, nullptr));
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.h2d_ms, ctx->ev[10], ctx->ev[11]));
-    ctx->stats.total_ms += ctx->stats.h2d_ms;
-    if (stats) *stats = ctx->stats;
-    return MI_OK;
+    const HostInputs host{W, a, b, c};
+    return prove_common(ctx, pk, (mi_fr *)base, n_wires, (mi_fr *)(base + wb), (mi_fr *)(base + wb + cb), (mi_fr *)(base + wb + 2 * cb),
+                        n_constraints, r, s, out, stats, &host);
 }
 }
