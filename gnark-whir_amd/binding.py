@@ -21,6 +21,7 @@ EXPORTS = [
     "mi_g2_compress", "mi_proof_write", "mi_g1_sum", "mi_g2_sum", "mi_gen_scalars_dev", "mi_gen_g1_dev",
     "mi_gen_g2_dev", "mi_field_op_dev", "mi_g1_add_dev", "mi_g2_add_dev", "mi_bench_modmul_dev", "mi_bench_valu_dev",
     "mi_dev_alloc", "mi_dev_free", "mi_dev_upload", "mi_dev_download", "mi_dev_sync",
+    "mi_msm_precompute_g1_dev", "mi_msm_precompute_g2_dev", "mi_msm_g1_fixed_dev", "mi_msm_g2_fixed_dev",
     "mi_batch_scalar_mul_g1", "mi_batch_scalar_mul_g1_dev", "mi_batch_scalar_mul_g2", "mi_batch_scalar_mul_g2_dev",
     "mi_pedersen_pk_load", "mi_pedersen_pk_free", "mi_pedersen_commit", "mi_pedersen_prove_knowledge", "mi_pedersen_fold",
 ]
@@ -208,6 +209,20 @@ class Context:
     def msm_g2_dev(self, pts_ptr, sc_ptr, n, flags=0):
         out = np.zeros(24, np.uint64)
         self._ck(self.lib.mi_msm_g2_dev(self.h, _p(pts_ptr), _p(sc_ptr), C.c_size_t(n), C.c_uint32(flags), _p(out))); return out
+
+    # ---- fixed-base MSM (window copies of static bases)
+    def msm_precompute(self, base_ptr, n, c, g2=False):
+        nwin = (256 + c - 1) // c
+        pre = self.alloc((128 if g2 else 64) * n * nwin)
+        f = self.lib.mi_msm_precompute_g2_dev if g2 else self.lib.mi_msm_precompute_g1_dev
+        self._ck(f(self.h, _p(base_ptr), C.c_size_t(n), C.c_uint32(c), _p(pre.ptr)))
+        return pre
+
+    def msm_fixed_dev(self, pre_ptr, sc_ptr, n, c, flags=0, g2=False):
+        out = np.zeros(24 if g2 else 12, np.uint64)
+        f = self.lib.mi_msm_g2_fixed_dev if g2 else self.lib.mi_msm_g1_fixed_dev
+        self._ck(f(self.h, _p(pre_ptr), _p(sc_ptr), C.c_size_t(n), C.c_uint32(c), C.c_uint32(flags), _p(out)))
+        return out
 
     # ---- proving key + prove
     def pk_load(self, pk: dict, device_points=False):

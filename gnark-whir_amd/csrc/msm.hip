@@ -14,17 +14,22 @@
 // performs one mixed addition (~10 Fp products): it is VALU-bound by two orders of magnitude; the HBM
 // figure reported for it is the algorithmic 96 B (160 B) per pair of SURVEY 8d over its duration.
 #include "ctx.h"
-#include "msm_core.cuh"
+#include "msm2_core.cuh"
 #include "msm_curve_ops.h"
 #include <cstring>
 #include <new>
 
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
+    u32 chunk = 0;                              // fixed-base sort: entries per pass-2 chunk (tests shrink it)
 };
 static MsmKnobs *knobs_of(mi_ctx *ctx) { return reinterpret_cast<MsmKnobs *>(ctx->msm_knobs); }
 __global__ void k_msm_hist(MsmShape s, const int16_t *digits, u32 *H);
 __global__ void k_msm_scatter(MsmShape s, const int16_t *digits, const u32 *keystart, const u32 *Hx, u32 *sorted);
+struct Msm2Shape;
+__global__ void k_msm2_hist2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const uint16_t *part_lo, u32 *H2);
+__global__ void k_msm2_scatter2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const u32 *keystart, const u32 *H2x,
+                                const uint16_t *part_lo, const u32 *part_val, u32 *sorted);
 
 // ---------------------------------------------------------------- kernels
 __global__ void k_msm_digits(MsmShape s, const Fr *scalars, int montgomery, int16_t *digits) {
@@ -64,6 +69,48 @@ __global__ void k_msm_prep_windows(u32 nwin, u32 tb, u32 L, u32 *start, u32 *cnt
     u32 w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w < nwin) { start[w] = w * tb; cnt[w] = tb; items[w] = (tb + L - 1) / L; }
 }
+// ---------------------------------------------------------------- fixed-base MSM: two-pass bucket sort (msm2_core.cuh)
+__global__ void __launch_bounds__(256) k_msm2_count(Msm2Shape s, const Fr *scalars, int montgomery, u32 *C1) {
+    __shared__ u32 lds[64];
+    if (threadIdx.x < 64) lds[threadIdx.x] = 0;
+    __syncthreads();
+    msm2_count_body(s, scalars, montgomery != 0, blockIdx.x, lds, threadIdx.x, blockDim.x);
+    __syncthreads();
+    if (threadIdx.x < s.ngroups) C1[(size_t)threadIdx.x * s.nslices + blockIdx.x] = lds[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) k_msm2_partition(Msm2Shape s, const Fr *scalars, int montgomery, const u32 *S1, uint16_t *part_lo, u32 *part_val) {
+    __shared__ u32 lds[64];
+    if (threadIdx.x < s.ngroups) lds[threadIdx.x] = S1[(size_t)threadIdx.x * s.nslices + blockIdx.x];
+    __syncthreads();
+    msm2_partition_body(s, scalars, montgomery != 0, blockIdx.x, lds, part_lo, part_val, threadIdx.x, blockDim.x);
+}
+__global__ void k_msm2_chunk_table(Msm2Shape s, const u32 *S1, u32 *gstart, u32 *cstart) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) msm2_chunk_table_body(s, S1, gstart, cstart);
+}
+__global__ void __launch_bounds__(1024) k_msm2_hist2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const uint16_t *part_lo, u32 *H2) {
+    extern __shared__ u32 lds_u32[];
+    u32 hi, b, e;
+    if (!msm2_chunk_range(s, gstart, cstart, blockIdx.x, hi, b, e)) return;   // the grid is a host-side bound
+    msm2_hist2_zero(lds_u32, threadIdx.x, blockDim.x);
+    __syncthreads();
+    msm2_hist2_count(part_lo, b, e, lds_u32, threadIdx.x, blockDim.x);
+    __syncthreads();
+    msm2_hist2_write(H2, blockIdx.x, lds_u32, threadIdx.x, blockDim.x);
+}
+__global__ void k_msm2_colsum(Msm2Shape s, const u32 *cstart, u32 *H2, u32 *total) {
+    u32 key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key < s.nkeys) msm2_colsum_body(cstart, H2, total, key);
+}
+__global__ void __launch_bounds__(1024) k_msm2_scatter2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const u32 *keystart, const u32 *H2x,
+                                                        const uint16_t *part_lo, const u32 *part_val, u32 *sorted) {
+    extern __shared__ u32 lds_u32[];
+    u32 hi, b, e;
+    if (!msm2_chunk_range(s, gstart, cstart, blockIdx.x, hi, b, e)) return;
+    msm2_scatter2_init(keystart, H2x, blockIdx.x, hi, lds_u32, threadIdx.x, blockDim.x);
+    __syncthreads();
+    msm2_scatter2_move(part_lo, part_val, b, e, lds_u32, sorted, threadIdx.x, blockDim.x);
+}
+
 // ---------------------------------------------------------------- exclusive scan of u32 (out has m+1 entries, out[m] = total)
 static constexpr u32 SCAN_PER_THREAD = 16, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_PER_THREAD * SCAN_THREADS;
 __device__ u32 block_exclusive_scan_256(u32 v, u32 *lds, u32 *total) {
@@ -145,12 +192,20 @@ static u32 auto_c(u32 n) {
     return (u32)c;
 }
 static MsmShape slot_shape(const MsmSlot &sl) { return msm_shape(sl.n, sl.c, sl.G); }
+// shape of the key space the accumulate / reduce stages see: nwin_keys windows of 2^(c-1) buckets
+static MsmShape key_shape(const MsmSlot &sl) {
+    MsmShape s;
+    s.c = sl.c; s.nwin = sl.nwin_keys; s.nbuckets = 1u << (sl.c - 1); s.nkeys = s.nwin * s.nbuckets; s.nslices = sl.G; s.n = sl.n;
+    return s;
+}
 
 void mi_msm_state_init(mi_ctx *ctx) {
     new (ctx->msm_knobs) MsmKnobs();
     // the c = 16 histogram / cursor image is 128 KiB of LDS (gfx950 allows 160 KiB per workgroup)
     (void)hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_msm2_hist2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_msm2_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (auto &sl : ctx->msm) {
         (void)hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
         for (auto &e : sl.ev) (void)hipEventCreate(&e);
@@ -167,7 +222,7 @@ void mi_msm_state_free(mi_ctx *ctx) {
 }
 
 // slot buffers
-enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_COUNT_ };
+enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_PVAL, B_C1, B_CHUNKS, B_COUNT_ };
 
 // Runs levels of the item machinery over `nkeys` keys whose level-0 decomposition (start/cnt/items) is
 // already in cur.  Level 0 reads (pts, sorted) when pts != null, else partial_first.
@@ -215,6 +270,7 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
     sl.c = kn->c ? kn->c : auto_c(n);
     sl.G = kn->G ? kn->G : (n / 8192 > 64 ? 64 : (n / 8192 ? n / 8192 : 1));
     const MsmShape s = slot_shape(sl);
+    sl.nwin_keys = sl.nwin_digits = s.nwin;
     const u64 T_bound = (u64)s.nwin * n;
     if (s.nwin > 128) MI_FAIL(ctx, MI_EINVAL, "msm: too many windows");
     MI_TRY(mi_reserve(ctx, sl.buf[B_DIGITS], T_bound * 2 + 64));
@@ -237,15 +293,54 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
     return MI_OK;
 }
 
+// fixed-base sort stage: entries of ALL windows keyed by one bucket set of 2^(c-1), two-pass sort.  Records sl.ev[0].
+static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c) {
+    MsmKnobs *kn = knobs_of(ctx);
+    if (c < 17 || c > 22) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: window bits must be 17..22");
+    const u32 G = n / 32768 > 512 ? 512 : (n / 32768 ? n / 32768 : 1);
+    const u32 chunk = kn->chunk ? kn->chunk : 65536;
+    const Msm2Shape s = msm2_shape(n, c, G, chunk);
+    sl.n = n; sl.c = c; sl.G = G; sl.nwin_keys = 1; sl.nwin_digits = s.nwin;
+    const u64 T_bound = (u64)s.nwin * n;
+    if (T_bound >= ((u64)1 << 31)) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: windows * n must stay below 2^31");
+    const u32 chunks_bound = (u32)(T_bound / chunk) + s.ngroups + 1;
+    MI_TRY(mi_reserve(ctx, sl.buf[B_C1], ((size_t)s.ngroups * G + 1) * 4 * 2));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_DIGITS], T_bound * 2 + 64));                  // part_lo (u16)
+    MI_TRY(mi_reserve(ctx, sl.buf[B_PVAL], (T_bound + 1) * 4));                   // part_val
+    MI_TRY(mi_reserve(ctx, sl.buf[B_CHUNKS], ((size_t)s.ngroups + 1) * 4 * 2));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_H], (size_t)chunks_bound * 32768 * 4));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_S], ((size_t)s.nkeys * 2 + 2) * 4));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_SORTED], (T_bound + 1) * 4));
+    u32 *C1 = (u32 *)sl.buf[B_C1].p, *S1 = C1 + (size_t)s.ngroups * G + 1;
+    uint16_t *part_lo = (uint16_t *)sl.buf[B_DIGITS].p;
+    u32 *part_val = (u32 *)sl.buf[B_PVAL].p, *gstart = (u32 *)sl.buf[B_CHUNKS].p, *cstart = gstart + s.ngroups + 1;
+    u32 *H2 = (u32 *)sl.buf[B_H].p, *keystart = (u32 *)sl.buf[B_S].p, *total = keystart + s.nkeys + 1, *sorted = (u32 *)sl.buf[B_SORTED].p;
+    const int mont = (flags & MI_MSM_SCALARS_CANONICAL) ? 0 : 1;
+    hipStream_t st = sl.stream;
+    hipLaunchKernelGGL(k_msm2_count, dim3(G), dim3(256), 0, st, s, scalars, mont, C1);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(exclusive_scan(ctx, st, C1, (size_t)s.ngroups * G, S1, sl.buf[B_SCAN]));
+    hipLaunchKernelGGL(k_msm2_partition, dim3(G), dim3(256), 0, st, s, scalars, mont, S1, part_lo, part_val);
+    hipLaunchKernelGGL(k_msm2_chunk_table, dim3(1), dim3(64), 0, st, s, S1, gstart, cstart);
+    hipLaunchKernelGGL(k_msm2_hist2, dim3(chunks_bound), dim3(1024), 32768 * 4, st, s, gstart, cstart, part_lo, H2);
+    hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, cstart, H2, total);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
+    hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound), dim3(1024), 32768 * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[0], st));
+    return MI_OK;
+}
+
 // accumulate stage on slot acc, reading the sort of slot srt (may be the same slot)
 static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &srt, MsmSlot &acc, const void *pts, bool timed) {
     MsmKnobs *kn = knobs_of(ctx);
-    acc.n = srt.n; acc.c = srt.c; acc.G = srt.G;
-    const MsmShape s = slot_shape(srt);
+    acc.n = srt.n; acc.c = srt.c; acc.G = srt.G; acc.nwin_keys = srt.nwin_keys; acc.nwin_digits = srt.nwin_digits;
+    const MsmShape s = key_shape(srt);
     const u32 n = s.n;
     const u32 L1 = kn->L1 ? kn->L1 : 16, L2 = kn->L2 ? kn->L2 : 8;   // tools/tune.py sweep, N = 2^23
     const u32 seg = kn->seg ? kn->seg : (s.nbuckets >= 256 ? 8 : 2);
-    const u64 T_bound = (u64)s.nwin * n;
+    const u64 T_bound = (u64)srt.nwin_digits * n;
     hipStream_t st = acc.stream;
     if (&srt != &acc) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, srt.ev[0], 0));
     MI_TRY(mi_reserve(ctx, acc.buf[B_LEVELS], ((size_t)s.nkeys + 1) * 4 * 8));
@@ -258,7 +353,9 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * ops.xyzz_bytes, st));
     hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, S, L1, A.start, A.cnt, A.items);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, n, L1, L2, pts, sorted, nullptr, bucket, timed));
+    // largest possible bucket: one entry per scalar and window of the key space it collects
+    const u64 max_count = (u64)(srt.nwin_digits / srt.nwin_keys) * n;
+    MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed));
     // bucket reduce -> per-window partials -> window sums -> pinned host memory
     const u32 tb = (s.nbuckets + seg - 1) / seg;
     MI_TRY(mi_reserve(ctx, acc.buf[B_WIN], ((size_t)s.nwin * tb + s.nwin + 1) * ops.xyzz_bytes));
@@ -279,7 +376,7 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
 static int32_t msm_finish(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, void *out) {
     if (!sl.active) { ops.combine_windows(nullptr, 0, 0, out); return MI_OK; }   // zero windows -> infinity
     MI_CHECK_HIP(ctx, hipStreamSynchronize(sl.stream));
-    const MsmShape s = slot_shape(sl);
+    const MsmShape s = key_shape(sl);
     ops.combine_windows(sl.host_wsum, s.nwin, s.c, out);   // Horner on the host, <= 128 points
     if (sl.timed) {
         float ms = 0;
@@ -294,8 +391,15 @@ static int32_t msm_finish(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, void
 }
 
 // internal entry points used by prove.hip (curve: 1 = G1, 2 = G2)
+int32_t mi_msm_precompute(mi_ctx *ctx, int curve, const void *base_dev, void *pre_dev, size_t n, uint32_t c) {
+    if (!ctx || !base_dev || !pre_dev || c < 17 || c > 22 || n >= ((size_t)1 << 31)) return MI_EINVAL;
+    const MsmCurveOps &ops = curve == 1 ? msm_g1_ops() : msm_g2_ops();
+    if (n) ops.precompute(ctx->stream, base_dev, pre_dev, (u32)n, c, (256 + c - 1) / c);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
 int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
-                       uint32_t flags, hipEvent_t wait_ev, bool timed) {
+                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c) {
     if (slot < 0 || slot >= MI_MSM_SLOTS || sort_slot >= MI_MSM_SLOTS) return MI_EINVAL;
     if (n > ((size_t)1 << 27)) MI_FAIL(ctx, MI_EINVAL, "msm: n > 2^27 pairs per device not supported (shard the points)");
     MsmSlot &sl = ctx->msm[slot];
@@ -304,7 +408,8 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
     MsmSlot &srt = sort_slot >= 0 ? ctx->msm[sort_slot] : sl;
-    if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags));
+    if (sort_slot < 0 && precomp_c) MI_TRY(msm2_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, precomp_c));
+    else if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags));
     else if (srt.n != n) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
     return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed);
 }
@@ -345,7 +450,43 @@ static int32_t msm_host_entry(mi_ctx *ctx, int curve, const AffT *pts, const mi_
     return msm_dev_entry<F>(ctx, curve, ctx->ws[2].p, ctx->ws[3].p, n, flags, out);
 }
 
+template <class F, class JacT>
+static int32_t msm_fixed_dev_entry(mi_ctx *ctx, int curve, const void *pre_dev, const void *scalars_dev, size_t n, uint32_t c, uint32_t flags, JacT *out) {
+    std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pre_dev, scalars_dev, n, flags, ctx->ev[0], curve == 1, c));
+    if (n) MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->msm[0].stream));
+    XYZZ<F> r;
+    MI_TRY(mi_msm_finish(ctx, 0, curve, &r));
+    if (n) MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.total_ms, ctx->ev[0], ctx->ev[1]));
+    xyzz_to_jac_out<F>(r, out);
+    return MI_OK;
+}
+
 extern "C" {
+int32_t mi_msm_precompute_g1_dev(mi_ctx *ctx, const mi_g1_affine *base_dev, size_t n, uint32_t c, mi_g1_affine *pre_dev) {
+    MI_TRY(mi_msm_precompute(ctx, 1, base_dev, pre_dev, n, c));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+int32_t mi_msm_precompute_g2_dev(mi_ctx *ctx, const mi_g2_affine *base_dev, size_t n, uint32_t c, mi_g2_affine *pre_dev) {
+    MI_TRY(mi_msm_precompute(ctx, 2, base_dev, pre_dev, n, c));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MI_OK;
+}
+int32_t mi_msm_g1_fixed_dev(mi_ctx *ctx, const mi_g1_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c, uint32_t flags, mi_g1_jac *out) {
+    if (!ctx || !out || ((!pre_dev || !scalars_dev) && n) || (flags & ~1u)) return MI_EINVAL;
+    return msm_fixed_dev_entry<Fp>(ctx, 1, pre_dev, scalars_dev, n, c, flags, out);
+}
+int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c, uint32_t flags, mi_g2_jac *out) {
+    if (!ctx || !out || ((!pre_dev || !scalars_dev) && n) || (flags & ~1u)) return MI_EINVAL;
+    return msm_fixed_dev_entry<Fp2>(ctx, 2, pre_dev, scalars_dev, n, c, flags, out);
+}
+int32_t mi_debug_set_msm_chunk(mi_ctx *ctx, uint32_t chunk) {
+    if (!ctx) return MI_EINVAL;
+    knobs_of(ctx)->chunk = chunk;
+    return MI_OK;
+}
 int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G) {
     if (!ctx || c == 1 || c > 16 || G > 1024 || L1 == 1 || L2 == 1) return MI_EINVAL;   // items of one entry would never shrink a level
     MsmKnobs *k = knobs_of(ctx);

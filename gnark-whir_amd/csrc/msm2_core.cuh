@@ -1,0 +1,156 @@
+// Fixed-base ("precomputed") MSM: per-thread bodies shared by the HIP kernels (msm2.hip) and the host emulation.
+//
+// The proving key is static, so mi_pk_load can store, next to every base P_i, the multiples 2^(c*w) * P_i (w < nwin).
+// A scalar's w-th signed digit d then contributes d * (2^(c*w) P_i): ALL windows share ONE set of 2^(c-1) buckets, the
+// window combine disappears and c can grow to 22 bits (12 digits per 254-bit scalar instead of 16) because the bucket
+// count no longer multiplies by the number of windows.  Same result as gnark-crypto's MultiExp (a canonical group
+// element); replaces the same reference functions as msm_core.cuh.
+//
+//   entry      key = |d| - 1 (21 bits), value = (w * n + i) | sign << 31     -> point = pre[w][i]
+//   sort       two passes: (1) partition by hi = key >> 15 (64 groups, long contiguous runs per slice);
+//              (2) inside a group, LDS counting sort by lo = key & 0x7fff over fixed-size chunks of the group.
+//   after that the item / level / bucket-reduce machinery of msm_core.cuh runs unchanged on nkeys = 2^(c-1), one window.
+#pragma once
+#include "msm_core.cuh"
+
+struct Msm2Shape {
+    u32 c;          // window bits (17..22)
+    u32 nwin;       // ceil(256 / c)
+    u32 nkeys;      // 2^(c-1) buckets, one set for all windows
+    u32 ngroups;    // nkeys >> 15
+    u32 nslices;    // slices of the scalar range for pass 1
+    u32 chunk;      // entries per pass-2 chunk
+    u32 n;          // pairs
+};
+MI_HD Msm2Shape msm2_shape(u32 n, u32 c, u32 nslices, u32 chunk) {
+    Msm2Shape s;
+    s.c = c; s.nwin = (256 + c - 1) / c; s.nkeys = 1u << (c - 1); s.ngroups = s.nkeys >> 15;
+    s.nslices = nslices; s.chunk = chunk; s.n = n;
+    return s;
+}
+MI_HD void msm2_slice_range(const Msm2Shape &s, u32 g, u32 &begin, u32 &end) {
+    u32 per = (s.n + s.nslices - 1) / s.nslices;
+    begin = g * per < s.n ? g * per : s.n;
+    end = begin + per < s.n ? begin + per : s.n;
+}
+// signed digit w of the canonical scalar v, carry chained from window 0 (digits in [-2^(c-1), 2^(c-1) - 1])
+struct Msm2Digits {
+    Fr v;
+    u32 carry;
+    u32 w;
+    MI_HD void start(const Fr &scalar, bool montgomery) { v = montgomery ? fe_from_mont(scalar) : scalar; carry = 0; w = 0; }
+    MI_HD int32_t next(const Msm2Shape &s) {
+        u32 bit = w * s.c, limb = bit >> 5, sh = bit & 31;
+        u64 lo = limb < 8 ? v.l[limb] : 0u, hi = limb + 1 < 8 ? v.l[limb + 1] : 0u;
+        u32 raw = (u32)(((hi << 32) | lo) >> sh) & ((1u << s.c) - 1);
+        int32_t d = (int32_t)(raw + carry);
+        if ((u32)d >= s.nkeys) { d -= (int32_t)(1u << s.c); carry = 1; } else carry = 0;
+        w++;
+        return d;
+    }
+};
+
+// ---- pass 1a: workgroup = slice g; LDS hist[ngroups]; C1[hi][g]
+MI_HD void msm2_count_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *lds, u32 tid, u32 nthr) {
+    u32 begin, end;
+    msm2_slice_range(s, g, begin, end);
+    for (u32 i = begin + tid; i < end; i += nthr) {
+        Msm2Digits dg;
+        dg.start(scalars[i], montgomery);
+        for (u32 w = 0; w < s.nwin; w++) {
+            int32_t d = dg.next(s);
+            if (d) MI_LDS_ATOMIC_ADD(&lds[((u32)(d < 0 ? -d : d) - 1) >> 15], 1u);
+        }
+    }
+}
+// ---- pass 1b: partition.  LDS cursor[hi] = S1[hi * G + g]; writes the group-local bucket (u16) and the value (u32)
+MI_HD void msm2_partition_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *lds, uint16_t *part_lo, u32 *part_val,
+                               u32 tid, u32 nthr) {
+    u32 begin, end;
+    msm2_slice_range(s, g, begin, end);
+    for (u32 i = begin + tid; i < end; i += nthr) {
+        Msm2Digits dg;
+        dg.start(scalars[i], montgomery);
+        for (u32 w = 0; w < s.nwin; w++) {
+            int32_t d = dg.next(s);
+            if (!d) continue;
+            u32 key = (u32)(d < 0 ? -d : d) - 1;
+            u32 pos = MI_LDS_ATOMIC_ADD(&lds[key >> 15], 1u);
+            part_lo[pos] = (uint16_t)(key & 0x7fffu);
+            part_val[pos] = (w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+// ---- chunk table: group hi owns entries [gstart[hi], gstart[hi+1]); it is cut into ceil(size / chunk) chunks.
+// cstart[hi] = first chunk id of group hi (exclusive scan), cstart[ngroups] = total chunks.   (single thread, <= 64 groups)
+MI_HD void msm2_chunk_table_body(const Msm2Shape &s, const u32 *S1, u32 *gstart, u32 *cstart) {
+    u32 acc = 0;
+    for (u32 hi = 0; hi < s.ngroups; hi++) {
+        u32 a = S1[(size_t)hi * s.nslices], b = S1[(size_t)(hi + 1) * s.nslices];   // S1 has ngroups*G + 1 entries
+        gstart[hi] = a;
+        cstart[hi] = acc;
+        acc += (b - a + s.chunk - 1) / s.chunk;
+    }
+    gstart[s.ngroups] = S1[(size_t)s.ngroups * s.nslices];
+    cstart[s.ngroups] = acc;
+}
+// chunk id -> (group, entry range)
+MI_HD bool msm2_chunk_range(const Msm2Shape &s, const u32 *gstart, const u32 *cstart, u32 chunk_id, u32 &hi, u32 &b, u32 &e) {
+    if (chunk_id >= cstart[s.ngroups]) return false;
+    u32 lo_g = 0, hi_g = s.ngroups;   // largest group with cstart <= chunk_id (groups without chunks share a start with their successor)
+    while (hi_g - lo_g > 1) {
+        u32 mid = (lo_g + hi_g) >> 1;
+        if (cstart[mid] <= chunk_id) lo_g = mid; else hi_g = mid;
+    }
+    hi = lo_g;
+    b = gstart[hi] + (chunk_id - cstart[hi]) * s.chunk;
+    e = gstart[hi + 1];
+    if (b + s.chunk < e) e = b + s.chunk;
+    return true;
+}
+// ---- pass 2a: workgroup = chunk; LDS hist[32768] (u32); H2[chunk][lo]
+MI_HD void msm2_hist2_zero(u32 *lds, u32 tid, u32 nthr) {
+    for (u32 b = tid; b < 32768; b += nthr) lds[b] = 0;
+}
+MI_HD void msm2_hist2_count(const uint16_t *part_lo, u32 b, u32 e, u32 *lds, u32 tid, u32 nthr) {
+    for (u32 k = b + tid; k < e; k += nthr) MI_LDS_ATOMIC_ADD(&lds[part_lo[k]], 1u);
+}
+MI_HD void msm2_hist2_write(u32 *H2, u32 chunk_id, const u32 *lds, u32 tid, u32 nthr) {
+    for (u32 b = tid; b < 32768; b += nthr) H2[(size_t)chunk_id * 32768 + b] = lds[b];
+}
+// ---- column sums: thread = key (hi, lo): H2[chunk][lo] <- exclusive prefix along the chunks of group hi (in place),
+// total[key] <- number of entries of the key
+MI_HD void msm2_colsum_body(const u32 *cstart, u32 *H2, u32 *total, u32 key) {
+    u32 hi = key >> 15, lo = key & 0x7fffu, run = 0;
+    for (u32 ch = cstart[hi]; ch < cstart[hi + 1]; ch++) {
+        size_t i = (size_t)ch * 32768 + lo;
+        u32 v = H2[i];
+        H2[i] = run;
+        run += v;
+    }
+    total[key] = run;
+}
+// ---- pass 2b: scatter.  cursor[lo] = keystart[hi*32768 + lo] + H2x[chunk][lo]
+MI_HD void msm2_scatter2_init(const u32 *keystart, const u32 *H2x, u32 chunk_id, u32 hi, u32 *lds, u32 tid, u32 nthr) {
+    for (u32 b = tid; b < 32768; b += nthr) lds[b] = keystart[(size_t)hi * 32768 + b] + H2x[(size_t)chunk_id * 32768 + b];
+}
+MI_HD void msm2_scatter2_move(const uint16_t *part_lo, const u32 *part_val, u32 b, u32 e, u32 *lds, u32 *sorted, u32 tid, u32 nthr) {
+    for (u32 k = b + tid; k < e; k += nthr) {
+        u32 pos = MI_LDS_ATOMIC_ADD(&lds[part_lo[k]], 1u);
+        sorted[pos] = part_val[k];
+    }
+}
+
+// ---- pk_load: the window copies pre[w][i] = 2^(c*w) * P_i, affine.  Thread i walks the windows.
+template <class F>
+MI_HD void msm2_precompute_body(const Affine<F> *base, Affine<F> *pre, u32 n, u32 c, u32 nwin, u32 i) {
+    Affine<F> p = base[i];
+    pre[i] = p;
+    XYZZ<F> acc = XYZZ<F>::from_affine(p);
+    for (u32 w = 1; w < nwin; w++) {
+        for (u32 k = 0; k < c; k++) acc = xyzz_dbl(acc);
+        Affine<F> a = xyzz_to_affine(acc);
+        pre[(size_t)w * n + i] = a;
+        acc = XYZZ<F>::from_affine(a);   // keep the chain in affine-normalised form (shorter numbers of squarings are not needed)
+    }
+}

@@ -1,7 +1,7 @@
 // Point kernels of the MSM, templated on the coordinate field; included by msm_g1.hip (F = Fp) and msm_g2.hip (F = Fp2).
 #pragma once
 #include <hip/hip_runtime.h>
-#include "msm_core.cuh"
+#include "msm2_core.cuh"
 #include "msm_curve_ops.h"
 
 // Occupancy target per curve (measured with tools/bench_g2 on MI355X): the G1 mixed add needs ~60 VGPRs and runs
@@ -47,6 +47,15 @@ static void launch_accum_xyzz(hipStream_t st, unsigned grid, const void *pin, co
 template <class F>
 static void launch_bucket_reduce(hipStream_t st, unsigned grid_x, unsigned nwin, const void *bucket, u32 nbuckets, u32 seg, u32 tb, void *out) {
     hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(grid_x, nwin), dim3(64), 0, st, (const XYZZ<F> *)bucket, nbuckets, seg, tb, (XYZZ<F> *)out);
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_msm2_precompute(const Affine<F> *base, Affine<F> *pre, u32 n, u32 c, u32 nwin) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) msm2_precompute_body<F>(base, pre, n, c, nwin, i);
+}
+template <class F>
+static void launch_precompute(hipStream_t st, const void *base, void *pre, u32 n, u32 c, u32 nwin) {
+    hipLaunchKernelGGL(k_msm2_precompute<F>, dim3((n + 63) / 64), dim3(64), 0, st, (const Affine<F> *)base, (Affine<F> *)pre, n, c, nwin);
 }
 template <class F>
 static void host_combine_windows(const void *wsum, u32 nwin, u32 c, void *out) {

@@ -13,6 +13,7 @@ struct MsmCurveOps {
     void (*accum_xyzz)(hipStream_t st, unsigned grid, const void *partial_in, const uint32_t *start, const uint32_t *cnt, const uint32_t *items,
                        const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out);
     void (*bucket_reduce)(hipStream_t st, unsigned grid_x, unsigned nwin, const void *bucket, uint32_t nbuckets, uint32_t seg, uint32_t tb, void *out);
+    void (*precompute)(hipStream_t st, const void *base, void *pre, uint32_t n, uint32_t c, uint32_t nwin);   // fixed-base window copies
     // total = sum_w 2^(c*w) * wsum[w] on the host; nwin == 0 yields the point at infinity
     void (*combine_windows)(const void *host_wsum, uint32_t nwin, uint32_t c, void *out_xyzz);
 };

@@ -146,6 +146,17 @@ int32_t mi_msm_g2(mi_ctx *ctx, const mi_g2_affine *pts, const mi_fr *scalars, si
 int32_t mi_msm_g2_dev(mi_ctx *ctx, const mi_g2_affine *pts_dev, const mi_fr *scalars_dev, size_t n,
                       uint32_t flags, mi_g2_jac *out);
 
+/* ---- fixed-base MSM: when the bases are static (a proving key), store next to every base P_i the window copies
+ * 2^(c*w) * P_i, w < ceil(256/c) (c in 17..22; pre holds ceil(256/c) * n points, [w][i] order).  All windows then share
+ * one set of 2^(c-1) buckets and a 254-bit scalar costs ceil(256/c) = 12 mixed additions at c = 22 instead of 16.  Same
+ * result as mi_msm_g1/g2.  mi_pk_load uses this internally when the copies fit in device memory. ---- */
+int32_t mi_msm_precompute_g1_dev(mi_ctx *ctx, const mi_g1_affine *base_dev, size_t n, uint32_t c, mi_g1_affine *pre_dev);
+int32_t mi_msm_precompute_g2_dev(mi_ctx *ctx, const mi_g2_affine *base_dev, size_t n, uint32_t c, mi_g2_affine *pre_dev);
+int32_t mi_msm_g1_fixed_dev(mi_ctx *ctx, const mi_g1_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c,
+                            uint32_t flags, mi_g1_jac *out);
+int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c,
+                            uint32_t flags, mi_g2_jac *out);
+
 /* ---- the fused prove path: replaces groth16.Prove after the solve (mt.go:496).
  * W: nb_wires wire values; a, b, c: n_constraints values each (solution.A/B/C);
  * r, s: the two blinding scalars gnark samples with fr.SetRandom (passed in so that CPU and
@@ -227,6 +238,7 @@ int32_t mi_bench_valu_dev(mi_ctx *ctx, int kind, size_t n_threads, uint32_t iter
 int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, uint32_t max_strided);
 int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads);
 int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G);
+int32_t mi_debug_set_msm_chunk(mi_ctx *ctx, uint32_t chunk);   /* fixed-base sort: entries per pass-2 chunk */
 /* raw device memory helpers so hosts without a HIP binding (ctypes, cgo) can stage data */
 int32_t mi_dev_alloc(mi_ctx *ctx, size_t bytes, void **out_dev);
 int32_t mi_dev_free(mi_ctx *ctx, void *dev);

@@ -208,3 +208,66 @@ extern "C" int emu_msm_g1(void *out, const void *pts, const void *sc, uint32_t n
 extern "C" int emu_msm_g2(void *out, const void *pts, const void *sc, uint32_t n, int mont, uint32_t c, uint32_t G, uint32_t L, uint32_t seg, uint32_t nthr) {
     return emu_msm_t<Fp2>(out, pts, sc, n, mont, c, G, L, seg, nthr);
 }
+
+// ---------------------------------------------------------------- fixed-base MSM (msm2_core.cuh on the host)
+#include "../../gnark-whir_amd/csrc/msm2_core.cuh"
+extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uint32_t n, int mont, uint32_t c, uint32_t G, uint32_t chunk, uint32_t L,
+                           uint32_t seg, uint32_t nthr) {
+    typedef Fp F;
+    Msm2Shape s = msm2_shape(n, c, G, chunk);
+    // pk_load: window copies
+    std::vector<Affine<F>> pre((size_t)s.nwin * n);
+    for (u32 i = 0; i < n; i++) msm2_precompute_body<F>((const Affine<F> *)pts_v, pre.data(), n, c, s.nwin, i);
+    // pass 1
+    std::vector<u32> C1((size_t)s.ngroups * G), lds(32768);
+    for (u32 g = 0; g < G; g++) {
+        for (u32 h = 0; h < s.ngroups; h++) lds[h] = 0;
+        for (u32 t = 0; t < nthr; t++) msm2_count_body(s, (const Fr *)sc_v, mont != 0, g, lds.data(), t, nthr);
+        for (u32 h = 0; h < s.ngroups; h++) C1[(size_t)h * G + g] = lds[h];
+    }
+    std::vector<u32> S1;
+    excl_scan(C1, S1);
+    u32 T = S1.back();
+    std::vector<uint16_t> part_lo(T + 1);
+    std::vector<u32> part_val(T + 1);
+    for (u32 g = 0; g < G; g++) {
+        for (u32 h = 0; h < s.ngroups; h++) lds[h] = S1[(size_t)h * G + g];
+        for (u32 t = 0; t < nthr; t++) msm2_partition_body(s, (const Fr *)sc_v, mont != 0, g, lds.data(), part_lo.data(), part_val.data(), t, nthr);
+    }
+    std::vector<u32> gstart(s.ngroups + 1), cstart(s.ngroups + 1);
+    msm2_chunk_table_body(s, S1.data(), gstart.data(), cstart.data());
+    u32 nchunks = cstart[s.ngroups];
+    std::vector<u32> H2((size_t)(nchunks + 1) * 32768), total(s.nkeys);
+    for (u32 ch = 0; ch < nchunks + 2; ch++) {   // over-launch like the bounded GPU grid
+        u32 hi, b, e;
+        if (!msm2_chunk_range(s, gstart.data(), cstart.data(), ch, hi, b, e)) continue;
+        for (u32 t = 0; t < nthr; t++) msm2_hist2_zero(lds.data(), t, nthr);
+        for (u32 t = 0; t < nthr; t++) msm2_hist2_count(part_lo.data(), b, e, lds.data(), t, nthr);
+        for (u32 t = 0; t < nthr; t++) msm2_hist2_write(H2.data(), ch, lds.data(), t, nthr);
+    }
+    for (u32 k = 0; k < s.nkeys; k++) msm2_colsum_body(cstart.data(), H2.data(), total.data(), k);
+    std::vector<u32> keystart;
+    excl_scan(total, keystart);
+    std::vector<u32> sorted(T + 1);
+    for (u32 ch = 0; ch < nchunks; ch++) {
+        u32 hi, b, e;
+        msm2_chunk_range(s, gstart.data(), cstart.data(), ch, hi, b, e);
+        for (u32 t = 0; t < nthr; t++) msm2_scatter2_init(keystart.data(), H2.data(), ch, hi, lds.data(), t, nthr);
+        for (u32 t = 0; t < nthr; t++) msm2_scatter2_move(part_lo.data(), part_val.data(), b, e, lds.data(), sorted.data(), t, nthr);
+    }
+    // items / levels over nkeys keys (one window), then bucket reduce with nwin = 1
+    MsmShape ks;
+    ks.c = c; ks.nwin = 1; ks.nbuckets = s.nkeys; ks.nkeys = s.nkeys; ks.nslices = G; ks.n = n;
+    std::vector<u32> start(s.nkeys), cnt(s.nkeys), items(s.nkeys);
+    for (u32 k = 0; k < s.nkeys; k++) msm_prep_level1(ks, keystart.data(), L, start.data(), cnt.data(), items.data(), k);
+    std::vector<XYZZ<F>> bucket(s.nkeys);
+    memset(bucket.data(), 0, sizeof(XYZZ<F>) * s.nkeys);
+    run_levels<F>(s.nkeys, start, cnt, items, L, pre.data(), sorted.data(), std::vector<XYZZ<F>>(), bucket, nthr);
+    u32 tb = (s.nkeys + seg - 1) / seg;
+    std::vector<XYZZ<F>> Pp(tb);
+    for (u32 t = 0; t < tb; t++) msm_bucket_reduce_body<F>(bucket.data(), s.nkeys, seg, Pp.data(), 0, t);
+    XYZZ<F> tot = XYZZ<F>::inf();
+    for (u32 t = 0; t < tb; t++) xyzz_add(tot, Pp[t]);
+    *(Affine<F> *)out_v = xyzz_to_affine(tot);
+    return (int)nchunks;
+}

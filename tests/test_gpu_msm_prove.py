@@ -302,3 +302,48 @@ def test_prove_degenerate_shapes_vs_oracle(ctx, log_n, nb_wires, nb_public, n_co
     want = cref.prove(pk, W, a, b, c, r, s)
     assert B.proof_write(got["raw"]) == cref.proof_write(want["raw"])
     ctx.pk_free(pkh)
+
+
+@pytest.mark.parametrize("n,dist,c,chunk", [(1, 0, 17, 0), (300, 1, 17, 64), (5000, 0, 18, 1000), (70000, 1, 20, 0), (200000, 0, 22, 0)])
+def test_fixed_base_msm_g1_vs_oracle(ctx, n, dist, c, chunk):
+    """fixed-base path: window copies 2^(c*w)*P built on the device, one bucket set, two-pass sort"""
+    assert ctx.lib.mi_debug_set_msm_chunk(ctx.h, chunk) == 0
+    try:
+        pts = cref.gen_g1(n, 1300 + n); sc = cref.gen_scalars(n, 1400 + n, dist)
+        if n > 10:
+            pts[3] = 0; sc[1] = fr_arr([P.R_MOD - 1])[0]; sc[2] = 0; pts[6] = pts[5]; sc[6] = sc[5]
+        dp, ds = ctx.to_dev(pts), ctx.to_dev(sc)
+        pre = ctx.msm_precompute(dp.ptr, n, c)
+        nwin = (256 + c - 1) // c
+        # the copies themselves: pre[w][i] == 2^(c*w) * P_i
+        got = pre.download((nwin * n, 8))
+        i = 0 if n < 10 else 9
+        assert np.array_equal(got[i], pts[i]) and np.array_equal(got[(nwin - 1) * n + i], cref.g1_scalar_mul(pts[i], 1 << (c * (nwin - 1))))
+        assert _jac_eq(ctx.msm_fixed_dev(pre.ptr, ds.ptr, n, c), cref.msm_g1(pts, sc))
+        for d in (dp, ds, pre):
+            d.free()
+    finally:
+        assert ctx.lib.mi_debug_set_msm_chunk(ctx.h, 0) == 0
+
+
+def test_fixed_base_msm_g2_vs_oracle(ctx):
+    n, c = 3000, 19
+    pts = cref.gen_g2(n, 1500); sc = cref.gen_scalars(n, 1501, 1)
+    dp, ds = ctx.to_dev(pts), ctx.to_dev(sc)
+    pre = ctx.msm_precompute(dp.ptr, n, c, g2=True)
+    assert _jac_eq(ctx.msm_fixed_dev(pre.ptr, ds.ptr, n, c, g2=True), cref.msm_g2(pts, sc))
+    for d in (dp, ds, pre):
+        d.free()
+
+
+def test_fixed_base_equals_generic_at_baseline_size(ctx):
+    """2^23 uniform pairs: the fixed-base path (c = 22, 12 digits) and the generic path (c = 16) agree"""
+    n, c = 1 << 23, 22
+    pts = ctx.gen_g1(n, 31); sc = ctx.gen_scalars(n, 32, 0)
+    want = ctx.msm_g1_dev(pts.ptr, sc.ptr, n); t_gen = ctx.stats()["total_ms"]
+    pre = ctx.msm_precompute(pts.ptr, n, c)
+    got = ctx.msm_fixed_dev(pre.ptr, sc.ptr, n, c); got = ctx.msm_fixed_dev(pre.ptr, sc.ptr, n, c); t_fix = ctx.stats()["total_ms"]
+    print(f"generic {t_gen:.2f} ms, fixed-base {t_fix:.2f} ms")
+    assert np.array_equal(got, want)
+    for d in (pts, sc, pre):
+        d.free()
