@@ -124,3 +124,33 @@ def test_compute_h_vs_oracle(ctx, nc):
 def test_compute_h_golden_toy1000(ctx):
     z = np.load(os.path.join(GOLD, "prove_toy1000.npz"))
     assert np.array_equal(ctx.compute_h(int(z["log_n"]), z["a"], z["b"], z["c"]), z["h"])
+
+
+def test_context_lifecycle_and_two_contexts():
+    """init / shutdown repeatedly (handles, streams, pinned buffers are released), two live contexts side by side"""
+    B = load_binding()
+    a = cref.gen_scalars(1 << 10, 5, 0)
+    want = cref.ntt(a, 10, 1)
+    for _ in range(10):
+        c = B.Context(0)
+        assert np.array_equal(c.ntt(a, 10, 1), want)
+        c.close()
+    c1, c2 = B.Context(0), B.Context(0)
+    pts = cref.gen_g1(500, 1); sc = cref.gen_scalars(500, 2, 1)
+    r1, r2 = c1.msm_g1(pts, sc), c2.msm_g1(pts, sc)
+    assert np.array_equal(r1, r2) and np.array_equal(r1, cref.msm_g1(pts, sc))
+    c1.close(); c2.close()
+
+
+def test_invalid_arguments_are_rejected_not_executed(ctx):
+    B = load_binding()
+    with pytest.raises(B.MiError):
+        ctx.ntt(np.zeros((4, 4), np.uint64), 29, 0)            # log_n > 28
+    with pytest.raises(B.MiError):
+        ctx.ntt(np.zeros((4, 4), np.uint64), 2, 8)             # unknown flag bit
+    with pytest.raises(B.MiError):
+        ctx.compute_h(2, np.zeros((5, 4), np.uint64), np.zeros((5, 4), np.uint64), np.zeros((5, 4), np.uint64))   # more constraints than the domain
+    assert ctx.lib.mi_debug_set_msm_plan(ctx.h, 1, 0, 0, 0, 0) != 0 and ctx.lib.mi_debug_set_msm_plan(ctx.h, 17, 0, 0, 0, 0) != 0
+    assert ctx.lib.mi_debug_set_msm_plan(ctx.h, 8, 1, 8, 0, 0) != 0      # items of one entry never converge
+    assert ctx.lib.mi_debug_set_ntt_plan(ctx.h, 13, 9, 7) != 0
+    assert b"" == b"" and ctx.lib.mi_last_error(ctx.h) is not None
