@@ -44,7 +44,7 @@ MI_HD XYZZ<F> xyzz_dbl(const XYZZ<F> &p) {
     F X2 = fe_sqr(p.x);
     F M = fe_dbl(X2) + X2;
     F X3 = fe_sqr(M) - fe_dbl(S);
-    F Y3 = M * (S - X3) - W * p.y;
+    F Y3 = fe_mul_sub(M, S - X3, W, p.y);
     return XYZZ<F>{X3, Y3, V * p.zz, W * p.zzz};
 }
 // doubling of an affine point straight to XYZZ (mdbl-2008-s-1)
@@ -57,7 +57,7 @@ MI_HD XYZZ<F> xyzz_dbl_affine(const F &x, const F &y) {
     F X2 = fe_sqr(x);
     F M = fe_dbl(X2) + X2;
     F X3 = fe_sqr(M) - fe_dbl(S);
-    F Y3 = M * (S - X3) - W * y;
+    F Y3 = fe_mul_sub(M, S - X3, W, y);
     return XYZZ<F>{X3, Y3, V, W};
 }
 // acc += (+/-) q, q affine (madd-2008-s); handles inf / equal / opposite operands
@@ -82,7 +82,7 @@ MI_HD void xyzz_madd(XYZZ<F> &acc, const Affine<F> &q, bool negate) {
     F PPP = Pp * PP;
     F Q = acc.x * PP;
     F X3 = fe_sqr(R) - PPP - fe_dbl(Q);
-    F Y3 = R * (Q - X3) - acc.y * PPP;
+    F Y3 = fe_mul_sub(R, Q - X3, acc.y, PPP);   // two products, one Montgomery reduction (field.cuh)
     acc = XYZZ<F>{X3, Y3, acc.zz * PP, acc.zzz * PPP};
 }
 // acc += q, both XYZZ (add-2008-s)
@@ -105,7 +105,7 @@ MI_HD void xyzz_add(XYZZ<F> &acc, const XYZZ<F> &q) {
     F PPP = Pp * PP;
     F Q = U1 * PP;
     F X3 = fe_sqr(R) - PPP - fe_dbl(Q);
-    F Y3 = R * (Q - X3) - S1 * PPP;
+    F Y3 = fe_mul_sub(R, Q - X3, S1, PPP);
     acc = XYZZ<F>{X3, Y3, acc.zz * q.zz * PP, acc.zzz * q.zzz * PPP};
 }
 template <class F>
