@@ -53,8 +53,8 @@ def cpu_baseline(log_n_sample, log_n_full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=23, help="FFT domain (2^23 = BASELINE configs[1])")
     ap.add_argument("--dist", choices=["whir", "uniform"], default="whir")
     ap.add_argument("--no-cpu-baseline", action="store_true")
