@@ -11,6 +11,7 @@
 #include <cstring>
 #include <vector>
 #include <chrono>
+#include <future>
 
 struct mi_pk {
     u32 log_n = 0, nb_public = 0;
@@ -252,8 +253,12 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     Fr r, s;
     std::memcpy(&r, r_m, 32); std::memcpy(&s, s_m, 32);
     Fr rc = fe_from_mont(r), sc = fe_from_mont(s), krc = fe_from_mont(fe_neg(r * s));
-    G1X r_delta = host_scalar_mul<Fp>(pk->delta1, rc), s_delta = host_scalar_mul<Fp>(pk->delta1, sc), kr_delta = host_scalar_mul<Fp>(pk->delta1, krc);
+    // (independent 256-bit scalar multiplications: one host thread each; for small circuits they are the longest chain)
+    auto f_r = std::async(std::launch::async, [&] { return host_scalar_mul<Fp>(pk->delta1, rc); });
+    auto f_s = std::async(std::launch::async, [&] { return host_scalar_mul<Fp>(pk->delta1, sc); });
+    auto f_kr = std::async(std::launch::async, [&] { return host_scalar_mul<Fp>(pk->delta1, krc); });
     G2X s_delta2 = host_scalar_mul<Fp2>(pk->delta2, sc);
+    G1X r_delta = f_r.get(), s_delta = f_s.get(), kr_delta = f_kr.get();
     // step 7: collect the five MSMs
     G1X msm_a, msm_b1, msm_k, msm_z;
     G2X msm_b2;
@@ -267,7 +272,9 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     xyzz_madd(bs1, pk->beta1, false);
     xyzz_add(bs1, s_delta);
     G1Aff ar_aff = xyzz_to_affine(ar), bs1_aff = xyzz_to_affine(bs1);
-    G1X s_ar = host_scalar_mul<Fp>(ar_aff, sc), r_bs1 = host_scalar_mul<Fp>(bs1_aff, rc);   // overlaps the remaining MSMs
+    auto f_sar = std::async(std::launch::async, [&] { return host_scalar_mul<Fp>(ar_aff, sc); });   // overlaps the remaining MSMs
+    G1X r_bs1 = host_scalar_mul<Fp>(bs1_aff, rc);
+    G1X s_ar = f_sar.get();
     MI_TRY(mi_msm_finish(ctx, 3, 1, &msm_k));
     MI_TRY(mi_msm_finish(ctx, 2, 2, &msm_b2));
     MI_TRY(mi_msm_finish(ctx, 4, 1, &msm_z));
