@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--dist", choices=["whir", "uniform"], default="whir")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank control-flow rehearsal on a 1-GPU box: every rank uses device 0 and the collectives run over gloo")
     args = ap.parse_args()
 
     import torch
@@ -67,11 +69,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     B = _binding()
     ctx = B.Context(local_rank)
@@ -124,7 +131,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if args.rehearse_on_one_gpu else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
