@@ -23,7 +23,7 @@ import (
 	"github.com/consensys/gnark/frontend/cs/r1cs"
 )
 
-// cubic: x^3 + x + 5 == y, plus a range check so that the circuit commits (BSB22) like the WHIR verifier does.
+// cubic: x^3 + x + 5 == y (no commitment; a circuit with api.Commit would exercise the Pedersen path of prove.go too).
 type cubic struct {
 	X frontend.Variable
 	Y frontend.Variable `gnark:",public"`
