@@ -24,6 +24,8 @@ EXPORTS = [
     "mi_msm_precompute_g1_dev", "mi_msm_precompute_g2_dev", "mi_msm_g1_fixed_dev", "mi_msm_g2_fixed_dev",
     "mi_batch_scalar_mul_g1", "mi_batch_scalar_mul_g1_dev", "mi_batch_scalar_mul_g2", "mi_batch_scalar_mul_g2_dev",
     "mi_pedersen_pk_load", "mi_pedersen_pk_free", "mi_pedersen_commit", "mi_pedersen_prove_knowledge", "mi_pedersen_fold",
+    "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
+    "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait",
 ]
 
 
@@ -63,6 +65,9 @@ def load():
         _LIB = C.CDLL(LIB_PATH)
         _LIB.mi_last_error.restype = C.c_char_p
         _LIB.mi_proof_write.restype = C.c_size_t
+        _LIB.mi_prover_last_error.restype = C.c_char_p
+        _LIB.mi_prover_ctx.restype = C.c_void_p
+        _LIB.mi_prover_in_flight.restype = C.c_uint32
     return _LIB
 
 
@@ -106,8 +111,12 @@ class DevArray:
 
 
 class Context:
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, _borrowed=None):
         self.lib = load()
+        self.owned = _borrowed is None
+        if _borrowed is not None:      # a context owned by a Prover pool (mi_prover_ctx)
+            self.h = C.c_void_p(_borrowed)
+            return
         h = C.c_void_p()
         rc = self.lib.mi_init(C.c_int(device_id), C.byref(h))
         if rc != 0:
@@ -119,9 +128,9 @@ class Context:
             raise MiError(f"rc={rc}: {self.lib.mi_last_error(self.h).decode()}")
 
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             self.lib.mi_shutdown(self.h)
-            self.h = None
+        self.h = None
 
     def set_stream(self, stream_ptr):
         self._ck(self.lib.mi_set_stream(self.h, C.c_void_p(int(stream_ptr))))
@@ -296,6 +305,57 @@ class Context:
 
 
 # ---- host-only helpers (no ctx)
+class Prover:
+    """Several proofs in flight on one device (mi_prover_*, include/mi355x_groth16.h).  Mirrors a prover service that
+    calls groth16.Prove (reference mt.go:496) from many goroutines: submit() returns a ticket, wait() the proof."""
+
+    def __init__(self, device_id=0, in_flight=2):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.mi_prover_create(C.c_int(device_id), C.c_uint32(in_flight), C.byref(h))
+        if rc != 0:
+            raise MiError(f"mi_prover_create failed: {rc} (no gfx950 device? the product has no CPU path)")
+        self.h = h
+        self.in_flight = int(self.lib.mi_prover_in_flight(h))
+        self._pending = {}
+
+    def ctx(self, i=0) -> "Context":
+        """context i of the pool, for mi_pk_load / device buffers (never prove on it directly)"""
+        p = self.lib.mi_prover_ctx(self.h, C.c_uint32(i))
+        if not p:
+            raise MiError("mi_prover_ctx: index out of range")
+        return Context(_borrowed=p)
+
+    def submit(self, pkh, W, a, b, c, r, s, device=False, n_wires=None, n_constraints=None) -> int:
+        out = np.zeros(32, np.uint64); st = Stats(); t = C.c_uint64()
+        r, s = _u64(r), _u64(s)
+        if device:
+            keep = ()
+            rc = self.lib.mi_prover_submit_dev(self.h, pkh, _p(W), C.c_size_t(n_wires), _p(a), _p(b), _p(c), C.c_size_t(n_constraints),
+                                               _p(r), _p(s), _p(out), C.byref(st), C.byref(t))
+        else:
+            W, a, b, c = _u64(W), _u64(a), _u64(b), _u64(c)
+            keep = (W, a, b, c)
+            rc = self.lib.mi_prover_submit(self.h, pkh, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c), C.c_size_t(a.shape[0]),
+                                           _p(r), _p(s), _p(out), C.byref(st), C.byref(t))
+        if rc != 0:
+            raise MiError(f"mi_prover_submit: rc={rc}")
+        self._pending[t.value] = (out, st, keep)   # the library writes into these until wait() returns
+        return t.value
+
+    def wait(self, ticket):
+        out, st, _ = self._pending.pop(ticket)
+        rc = self.lib.mi_prover_wait(self.h, C.c_uint64(ticket))
+        if rc != 0:
+            raise MiError(f"rc={rc}: {self.lib.mi_prover_last_error(self.h).decode()}")
+        return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
+
+    def close(self):
+        if self.h:
+            self.lib.mi_prover_destroy(self.h)
+            self.h = None
+
+
 def proof_write(raw, commitments=None, pok=None):
     n = 0 if commitments is None else commitments.shape[0]
     buf = np.zeros(164 + 32 * n, np.uint8)

@@ -149,7 +149,7 @@ int32_t mi_msm_g2_dev(mi_ctx *ctx, const mi_g2_affine *pts_dev, const mi_fr *sca
 /* ---- fixed-base MSM: when the bases are static (a proving key), store next to every base P_i the window copies
  * 2^(c*w) * P_i, w < ceil(256/c) (c in 17..22; pre holds ceil(256/c) * n points, [w][i] order).  All windows then share
  * one set of 2^(c-1) buckets and a 254-bit scalar costs ceil(256/c) = 12 mixed additions at c = 22 instead of 16.  Same
- * result as mi_msm_g1/g2.  mi_pk_load uses this internally when the copies fit in device memory. ---- */
+ * result as mi_msm_g1/g2.  Offered as an API; the prove path does not use it (measured: no net gain). ---- */
 int32_t mi_msm_precompute_g1_dev(mi_ctx *ctx, const mi_g1_affine *base_dev, size_t n, uint32_t c, mi_g1_affine *pre_dev);
 int32_t mi_msm_precompute_g2_dev(mi_ctx *ctx, const mi_g2_affine *base_dev, size_t n, uint32_t c, mi_g2_affine *pre_dev);
 int32_t mi_msm_g1_fixed_dev(mi_ctx *ctx, const mi_g1_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c,
@@ -171,6 +171,30 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, size_t 
                              mi_proof_out *out, mi_stats *stats);
 /* Stats of the last mi_msm_* / mi_ntt* / mi_compute_h* / prove call on ctx. */
 int32_t mi_get_stats(mi_ctx *ctx, mi_stats *out);
+
+/* ---- prover pool: several proofs in flight on one device.
+ * The reference proves one circuit per groth16.Prove call (mt.go:496) and a prover service issues those calls from many
+ * goroutines; gnark's CPU prover then shares the cores between them.  The drop-in equivalent: `in_flight` contexts on one
+ * GPU, each with its own streams, workspaces and host worker thread, fed from one queue, so that the GPU fills the
+ * serial head and tail of one proof (first NTT passes, last MSM's reduce, host assembly) with the bulk of another.
+ * The proving key is read-only during prove: load it once with mi_pk_load[_dev] on mi_prover_ctx(p, 0) and share it.
+ * submit returns at once with a ticket; W/a/b/c (host or device memory as the variant says), out and stats must stay
+ * valid until mi_prover_wait(ticket) returns the job's status (r and s are copied).  Each ticket is waited on exactly
+ * once, from any thread.  Proofs are bit-identical to mi_groth16_prove[_dev] on the same inputs.
+ * mi_prover_destroy runs the jobs still queued, then frees every context. ---- */
+typedef struct mi_prover mi_prover;
+int32_t mi_prover_create(int device_id, uint32_t in_flight /* 1..16 */, mi_prover **out);
+int32_t mi_prover_destroy(mi_prover *p);
+uint32_t mi_prover_in_flight(const mi_prover *p);
+mi_ctx *mi_prover_ctx(mi_prover *p, uint32_t i);        /* i < in_flight; NULL otherwise.  Prove on it yourself only while the pool is idle */
+const char *mi_prover_last_error(mi_prover *p);         /* message of the last job whose mi_prover_wait returned != MI_OK */
+int32_t mi_prover_submit(mi_prover *p, mi_pk *pk, const mi_fr *W, size_t n_wires,
+                         const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
+                         const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket);
+int32_t mi_prover_submit_dev(mi_prover *p, mi_pk *pk, const mi_fr *W_dev, size_t n_wires,
+                             const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev, size_t n_constraints,
+                             const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket);
+int32_t mi_prover_wait(mi_prover *p, uint64_t ticket);
 
 /* ---- Proof.WriteTo / point encoding (row a12), pure host code ---- */
 void mi_g1_compress(const mi_g1_affine *p, uint8_t out[32]);

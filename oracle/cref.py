@@ -39,6 +39,9 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
+        # libgomp sizes its spin-waits by the visible cores, not by a container's CPU quota: under a quota the spinning threads
+        # burn it and every barrier then costs a scheduler period (seen: 13 s for a 2^12 prove).  Yield instead.
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _LIB = C.CDLL(build())
         _LIB.ref_proof_write.restype = C.c_size_t
     return _LIB
