@@ -42,11 +42,17 @@ import (
 type ProvingKey struct {
 	groth16_bn254.ProvingKey
 	once sync.Once
-	ctx  *C.mi_ctx
-	dev  *C.mi_pk
+	ctx  *C.mi_ctx    // key load + the mid-solve Pedersen commitments (guarded by mu: a context is single-threaded)
+	mu   sync.Mutex
+	pool *C.mi_prover // InFlight contexts on the same GPU: concurrent Prove calls overlap on the device
+	dev  *C.mi_pk     // device-resident key, read-only during prove, shared by every context
 	ped  []*C.mi_pedersen_pk
 	err  error
 }
+
+// InFlight is the number of proofs the device keeps in flight per key (mi_prover_create).  Goroutines calling Prove
+// beyond that queue up in the library.  3 fills an MI355X at the WHIR-verifier size (DESIGN.md section 5).
+var InFlight = 3
 
 func status(ctx *C.mi_ctx, rc C.int32_t) error {
 	if rc == C.MI_OK {
@@ -60,6 +66,10 @@ func (pk *ProvingKey) setup(r1cs *cs.R1CS, device int) error {
 	pk.once.Do(func() {
 		if rc := C.mi_init(C.int(device), &pk.ctx); rc != C.MI_OK {
 			pk.err = fmt.Errorf("mi355x: mi_init rc=%d (no gfx950 device?)", int(rc))
+			return
+		}
+		if rc := C.mi_prover_create(C.int(device), C.uint32_t(InFlight), &pk.pool); rc != C.MI_OK {
+			pk.err = fmt.Errorf("mi355x: mi_prover_create rc=%d", int(rc))
 			return
 		}
 		var d C.mi_pk_desc
@@ -117,6 +127,8 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 		}
 		privateCommittedValues[i] = vals
 		// device-resident Pedersen key (mi_pedersen_pk_load once per key, see pedersenKey below)
+		pk.mu.Lock()
+		defer pk.mu.Unlock()
 		ppk, err := pk.pedersenKey(i)
 		if err != nil {
 			return err
@@ -157,15 +169,26 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 		return nil, err
 	}
 
-	var out C.mi_proof_out
-	rc := C.mi_groth16_prove(pk.ctx, pk.dev,
+	// submit + wait on the pool: this goroutine blocks in cgo (the Go scheduler parks it on its own OS thread) while the
+	// proofs of other goroutines overlap with it on the GPU.  The output lives in C memory: the library writes it from a
+	// worker thread after this cgo call has returned, which Go memory passed by pointer must not be used for.
+	out := (*C.mi_proof_out)(C.malloc(C.size_t(unsafe.Sizeof(C.mi_proof_out{}))))
+	defer C.free(unsafe.Pointer(out))
+	var pin runtime.Pinner // W, a, b, c are read by the worker thread until mi_prover_wait returns
+	pin.Pin(&W[0]); pin.Pin(&a[0]); pin.Pin(&b[0]); pin.Pin(&c[0])
+	defer pin.Unpin()
+	var ticket C.uint64_t
+	rc := C.mi_prover_submit(pk.pool, pk.dev,
 		(*C.mi_fr)(unsafe.Pointer(&W[0])), C.size_t(len(W)),
 		(*C.mi_fr)(unsafe.Pointer(&a[0])), (*C.mi_fr)(unsafe.Pointer(&b[0])), (*C.mi_fr)(unsafe.Pointer(&c[0])), C.size_t(len(a)),
-		(*C.mi_fr)(unsafe.Pointer(&r)), (*C.mi_fr)(unsafe.Pointer(&s)), &out, nil)
-	runtime.KeepAlive(W)
-	if err := status(pk.ctx, rc); err != nil {
-		return nil, err
+		(*C.mi_fr)(unsafe.Pointer(&r)), (*C.mi_fr)(unsafe.Pointer(&s)), out, nil, &ticket)
+	if rc != C.MI_OK {
+		return nil, fmt.Errorf("mi355x: mi_prover_submit rc=%d", int(rc))
 	}
+	if rc := C.mi_prover_wait(pk.pool, ticket); rc != C.MI_OK {
+		return nil, fmt.Errorf("mi355x: rc=%d: %s", int(rc), C.GoString(C.mi_prover_last_error(pk.pool)))
+	}
+	runtime.KeepAlive(W)
 	proof.Ar = *(*bn254.G1Affine)(unsafe.Pointer(&out.ar))
 	proof.Bs = *(*bn254.G2Affine)(unsafe.Pointer(&out.bs))
 	proof.Krs = *(*bn254.G1Affine)(unsafe.Pointer(&out.krs))

@@ -13,6 +13,7 @@
 // Errors surface as groth16::Error (gnark returns `error`); nothing is swallowed.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -85,6 +86,47 @@ inline Proof Prove(const Context &ctx, const ProvingKey &pk, const Solution &s, 
     p.Ar = out.ar; p.Bs = out.bs; p.Krs = out.krs;
     return p;
 }
+
+// Several groth16.Prove calls in flight on one GPU (what goroutines calling Prove concurrently get from gnark's CPU
+// prover): Submit queues a proof and returns a handle, Wait blocks for it.  One device-resident key serves every context.
+class Prover {
+  public:
+    class Pending {
+      public:
+        Proof Wait() {   // once
+            int32_t rc = mi_prover_wait(p_, ticket_);
+            if (rc != MI_OK) throw Error(rc, mi_prover_last_error(p_));
+            Proof pr;
+            pr.Ar = out_->ar; pr.Bs = out_->bs; pr.Krs = out_->krs;
+            return pr;
+        }
+      private:
+        friend class Prover;
+        mi_prover *p_ = nullptr;
+        uint64_t ticket_ = 0;
+        std::unique_ptr<mi_proof_out> out_;   // written by a worker thread until Wait returns
+    };
+    explicit Prover(int device = 0, uint32_t inFlight = 3) {
+        int32_t rc = mi_prover_create(device, inFlight, &p_);
+        if (rc != MI_OK) throw Error(rc, "mi_prover_create failed (no gfx950 device? there is no CPU path)");
+    }
+    ~Prover() { if (p_) mi_prover_destroy(p_); }
+    Prover(const Prover &) = delete;
+    Prover &operator=(const Prover &) = delete;
+    mi_ctx *ctx(uint32_t i = 0) const { return mi_prover_ctx(p_, i); }   // for mi_pk_load
+    // the solution vectors must stay alive until Wait returns
+    Pending Submit(mi_pk *pk, const Solution &s, const mi_fr &r, const mi_fr &sBlind) {
+        Pending h;
+        h.p_ = p_;
+        h.out_.reset(new mi_proof_out{});
+        int32_t rc = mi_prover_submit(p_, pk, s.W, s.nWires, s.A, s.B, s.C, s.nConstraints, &r, &sBlind, h.out_.get(), nullptr, &h.ticket_);
+        if (rc != MI_OK) throw Error(rc, "mi_prover_submit failed");
+        return h;
+    }
+
+  private:
+    mi_prover *p_ = nullptr;
+};
 
 // ecc/bn254 MultiExp
 inline mi_g1_jac MultiExpG1(const Context &ctx, const std::vector<mi_g1_affine> &points, const std::vector<mi_fr> &scalars) {

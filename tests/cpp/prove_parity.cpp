@@ -65,6 +65,21 @@ int main() {
         try { groth16::Solution bad{W.data(), nWires - 1, a.data(), b.data(), c.data(), nConstraints}; groth16::Prove(ctx, pk, bad, rs[0], rs[1]); }
         catch (const groth16::Error &) { threw = true; }
         if (!threw) { std::puts("MISMATCH: size check"); return 1; }
+        // four proofs in flight on a pool of two contexts sharing the same key: same bytes, job for job
+        {
+            groth16::Prover pool(0, 2);
+            std::vector<groth16::Prover::Pending> pending;
+            for (int k = 0; k < 4; k++) pending.push_back(pool.Submit(pk.get(), sol, rs[0], rs[1]));
+            for (auto &h : pending) {
+                std::vector<uint8_t> pb;
+                h.Wait().WriteTo(pb);
+                if (pb != wb) { std::puts("MISMATCH: pool proof bytes differ"); return 1; }
+            }
+            threw = false;
+            try { groth16::Solution bad{W.data(), nWires - 1, a.data(), b.data(), c.data(), nConstraints}; pool.Submit(pk.get(), bad, rs[0], rs[1]).Wait(); }
+            catch (const groth16::Error &) { threw = true; }
+            if (!threw) { std::puts("MISMATCH: pool size check"); return 1; }
+        }
         std::printf("OK %zu proof bytes identical\n", got.size());
         return 0;
     } catch (const groth16::Error &e) {
