@@ -59,8 +59,9 @@ def main():
     ap.add_argument("--dist", choices=["whir", "uniform"], default="whir")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
-    ap.add_argument("--in-flight", type=int, default=3,
-                    help="proofs kept in flight per GPU by the prover pool (mi_prover_*); 1 = strictly one proof at a time")
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="proofs kept in flight per GPU by the prover pool (mi_prover_*); 1 = strictly one proof at a time; "
+                         "0 = 3 up to N=2^24, 1 above (a context's workspaces take about 1.2 KB x N of HBM)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank control-flow rehearsal on a 1-GPU box: every rank uses device 0 and the collectives run over gloo")
     args = ap.parse_args()
@@ -84,7 +85,7 @@ def main():
 
     B = _binding()
     # the prover pool: --in-flight contexts on this rank's GPU (own streams, workspaces, host worker thread), one shared key
-    pool = B.Prover(local_rank, args.in_flight)
+    pool = B.Prover(local_rank, args.in_flight if args.in_flight > 0 else (3 if args.log_n <= 24 else 1))
     ctx = pool.ctx(0)
 
     # ---- synthetic workload, generated on the device: seed "WHIR" + config index
@@ -105,7 +106,10 @@ def main():
           "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk), "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb),
           "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0], "delta2": small2[1],
           "infinity_a": inf_a, "infinity_b": inf_b}
-    pkh = ctx.pk_load(pk, device_points=True)
+    ctx.sync()
+    t_load = time.perf_counter()
+    pkh = ctx.pk_load(pk, device_points=True)   # includes building the fixed-base window tables (once per key)
+    t_load = time.perf_counter() - t_load
     W = ctx.gen_scalars(nb_wires, seed + 8, dist_id)
     a = ctx.gen_scalars(n_constraints, seed + 9, dist_id); b = ctx.gen_scalars(n_constraints, seed + 10, 0)
     c = ctx.alloc(32 * n_constraints)
@@ -186,6 +190,8 @@ def main():
             # latency of ONE proof with nothing else on the GPU (untimed region, context 0); value above is throughput with
             # proofs_in_flight_per_gpu proofs overlapping, every one of the K steps submitted and completed inside the timed region
             "single_proof_latency_ms": serial_ms,
+            "pk_load_s": t_load,
+            "hbm_in_use_gb": (lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info()),
             # second half of BASELINE's metric: one G1 MSM of 2^23 uniform pairs alone on the GPU (standard MSM benchmark shape);
             # inside a proof the five MSMs overlap on five streams, so per-MSM spans there are not rates
             "g1_msm_pts_per_s": solo["msm_pts_per_s"], "g1_pairs_per_proof": g1_pairs_per_proof,

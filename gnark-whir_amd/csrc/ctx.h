@@ -36,6 +36,7 @@ struct mi_ctx {
     DevBuf ws[24];
     MsmSlot msm[MI_MSM_SLOTS];          // MSM / prove workspaces, see msm.hip / prove.hip
     int cu_count = 256;
+    uint32_t fixed_knob[3] = {0, 0, 0};  // prove's fixed-base tables for A+K / B / Z: 0 = automatic, 1 = never, 17..22 = forced (prove.hip)
 };
 
 #define MI_CHECK_HIP(ctx, call)                                                                       \

@@ -493,6 +493,12 @@ int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2,
     k->c = c; k->L1 = L1; k->L2 = L2; k->seg = seg; k->G = G;
     return MI_OK;
 }
+int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, uint32_t c_z) {
+    if (!ctx) return MI_EINVAL;
+    for (uint32_t c : {c_ak, c_b, c_z}) if (c > 1 && (c < 17 || c > 22)) return MI_EINVAL;
+    ctx->fixed_knob[0] = c_ak; ctx->fixed_knob[1] = c_b; ctx->fixed_knob[2] = c_z;
+    return MI_OK;
+}
 int32_t mi_msm_g1(mi_ctx *ctx, const mi_g1_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags, mi_g1_jac *out) {
     return msm_host_entry<Fp>(ctx, 1, pts, scalars, n, flags, out);
 }

@@ -149,7 +149,7 @@ int32_t mi_msm_g2_dev(mi_ctx *ctx, const mi_g2_affine *pts_dev, const mi_fr *sca
 /* ---- fixed-base MSM: when the bases are static (a proving key), store next to every base P_i the window copies
  * 2^(c*w) * P_i, w < ceil(256/c) (c in 17..22; pre holds ceil(256/c) * n points, [w][i] order).  All windows then share
  * one set of 2^(c-1) buckets and a 254-bit scalar costs ceil(256/c) = 12 mixed additions at c = 22 instead of 16.  Same
- * result as mi_msm_g1/g2.  Offered as an API; the prove path does not use it (measured: no net gain). ---- */
+ * result as mi_msm_g1/g2.  mi_pk_load builds such tables for the prove path's large MSMs when they fit. ---- */
 int32_t mi_msm_precompute_g1_dev(mi_ctx *ctx, const mi_g1_affine *base_dev, size_t n, uint32_t c, mi_g1_affine *pre_dev);
 int32_t mi_msm_precompute_g2_dev(mi_ctx *ctx, const mi_g2_affine *base_dev, size_t n, uint32_t c, mi_g2_affine *pre_dev);
 int32_t mi_msm_g1_fixed_dev(mi_ctx *ctx, const mi_g1_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c,
@@ -263,6 +263,10 @@ int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, 
 int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads);
 int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G);
 int32_t mi_debug_set_msm_chunk(mi_ctx *ctx, uint32_t chunk);   /* fixed-base sort: entries per pass-2 chunk */
+/* window widths of the fixed-base tables the NEXT mi_pk_load[_dev] on ctx builds for the MSM groups A+K, B1+B2, Z:
+ * 0 = automatic (tables when the MSM has >= 2^20 points and they fit in a third of the free device memory),
+ * 1 = never, 17..22 = that width whatever the size */
+int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, uint32_t c_z);
 /* raw device memory helpers so hosts without a HIP binding (ctypes, cgo) can stage data */
 int32_t mi_dev_alloc(mi_ctx *ctx, size_t bytes, void **out_dev);
 int32_t mi_dev_free(mi_ctx *ctx, void *dev);

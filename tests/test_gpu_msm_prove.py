@@ -161,6 +161,31 @@ def test_prove_synthetic_vs_oracle(ctx, log_n, n_committed):
     ctx.pk_free(pkh)
 
 
+@pytest.mark.parametrize("knob", [(17, 17, 17), (19, 18, 20), (1, 17, 1), (22, 1, 1), (1, 1, 1)])
+def test_prove_with_fixed_base_tables_vs_oracle(ctx, knob):
+    """mi_pk_load builds fixed-base window tables for the large MSM groups (A+K, B1+B2, Z); forced here at a size the
+    oracle finishes in seconds, in every mix of table / generic groups: proof bytes == oracle proof bytes"""
+    B = load_binding()
+    log_n = 12
+    n = 1 << log_n
+    nb_wires, nb_public, n_constraints = n - 13, 41, n - 5
+    pk = synthetic_pk(log_n, nb_wires, nb_public, 7700, n_committed=9)
+    W = cref.gen_scalars(nb_wires, 1, 1)
+    a = cref.gen_scalars(n_constraints, 2, 1); b = cref.gen_scalars(n_constraints, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0
+    try:
+        pkh = ctx.pk_load(pk)
+    finally:
+        assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
+    got, _ = ctx.prove(pkh, W, a, b, c, r, s)
+    assert B.proof_write(got["raw"]) == want
+    # device-resident key arrays owned by the caller (mi_pk_load_dev) stay untouched and usable next to the tables
+    ctx.pk_free(pkh)
+    assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 16, 0, 0) != 0 and ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 23, 0) != 0
+
+
 def test_prove_rejects_mismatched_inputs(ctx):
     z, pk = _load_toy()
     bad = dict(pk); bad["g1_a"] = pk["g1_a"][:-1]
