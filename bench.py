@@ -34,6 +34,7 @@ def cpu_baseline(log_n_sample, log_n_full):
     sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import cref
+    cref.WAIT_POLICY = None   # keep libgomp's default (spinning) waits for the timed sample: the CPU side at its best
     from helpers import synthetic_pk
     n = 1 << log_n_sample
     nb_wires, nb_public, n_constraints = n - 1000, 4097, n - 100
@@ -41,12 +42,15 @@ def cpu_baseline(log_n_sample, log_n_full):
     W = cref.gen_scalars(nb_wires, 1, 1)
     a = cref.gen_scalars(n_constraints, 2, 1); b = cref.gen_scalars(n_constraints, 3, 0); c = cref.field_op(0, 2, a, b)
     r, s = cref.gen_scalars(2, 4, 0)
-    t0 = time.perf_counter()
-    cref.prove(pk, W, a, b, c, r, s)
-    dt = time.perf_counter() - t0
+    dt = None
+    for _ in range(3):   # best of three (the first call also spins up the OpenMP team)
+        t0 = time.perf_counter()
+        cref.prove(pk, W, a, b, c, r, s)
+        d1 = time.perf_counter() - t0
+        dt = d1 if dt is None else min(dt, d1)
     scale = float(1 << (log_n_full - log_n_sample))
     return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": cref.num_threads(), "kind": "port",
-            "sample": f"one full prove of the same synthetic shape at N=2^{log_n_sample} ({dt:.2f} s on {cref.num_threads()} threads), "
+            "sample": f"one full prove of the same synthetic shape at N=2^{log_n_sample} (best of 3: {dt:.2f} s on {cref.num_threads()} threads), "
                       f"scaled x{int(scale)} linearly in N to N=2^{log_n_full}"}
 
 

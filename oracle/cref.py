@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+WAIT_POLICY = "passive"   # OMP_WAIT_POLICY default for the oracle's OpenMP runtime (None = leave libgomp's own default); see lib()
 
 
 class PkDesc(C.Structure):
@@ -41,7 +42,9 @@ def lib():
     if _LIB is None:
         # libgomp sizes its spin-waits by the visible cores, not by a container's CPU quota: under a quota the spinning threads
         # burn it and every barrier then costs a scheduler period (seen: 13 s for a 2^12 prove).  Yield instead.
-        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        # bench.py's cpu_baseline leg sets WAIT_POLICY = None: the timed CPU sample keeps libgomp's default (spinning) waits.
+        if WAIT_POLICY:
+            os.environ.setdefault("OMP_WAIT_POLICY", WAIT_POLICY)
         _LIB = C.CDLL(build())
         _LIB.ref_proof_write.restype = C.c_size_t
     return _LIB

@@ -27,3 +27,16 @@ for rep in range(3):
     t = time.perf_counter(); ctx.prove(pkh, Wd.ptr, ad.ptr, bd.ptr, cd.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints); print(f"device-pointer prove: {(time.perf_counter() - t) * 1e3:.1f} ms", flush=True)
 assert np.array_equal(p_host["raw"], p_dev["raw"])
 print("host-path proof == device-path proof")
+# the same through the prover pool, host buffers, D proofs in flight
+for D in (2, 3):
+    pool = B.Prover(0, D)
+    for i in range(D):
+        pool.ctx(i).prove(pkh, W, a, b, c, rs[0], rs[1])
+    K = 12
+    t = time.perf_counter()
+    tk = [pool.submit(pkh, W, a, b, c, rs[0], rs[1]) for _ in range(K)]
+    res = [pool.wait(x) for x in tk]
+    dt = time.perf_counter() - t
+    assert all(np.array_equal(r[0]["raw"], p_dev["raw"]) for r in res)
+    print(f"pool, host buffers, {D} in flight: {dt / K * 1e3:.1f} ms per proof = {K / dt:.2f} proofs/s", flush=True)
+    pool.close()
