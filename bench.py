@@ -67,6 +67,8 @@ def main():
                     help="proofs kept in flight per GPU by the prover pool (mi_prover_*); 1 = strictly one proof at a time; "
                          "0 = 3 up to N=2^24, 1 above (a context's workspaces take about 1.2 KB x N of HBM)")
     ap.add_argument("--msm-plan", default="", help="tuning: c,L1,L2,seg,G for mi_debug_set_msm_plan on every context (0 = automatic)")
+    ap.add_argument("--msm-group-bits", type=int, default=0, help="tuning: mi_debug_set_msm_group_bits on every context")
+    ap.add_argument("--msm-chunk", type=int, default=0, help="tuning: mi_debug_set_msm_chunk on every context")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank control-flow rehearsal on a 1-GPU box: every rank uses device 0 and the collectives run over gloo")
     args = ap.parse_args()
@@ -92,6 +94,9 @@ def main():
     # the prover pool: --in-flight contexts on this rank's GPU (own streams, workspaces, host worker thread), one shared key
     pool = B.Prover(local_rank, args.in_flight if args.in_flight > 0 else (3 if args.log_n <= 24 else 1))
     ctx = pool.ctx(0)
+    for i in range(pool.in_flight):
+        assert pool.lib.mi_debug_set_msm_group_bits(pool.ctx(i).h, args.msm_group_bits) == 0
+        assert pool.lib.mi_debug_set_msm_chunk(pool.ctx(i).h, args.msm_chunk) == 0
     if args.msm_plan:
         plan = [int(x) for x in args.msm_plan.split(",")]
         for i in range(pool.in_flight):

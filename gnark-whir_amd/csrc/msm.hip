@@ -22,6 +22,7 @@
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
     u32 chunk = 0;                              // fixed-base sort: entries per pass-2 chunk (tests shrink it)
+    u32 gbits = 0;                              // fixed-base sort: log2 buckets per pass-1 group (0 = automatic)
 };
 static MsmKnobs *knobs_of(mi_ctx *ctx) { return reinterpret_cast<MsmKnobs *>(ctx->msm_knobs); }
 __global__ void k_msm_hist(MsmShape s, const int16_t *digits, u32 *H);
@@ -70,43 +71,62 @@ __global__ void k_msm_prep_windows(u32 nwin, u32 tb, u32 L, u32 *start, u32 *cnt
     if (w < nwin) { start[w] = w * tb; cnt[w] = tb; items[w] = (tb + L - 1) / L; }
 }
 // ---------------------------------------------------------------- fixed-base MSM: two-pass bucket sort (msm2_core.cuh)
+static constexpr u32 MSM2_MAX_GROUPS = 4096;   // 2^(c-1-gbits) <= 2^(21-9)
 __global__ void __launch_bounds__(256) k_msm2_count(Msm2Shape s, const Fr *scalars, int montgomery, u32 *C1) {
-    __shared__ u32 lds[64];
-    if (threadIdx.x < 64) lds[threadIdx.x] = 0;
+    __shared__ u32 lds[MSM2_MAX_GROUPS];
+    for (u32 g = threadIdx.x; g < s.ngroups; g += blockDim.x) lds[g] = 0;
     __syncthreads();
     msm2_count_body(s, scalars, montgomery != 0, blockIdx.x, lds, threadIdx.x, blockDim.x);
     __syncthreads();
-    if (threadIdx.x < s.ngroups) C1[(size_t)threadIdx.x * s.nslices + blockIdx.x] = lds[threadIdx.x];
+    for (u32 g = threadIdx.x; g < s.ngroups; g += blockDim.x) C1[(size_t)g * s.nslices + blockIdx.x] = lds[g];
 }
-__global__ void __launch_bounds__(256) k_msm2_partition(Msm2Shape s, const Fr *scalars, int montgomery, const u32 *S1, uint16_t *part_lo, u32 *part_val) {
-    __shared__ u32 lds[64];
-    if (threadIdx.x < s.ngroups) lds[threadIdx.x] = S1[(size_t)threadIdx.x * s.nslices + blockIdx.x];
+__device__ u32 block_exclusive_scan_256(u32 v, u32 *lds, u32 *total);
+__global__ void __launch_bounds__(256) k_msm2_partition(Msm2Shape s, const Fr *scalars, int montgomery, const u32 *S1, u32 cap, uint16_t *part_lo, u32 *part_val) {
+    extern __shared__ u32 lds_u32[];
+    u32 *hist = lds_u32, *loff = hist + s.ngroups, *gbase = loff + s.ngroups + 1, *tmp = gbase + s.ngroups, *stage_val = tmp + 256;
+    uint16_t *stage_lo = (uint16_t *)(stage_val + cap);
+    for (u32 g = threadIdx.x; g < s.ngroups; g += blockDim.x) hist[g] = 0;
     __syncthreads();
-    msm2_partition_body(s, scalars, montgomery != 0, blockIdx.x, lds, part_lo, part_val, threadIdx.x, blockDim.x);
+    msm2_count_body(s, scalars, montgomery != 0, blockIdx.x, hist, threadIdx.x, blockDim.x);
+    __syncthreads();
+    u32 carry = 0;
+    for (u32 base = 0; base < s.ngroups; base += 256) {   // loff = exclusive scan of hist; hist becomes the cursor
+        u32 i = base + threadIdx.x;
+        u32 v = i < s.ngroups ? hist[i] : 0, total;
+        u32 ex = block_exclusive_scan_256(v, tmp, &total);
+        if (i < s.ngroups) { loff[i] = carry + ex; hist[i] = carry + ex; gbase[i] = S1[(size_t)i * s.nslices + blockIdx.x]; }
+        carry += total;
+    }
+    if (threadIdx.x == 0) loff[s.ngroups] = carry;
+    __syncthreads();
+    msm2_stage_place_body(s, scalars, montgomery != 0, blockIdx.x, hist, stage_lo, stage_val, threadIdx.x, blockDim.x);
+    __syncthreads();
+    msm2_stage_copy_body(s, gbase, loff, stage_lo, stage_val, part_lo, part_val, threadIdx.x, blockDim.x);
 }
-__global__ void k_msm2_chunk_table(Msm2Shape s, const u32 *S1, u32 *gstart, u32 *cstart) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) msm2_chunk_table_body(s, S1, gstart, cstart);
+__global__ void k_msm2_chunk_count(Msm2Shape s, const u32 *S1, u32 *gstart, u32 *nchunks) {
+    u32 hi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hi < s.ngroups) msm2_chunk_count_body(s, S1, gstart, nchunks, hi);
 }
 __global__ void __launch_bounds__(1024) k_msm2_hist2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const uint16_t *part_lo, u32 *H2) {
     extern __shared__ u32 lds_u32[];
     u32 hi, b, e;
     if (!msm2_chunk_range(s, gstart, cstart, blockIdx.x, hi, b, e)) return;   // the grid is a host-side bound
-    msm2_hist2_zero(lds_u32, threadIdx.x, blockDim.x);
+    msm2_hist2_zero(s, lds_u32, threadIdx.x, blockDim.x);
     __syncthreads();
     msm2_hist2_count(part_lo, b, e, lds_u32, threadIdx.x, blockDim.x);
     __syncthreads();
-    msm2_hist2_write(H2, blockIdx.x, lds_u32, threadIdx.x, blockDim.x);
+    msm2_hist2_write(s, H2, blockIdx.x, lds_u32, threadIdx.x, blockDim.x);
 }
 __global__ void k_msm2_colsum(Msm2Shape s, const u32 *cstart, u32 *H2, u32 *total) {
     u32 key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key < s.nkeys) msm2_colsum_body(cstart, H2, total, key);
+    if (key < s.nkeys) msm2_colsum_body(s, cstart, H2, total, key);
 }
 __global__ void __launch_bounds__(1024) k_msm2_scatter2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const u32 *keystart, const u32 *H2x,
                                                         const uint16_t *part_lo, const u32 *part_val, u32 *sorted) {
     extern __shared__ u32 lds_u32[];
     u32 hi, b, e;
     if (!msm2_chunk_range(s, gstart, cstart, blockIdx.x, hi, b, e)) return;
-    msm2_scatter2_init(keystart, H2x, blockIdx.x, hi, lds_u32, threadIdx.x, blockDim.x);
+    msm2_scatter2_init(s, keystart, H2x, blockIdx.x, hi, lds_u32, threadIdx.x, blockDim.x);
     __syncthreads();
     msm2_scatter2_move(part_lo, part_val, b, e, lds_u32, sorted, threadIdx.x, blockDim.x);
 }
@@ -205,6 +225,7 @@ void mi_msm_state_init(mi_ctx *ctx) {
     (void)hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_msm2_hist2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_msm2_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_msm2_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (auto &sl : ctx->msm) {
         (void)hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
@@ -297,9 +318,12 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
 static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c) {
     MsmKnobs *kn = knobs_of(ctx);
     if (c < 17 || c > 22) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: window bits must be 17..22");
-    const u32 G = n / 32768 > 512 ? 512 : (n / 32768 ? n / 32768 : 1);
-    const u32 chunk = kn->chunk ? kn->chunk : 65536;
-    const Msm2Shape s = msm2_shape(n, c, G, chunk);
+    const u32 G = n ? (n + MSM2_SLICE - 1) / MSM2_SLICE : 1;   // pass-1 slices
+    const u32 chunk = kn->chunk ? kn->chunk : 16384;   // (gbits, chunk) sweep at 2^23 pairs, c = 20: tools/fixed_probe.py
+    u32 gbits = kn->gbits ? kn->gbits : 11;
+    if (gbits > 15) gbits = 15;
+    while (((1u << (c - 1)) >> gbits) > MSM2_MAX_GROUPS) gbits++;
+    const Msm2Shape s = msm2_shape(n, c, G, chunk, gbits);
     sl.n = n; sl.c = c; sl.G = G; sl.nwin_keys = 1; sl.nwin_digits = s.nwin;
     const u64 T_bound = (u64)s.nwin * n;
     if (T_bound >= ((u64)1 << 31)) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: windows * n must stay below 2^31");
@@ -307,26 +331,31 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     MI_TRY(mi_reserve(ctx, sl.buf[B_C1], ((size_t)s.ngroups * G + 1) * 4 * 2));
     MI_TRY(mi_reserve(ctx, sl.buf[B_DIGITS], T_bound * 2 + 64));                  // part_lo (u16)
     MI_TRY(mi_reserve(ctx, sl.buf[B_PVAL], (T_bound + 1) * 4));                   // part_val
-    MI_TRY(mi_reserve(ctx, sl.buf[B_CHUNKS], ((size_t)s.ngroups + 1) * 4 * 2));
-    MI_TRY(mi_reserve(ctx, sl.buf[B_H], (size_t)chunks_bound * 32768 * 4));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_CHUNKS], ((size_t)s.ngroups + 1) * 4 * 3));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_H], (size_t)chunks_bound * s.gsize * 4));
     MI_TRY(mi_reserve(ctx, sl.buf[B_S], ((size_t)s.nkeys * 2 + 2) * 4));
     MI_TRY(mi_reserve(ctx, sl.buf[B_SORTED], (T_bound + 1) * 4));
     u32 *C1 = (u32 *)sl.buf[B_C1].p, *S1 = C1 + (size_t)s.ngroups * G + 1;
     uint16_t *part_lo = (uint16_t *)sl.buf[B_DIGITS].p;
-    u32 *part_val = (u32 *)sl.buf[B_PVAL].p, *gstart = (u32 *)sl.buf[B_CHUNKS].p, *cstart = gstart + s.ngroups + 1;
+    u32 *part_val = (u32 *)sl.buf[B_PVAL].p, *gstart = (u32 *)sl.buf[B_CHUNKS].p, *cstart = gstart + s.ngroups + 1, *nchunks = cstart + s.ngroups + 1;
     u32 *H2 = (u32 *)sl.buf[B_H].p, *keystart = (u32 *)sl.buf[B_S].p, *total = keystart + s.nkeys + 1, *sorted = (u32 *)sl.buf[B_SORTED].p;
     const int mont = (flags & MI_MSM_SCALARS_CANONICAL) ? 0 : 1;
     hipStream_t st = sl.stream;
     hipLaunchKernelGGL(k_msm2_count, dim3(G), dim3(256), 0, st, s, scalars, mont, C1);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, C1, (size_t)s.ngroups * G, S1, sl.buf[B_SCAN]));
-    hipLaunchKernelGGL(k_msm2_partition, dim3(G), dim3(256), 0, st, s, scalars, mont, S1, part_lo, part_val);
-    hipLaunchKernelGGL(k_msm2_chunk_table, dim3(1), dim3(64), 0, st, s, S1, gstart, cstart);
-    hipLaunchKernelGGL(k_msm2_hist2, dim3(chunks_bound), dim3(1024), 32768 * 4, st, s, gstart, cstart, part_lo, H2);
+    const u32 cap = ((n + G - 1) / G) * s.nwin;   // entries of one slice at most
+    const size_t part_lds = ((size_t)3 * s.ngroups + 1 + 256 + cap) * 4 + (size_t)cap * 2;
+    if (part_lds > 160 * 1024) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: pass-1 slice does not fit in LDS");
+    hipLaunchKernelGGL(k_msm2_partition, dim3(G), dim3(256), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val);
+    hipLaunchKernelGGL(k_msm2_chunk_count, dim3((s.ngroups + 63) / 64), dim3(64), 0, st, s, S1, gstart, nchunks);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(exclusive_scan(ctx, st, nchunks, s.ngroups, cstart, sl.buf[B_SCAN]));
+    hipLaunchKernelGGL(k_msm2_hist2, dim3(chunks_bound), dim3(1024), s.gsize * 4, st, s, gstart, cstart, part_lo, H2);
     hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, cstart, H2, total);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
-    hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound), dim3(1024), 32768 * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
+    hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound), dim3(1024), s.gsize * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[0], st));
     return MI_OK;
@@ -485,6 +514,11 @@ int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_f
 int32_t mi_debug_set_msm_chunk(mi_ctx *ctx, uint32_t chunk) {
     if (!ctx) return MI_EINVAL;
     knobs_of(ctx)->chunk = chunk;
+    return MI_OK;
+}
+int32_t mi_debug_set_msm_group_bits(mi_ctx *ctx, uint32_t gbits) {
+    if (!ctx || (gbits && (gbits < 6 || gbits > 15))) return MI_EINVAL;
+    knobs_of(ctx)->gbits = gbits;
     return MI_OK;
 }
 int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G) {

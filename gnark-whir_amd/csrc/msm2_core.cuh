@@ -7,8 +7,12 @@
 // element); replaces the same reference functions as msm_core.cuh.
 //
 //   entry      key = |d| - 1 (21 bits), value = (w * n + i) | sign << 31     -> point = pre[w][i]
-//   sort       two passes: (1) partition by hi = key >> 15 (64 groups, long contiguous runs per slice);
-//              (2) inside a group, LDS counting sort by lo = key & 0x7fff over fixed-size chunks of the group.
+//   slices     pass 1 cuts the scalars into slices of <= MSM2_SLICE; a slice's entries fit an LDS staging area
+//   sort       two passes: (1) partition by hi = key >> gbits (2^(c-1-gbits) groups, long contiguous runs per slice);
+//              (2) inside a group, LDS counting sort by lo = key & (2^gbits - 1) over fixed-size chunks of the group.
+//              Narrow groups (gbits = 10..12) keep a chunk's stores to one bucket adjacent (chunk / 2^gbits entries in a
+//              row, merged in L2 instead of one 4-B write per line), shrink the chunk histograms 8..32x and let several
+//              chunk workgroups share a CU.
 //   after that the item / level / bucket-reduce machinery of msm_core.cuh runs unchanged on nkeys = 2^(c-1), one window.
 #pragma once
 #include "msm_core.cuh"
@@ -17,17 +21,20 @@ struct Msm2Shape {
     u32 c;          // window bits (17..22)
     u32 nwin;       // ceil(256 / c)
     u32 nkeys;      // 2^(c-1) buckets, one set for all windows
-    u32 ngroups;    // nkeys >> 15
+    u32 gbits;      // log2 of the buckets per group (<= 15: the group-local bucket travels as u16)
+    u32 gsize;      // 1 << gbits
+    u32 ngroups;    // nkeys >> gbits
     u32 nslices;    // slices of the scalar range for pass 1
     u32 chunk;      // entries per pass-2 chunk
     u32 n;          // pairs
 };
-MI_HD Msm2Shape msm2_shape(u32 n, u32 c, u32 nslices, u32 chunk) {
+MI_HD Msm2Shape msm2_shape(u32 n, u32 c, u32 nslices, u32 chunk, u32 gbits = 15) {
     Msm2Shape s;
-    s.c = c; s.nwin = (256 + c - 1) / c; s.nkeys = 1u << (c - 1); s.ngroups = s.nkeys >> 15;
+    s.c = c; s.nwin = (256 + c - 1) / c; s.nkeys = 1u << (c - 1); s.gbits = gbits; s.gsize = 1u << gbits; s.ngroups = s.nkeys >> gbits;
     s.nslices = nslices; s.chunk = chunk; s.n = n;
     return s;
 }
+static constexpr u32 MSM2_SLICE = 512;   // scalars per pass-1 workgroup: 512 * 15 windows * 6 B = 45 KiB of staging
 MI_HD void msm2_slice_range(const Msm2Shape &s, u32 g, u32 &begin, u32 &end) {
     u32 per = (s.n + s.nslices - 1) / s.nslices;
     begin = g * per < s.n ? g * per : s.n;
@@ -59,13 +66,17 @@ MI_HD void msm2_count_body(const Msm2Shape &s, const Fr *scalars, bool montgomer
         dg.start(scalars[i], montgomery);
         for (u32 w = 0; w < s.nwin; w++) {
             int32_t d = dg.next(s);
-            if (d) MI_LDS_ATOMIC_ADD(&lds[((u32)(d < 0 ? -d : d) - 1) >> 15], 1u);
+            if (d) MI_LDS_ATOMIC_ADD(&lds[((u32)(d < 0 ? -d : d) - 1) >> s.gbits], 1u);
         }
     }
 }
-// ---- pass 1b: partition.  LDS cursor[hi] = S1[hi * G + g]; writes the group-local bucket (u16) and the value (u32)
-MI_HD void msm2_partition_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *lds, uint16_t *part_lo, u32 *part_val,
-                               u32 tid, u32 nthr) {
+// ---- pass 1b: partition, staged through LDS so that the global stores are runs, not single entries.
+// The workgroup of slice g has hist[hi] (msm2_count_body again), loff = exclusive scan of hist (loff[ngroups] = entries
+// of the slice), cursor[hi] = loff[hi].  place: every entry goes to its group's run inside the LDS staging area;
+// copy: entry e of the staging area belongs to the group hi with loff[hi] <= e < loff[hi+1] and lands at
+// gbase[hi] + (e - loff[hi]), gbase[hi] = S1[hi * G + g]: consecutive e of a group are consecutive in part_lo / part_val.
+MI_HD void msm2_stage_place_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *cursor, uint16_t *stage_lo, u32 *stage_val,
+                                 u32 tid, u32 nthr) {
     u32 begin, end;
     msm2_slice_range(s, g, begin, end);
     for (u32 i = begin + tid; i < end; i += nthr) {
@@ -75,24 +86,34 @@ MI_HD void msm2_partition_body(const Msm2Shape &s, const Fr *scalars, bool montg
             int32_t d = dg.next(s);
             if (!d) continue;
             u32 key = (u32)(d < 0 ? -d : d) - 1;
-            u32 pos = MI_LDS_ATOMIC_ADD(&lds[key >> 15], 1u);
-            part_lo[pos] = (uint16_t)(key & 0x7fffu);
-            part_val[pos] = (w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
+            u32 pos = MI_LDS_ATOMIC_ADD(&cursor[key >> s.gbits], 1u);
+            stage_lo[pos] = (uint16_t)(key & (s.gsize - 1));
+            stage_val[pos] = (w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
         }
     }
 }
-// ---- chunk table: group hi owns entries [gstart[hi], gstart[hi+1]); it is cut into ceil(size / chunk) chunks.
-// cstart[hi] = first chunk id of group hi (exclusive scan), cstart[ngroups] = total chunks.   (single thread, <= 64 groups)
-MI_HD void msm2_chunk_table_body(const Msm2Shape &s, const u32 *S1, u32 *gstart, u32 *cstart) {
-    u32 acc = 0;
-    for (u32 hi = 0; hi < s.ngroups; hi++) {
-        u32 a = S1[(size_t)hi * s.nslices], b = S1[(size_t)(hi + 1) * s.nslices];   // S1 has ngroups*G + 1 entries
-        gstart[hi] = a;
-        cstart[hi] = acc;
-        acc += (b - a + s.chunk - 1) / s.chunk;
+// gbase[hi] = S1[hi * G + g] (the slice's run of group hi in the partitioned arrays), loaded once per workgroup
+MI_HD void msm2_stage_copy_body(const Msm2Shape &s, const u32 *gbase, const u32 *loff, const uint16_t *stage_lo, const u32 *stage_val,
+                                uint16_t *part_lo, u32 *part_val, u32 tid, u32 nthr) {
+    const u32 total = loff[s.ngroups];
+    for (u32 e = tid; e < total; e += nthr) {
+        u32 lo_g = 0, hi_g = s.ngroups;   // largest group with loff <= e (empty groups share a start with their successor)
+        while (hi_g - lo_g > 1) {
+            u32 mid = (lo_g + hi_g) >> 1;
+            if (loff[mid] <= e) lo_g = mid; else hi_g = mid;
+        }
+        u32 pos = gbase[lo_g] + (e - loff[lo_g]);
+        part_lo[pos] = stage_lo[e];
+        part_val[pos] = stage_val[e];
     }
-    gstart[s.ngroups] = S1[(size_t)s.ngroups * s.nslices];
-    cstart[s.ngroups] = acc;
+}
+// ---- chunk table: group hi owns entries [gstart[hi], gstart[hi+1]); it is cut into ceil(size / chunk) chunks.
+// thread = group: gstart[hi] and the group's chunk count; cstart = exclusive scan of the counts (cstart[ngroups] = total chunks)
+MI_HD void msm2_chunk_count_body(const Msm2Shape &s, const u32 *S1, u32 *gstart, u32 *nchunks, u32 hi) {
+    u32 a = S1[(size_t)hi * s.nslices], b = S1[(size_t)(hi + 1) * s.nslices];   // S1 has ngroups*G + 1 entries
+    gstart[hi] = a;
+    nchunks[hi] = (b - a + s.chunk - 1) / s.chunk;
+    if (hi + 1 == s.ngroups) gstart[s.ngroups] = b;
 }
 // chunk id -> (group, entry range)
 MI_HD bool msm2_chunk_range(const Msm2Shape &s, const u32 *gstart, const u32 *cstart, u32 chunk_id, u32 &hi, u32 &b, u32 &e) {
@@ -108,31 +129,31 @@ MI_HD bool msm2_chunk_range(const Msm2Shape &s, const u32 *gstart, const u32 *cs
     if (b + s.chunk < e) e = b + s.chunk;
     return true;
 }
-// ---- pass 2a: workgroup = chunk; LDS hist[32768] (u32); H2[chunk][lo]
-MI_HD void msm2_hist2_zero(u32 *lds, u32 tid, u32 nthr) {
-    for (u32 b = tid; b < 32768; b += nthr) lds[b] = 0;
+// ---- pass 2a: workgroup = chunk; LDS hist[gsize] (u32); H2[chunk][lo]
+MI_HD void msm2_hist2_zero(const Msm2Shape &s, u32 *lds, u32 tid, u32 nthr) {
+    for (u32 b = tid; b < s.gsize; b += nthr) lds[b] = 0;
 }
 MI_HD void msm2_hist2_count(const uint16_t *part_lo, u32 b, u32 e, u32 *lds, u32 tid, u32 nthr) {
     for (u32 k = b + tid; k < e; k += nthr) MI_LDS_ATOMIC_ADD(&lds[part_lo[k]], 1u);
 }
-MI_HD void msm2_hist2_write(u32 *H2, u32 chunk_id, const u32 *lds, u32 tid, u32 nthr) {
-    for (u32 b = tid; b < 32768; b += nthr) H2[(size_t)chunk_id * 32768 + b] = lds[b];
+MI_HD void msm2_hist2_write(const Msm2Shape &s, u32 *H2, u32 chunk_id, const u32 *lds, u32 tid, u32 nthr) {
+    for (u32 b = tid; b < s.gsize; b += nthr) H2[(size_t)chunk_id * s.gsize + b] = lds[b];
 }
 // ---- column sums: thread = key (hi, lo): H2[chunk][lo] <- exclusive prefix along the chunks of group hi (in place),
 // total[key] <- number of entries of the key
-MI_HD void msm2_colsum_body(const u32 *cstart, u32 *H2, u32 *total, u32 key) {
-    u32 hi = key >> 15, lo = key & 0x7fffu, run = 0;
+MI_HD void msm2_colsum_body(const Msm2Shape &s, const u32 *cstart, u32 *H2, u32 *total, u32 key) {
+    u32 hi = key >> s.gbits, lo = key & (s.gsize - 1), run = 0;
     for (u32 ch = cstart[hi]; ch < cstart[hi + 1]; ch++) {
-        size_t i = (size_t)ch * 32768 + lo;
+        size_t i = (size_t)ch * s.gsize + lo;
         u32 v = H2[i];
         H2[i] = run;
         run += v;
     }
     total[key] = run;
 }
-// ---- pass 2b: scatter.  cursor[lo] = keystart[hi*32768 + lo] + H2x[chunk][lo]
-MI_HD void msm2_scatter2_init(const u32 *keystart, const u32 *H2x, u32 chunk_id, u32 hi, u32 *lds, u32 tid, u32 nthr) {
-    for (u32 b = tid; b < 32768; b += nthr) lds[b] = keystart[(size_t)hi * 32768 + b] + H2x[(size_t)chunk_id * 32768 + b];
+// ---- pass 2b: scatter.  cursor[lo] = keystart[hi*gsize + lo] + H2x[chunk][lo]
+MI_HD void msm2_scatter2_init(const Msm2Shape &s, const u32 *keystart, const u32 *H2x, u32 chunk_id, u32 hi, u32 *lds, u32 tid, u32 nthr) {
+    for (u32 b = tid; b < s.gsize; b += nthr) lds[b] = keystart[(size_t)hi * s.gsize + b] + H2x[(size_t)chunk_id * s.gsize + b];
 }
 MI_HD void msm2_scatter2_move(const uint16_t *part_lo, const u32 *part_val, u32 b, u32 e, u32 *lds, u32 *sorted, u32 tid, u32 nthr) {
     for (u32 k = b + tid; k < e; k += nthr) {

@@ -263,6 +263,7 @@ int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, 
 int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads);
 int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G);
 int32_t mi_debug_set_msm_chunk(mi_ctx *ctx, uint32_t chunk);   /* fixed-base sort: entries per pass-2 chunk */
+int32_t mi_debug_set_msm_group_bits(mi_ctx *ctx, uint32_t gbits);   /* fixed-base sort: log2 buckets per pass-1 group, 6..15 */
 /* window widths of the fixed-base tables the NEXT mi_pk_load[_dev] on ctx builds for the MSM groups A+K, B1+B2, Z:
  * 0 = automatic (tables when the MSM has >= 2^20 points and they fit in a third of the free device memory),
  * 1 = never, 17..22 = that width whatever the size */

@@ -212,14 +212,14 @@ extern "C" int emu_msm_g2(void *out, const void *pts, const void *sc, uint32_t n
 // ---------------------------------------------------------------- fixed-base MSM (msm2_core.cuh on the host)
 #include "../../gnark-whir_amd/csrc/msm2_core.cuh"
 extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uint32_t n, int mont, uint32_t c, uint32_t G, uint32_t chunk, uint32_t L,
-                           uint32_t seg, uint32_t nthr) {
+                           uint32_t seg, uint32_t nthr, uint32_t gbits) {
     typedef Fp F;
-    Msm2Shape s = msm2_shape(n, c, G, chunk);
+    Msm2Shape s = msm2_shape(n, c, G, chunk, gbits);
     // pk_load: window copies
     std::vector<Affine<F>> pre((size_t)s.nwin * n);
     for (u32 i = 0; i < n; i++) msm2_precompute_body<F>((const Affine<F> *)pts_v, pre.data(), n, c, s.nwin, i);
     // pass 1
-    std::vector<u32> C1((size_t)s.ngroups * G), lds(32768);
+    std::vector<u32> C1((size_t)s.ngroups * G), lds(s.gsize > s.ngroups ? s.gsize : s.ngroups);
     for (u32 g = 0; g < G; g++) {
         for (u32 h = 0; h < s.ngroups; h++) lds[h] = 0;
         for (u32 t = 0; t < nthr; t++) msm2_count_body(s, (const Fr *)sc_v, mont != 0, g, lds.data(), t, nthr);
@@ -230,29 +230,40 @@ extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uin
     u32 T = S1.back();
     std::vector<uint16_t> part_lo(T + 1);
     std::vector<u32> part_val(T + 1);
-    for (u32 g = 0; g < G; g++) {
-        for (u32 h = 0; h < s.ngroups; h++) lds[h] = S1[(size_t)h * G + g];
-        for (u32 t = 0; t < nthr; t++) msm2_partition_body(s, (const Fr *)sc_v, mont != 0, g, lds.data(), part_lo.data(), part_val.data(), t, nthr);
+    const u32 cap = ((n + G - 1) / G) * s.nwin;
+    std::vector<uint16_t> stage_lo(cap + 1);
+    std::vector<u32> stage_val(cap + 1), hist(s.ngroups), loff;
+    for (u32 g = 0; g < G; g++) {   // LDS-staged partition: count again, scan, place, copy
+        for (u32 h = 0; h < s.ngroups; h++) hist[h] = 0;
+        for (u32 t = 0; t < nthr; t++) msm2_count_body(s, (const Fr *)sc_v, mont != 0, g, hist.data(), t, nthr);
+        excl_scan(hist, loff);
+        if (loff[s.ngroups] > cap) return -1;
+        for (u32 h = 0; h < s.ngroups; h++) hist[h] = loff[h];
+        for (u32 t = 0; t < nthr; t++) msm2_stage_place_body(s, (const Fr *)sc_v, mont != 0, g, hist.data(), stage_lo.data(), stage_val.data(), t, nthr);
+        std::vector<u32> gbase(s.ngroups);
+        for (u32 h = 0; h < s.ngroups; h++) gbase[h] = S1[(size_t)h * G + g];
+        for (u32 t = 0; t < nthr; t++) msm2_stage_copy_body(s, gbase.data(), loff.data(), stage_lo.data(), stage_val.data(), part_lo.data(), part_val.data(), t, nthr);
     }
-    std::vector<u32> gstart(s.ngroups + 1), cstart(s.ngroups + 1);
-    msm2_chunk_table_body(s, S1.data(), gstart.data(), cstart.data());
+    std::vector<u32> gstart(s.ngroups + 1), cstart, nch(s.ngroups);
+    for (u32 h = 0; h < s.ngroups; h++) msm2_chunk_count_body(s, S1.data(), gstart.data(), nch.data(), h);
+    excl_scan(nch, cstart);
     u32 nchunks = cstart[s.ngroups];
-    std::vector<u32> H2((size_t)(nchunks + 1) * 32768), total(s.nkeys);
+    std::vector<u32> H2((size_t)(nchunks + 1) * s.gsize), total(s.nkeys);
     for (u32 ch = 0; ch < nchunks + 2; ch++) {   // over-launch like the bounded GPU grid
         u32 hi, b, e;
         if (!msm2_chunk_range(s, gstart.data(), cstart.data(), ch, hi, b, e)) continue;
-        for (u32 t = 0; t < nthr; t++) msm2_hist2_zero(lds.data(), t, nthr);
+        for (u32 t = 0; t < nthr; t++) msm2_hist2_zero(s, lds.data(), t, nthr);
         for (u32 t = 0; t < nthr; t++) msm2_hist2_count(part_lo.data(), b, e, lds.data(), t, nthr);
-        for (u32 t = 0; t < nthr; t++) msm2_hist2_write(H2.data(), ch, lds.data(), t, nthr);
+        for (u32 t = 0; t < nthr; t++) msm2_hist2_write(s, H2.data(), ch, lds.data(), t, nthr);
     }
-    for (u32 k = 0; k < s.nkeys; k++) msm2_colsum_body(cstart.data(), H2.data(), total.data(), k);
+    for (u32 k = 0; k < s.nkeys; k++) msm2_colsum_body(s, cstart.data(), H2.data(), total.data(), k);
     std::vector<u32> keystart;
     excl_scan(total, keystart);
     std::vector<u32> sorted(T + 1);
     for (u32 ch = 0; ch < nchunks; ch++) {
         u32 hi, b, e;
         msm2_chunk_range(s, gstart.data(), cstart.data(), ch, hi, b, e);
-        for (u32 t = 0; t < nthr; t++) msm2_scatter2_init(keystart.data(), H2.data(), ch, hi, lds.data(), t, nthr);
+        for (u32 t = 0; t < nthr; t++) msm2_scatter2_init(s, keystart.data(), H2.data(), ch, hi, lds.data(), t, nthr);
         for (u32 t = 0; t < nthr; t++) msm2_scatter2_move(part_lo.data(), part_val.data(), b, e, lds.data(), sorted.data(), t, nthr);
     }
     // items / levels over nkeys keys (one window), then bucket reduce with nwin = 1

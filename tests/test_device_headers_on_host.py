@@ -121,14 +121,15 @@ def test_msm_pipeline_g2_matches_oracle(emu):
     assert np.array_equal(out, cref.msm_g2(pts, sc)[:16])
 
 
-@pytest.mark.parametrize("n,dist,c,G,chunk,L", [(1, 0, 17, 1, 8, 4), (60, 1, 17, 3, 16, 3), (200, 0, 18, 2, 50, 8), (150, 1, 19, 4, 7, 4)])
-def test_fixed_base_msm_pipeline_matches_oracle(emu, n, dist, c, G, chunk, L):
+@pytest.mark.parametrize("n,dist,c,G,chunk,L,gbits", [(1, 0, 17, 1, 8, 4, 15), (60, 1, 17, 3, 16, 3, 11), (200, 0, 18, 2, 50, 8, 9),
+                                                     (150, 1, 19, 4, 7, 4, 12), (90, 1, 17, 2, 16, 4, 16 - 1)])
+def test_fixed_base_msm_pipeline_matches_oracle(emu, n, dist, c, G, chunk, L, gbits):
     """msm2_core.cuh: window copies 2^(c*w)*P, one bucket set for all windows, two-pass sort (partition by the high
-    bucket bits, chunked LDS counting sort by the low 15), then the shared item / bucket-reduce bodies"""
+    bucket bits, chunked LDS counting sort by the low gbits), then the shared item / bucket-reduce bodies"""
     pts = cref.gen_g1(n, 900 + n); sc = cref.gen_scalars(n, 901 + n, dist)
     if n > 30:
         pts[3] = 0; sc[1] = fr_arr([P.R_MOD - 1])[0]; sc[2] = 0; pts[6] = pts[5]; sc[6] = sc[5]
     out = np.zeros(8, np.uint64)
-    nchunks = emu.emu_msm2_g1(_p(out), _p(pts), _p(sc), n, 1, c, G, chunk, L, 64, 5)
+    nchunks = emu.emu_msm2_g1(_p(out), _p(pts), _p(sc), n, 1, c, G, chunk, L, 64, 5, gbits)
     want = cref.msm_g1(pts, sc)
     assert nchunks >= 1 and (np.array_equal(out, want[:8]) or (not want[8:].any() and not out.any()))

@@ -329,10 +329,12 @@ def test_prove_degenerate_shapes_vs_oracle(ctx, log_n, nb_wires, nb_public, n_co
     ctx.pk_free(pkh)
 
 
-@pytest.mark.parametrize("n,dist,c,chunk", [(1, 0, 17, 0), (300, 1, 17, 64), (5000, 0, 18, 1000), (70000, 1, 20, 0), (200000, 0, 22, 0)])
-def test_fixed_base_msm_g1_vs_oracle(ctx, n, dist, c, chunk):
-    """fixed-base path: window copies 2^(c*w)*P built on the device, one bucket set, two-pass sort"""
-    assert ctx.lib.mi_debug_set_msm_chunk(ctx.h, chunk) == 0
+@pytest.mark.parametrize("n,dist,c,chunk,gbits", [(1, 0, 17, 0, 0), (300, 1, 17, 64, 6), (5000, 0, 18, 1000, 15), (70000, 1, 20, 0, 0),
+                                                  (200000, 0, 22, 0, 9), (513, 1, 19, 100, 12), (66000, 0, 21, 4096, 10)])
+def test_fixed_base_msm_g1_vs_oracle(ctx, n, dist, c, chunk, gbits):
+    """fixed-base path: window copies 2^(c*w)*P built on the device, one bucket set, two-pass sort (pass 1 staged through
+    LDS per slice of 512 scalars, group width and chunk size forced through the knobs)"""
+    assert ctx.lib.mi_debug_set_msm_chunk(ctx.h, chunk) == 0 and ctx.lib.mi_debug_set_msm_group_bits(ctx.h, gbits) == 0
     try:
         pts = cref.gen_g1(n, 1300 + n); sc = cref.gen_scalars(n, 1400 + n, dist)
         if n > 10:
@@ -348,7 +350,8 @@ def test_fixed_base_msm_g1_vs_oracle(ctx, n, dist, c, chunk):
         for d in (dp, ds, pre):
             d.free()
     finally:
-        assert ctx.lib.mi_debug_set_msm_chunk(ctx.h, 0) == 0
+        assert ctx.lib.mi_debug_set_msm_chunk(ctx.h, 0) == 0 and ctx.lib.mi_debug_set_msm_group_bits(ctx.h, 0) == 0
+    assert ctx.lib.mi_debug_set_msm_group_bits(ctx.h, 5) != 0 and ctx.lib.mi_debug_set_msm_group_bits(ctx.h, 16) != 0
 
 
 def test_fixed_base_msm_g2_vs_oracle(ctx):
