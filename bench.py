@@ -168,6 +168,7 @@ def main():
     # the same kernel measured alone (no other stream competing for the CUs): one uniform-scalar G1 MSM over pk.G1.Z
     solo = None
     if rank == 0:
+        ctx.msm_g1_dev(g1z.ptr, b.ptr, n_constraints)   # sizes the generic path's workspaces (the proofs above used the fixed-base tables)
         ctx.msm_g1_dev(g1z.ptr, b.ptr, n_constraints)
         st = ctx.stats()
         solo = {"pairs": n_constraints, "scalars": "uniform", "msm_total_ms": st["total_ms"], "accum_launch_ms": st["g1_accum_kernel_ms"],
