@@ -19,7 +19,11 @@ int32_t mi_init(int device_id, mi_ctx **out) {
     if (!ctx) return MI_ENOMEM;
     ctx->dev = device_id;
     ctx->cu_count = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return MI_EHIP; }
+    {   // the context's stream carries computeH, the head of a proof's longest chain (h -> Z MSM): high priority (see msm.hip)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete ctx; return MI_EHIP; }
+    }
     ctx->own_stream = true;
     mi_ntt_state_init(ctx);
     mi_msm_state_init(ctx);

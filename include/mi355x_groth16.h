@@ -114,7 +114,9 @@ typedef struct mi_stats {
 int32_t mi_init(int device_id, mi_ctx **out);             /* replaces icicle device init      */
 int32_t mi_shutdown(mi_ctx *ctx);
 const char *mi_last_error(mi_ctx *ctx);                   /* never NULL                       */
-/* Use the caller's HIP stream (a hipStream_t passed as void*) for all later work of ctx. */
+/* Use the caller's HIP stream (a hipStream_t passed as void*) for all later work of ctx.  The context's own stream
+ * is created at the device's highest priority (it carries computeH, the head of a proof's longest chain; the Z MSM runs
+ * on a low-priority library stream so that the other MSMs' tails hide under it): pass a high-priority stream to keep that. */
 int32_t mi_set_stream(mi_ctx *ctx, void *hip_stream);
 
 /* ---- proving key: upload once, device-resident across proofs ---- */
