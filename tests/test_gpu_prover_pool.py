@@ -98,3 +98,44 @@ def test_pool_reports_job_errors_and_keeps_running():
         B.Prover(0, 0)
     c0.pk_free(pkh)
     pool.close()
+
+
+def test_pool_at_2p20_overlapping_witnesses_match_single_context():
+    """N = 2^20 (fixed-base tables active, kernels of different proofs genuinely overlapping): nine jobs over three witnesses
+    through a pool of three; every proof equals the one a plain context computes alone for the same (witness, r, s)"""
+    B = load_binding()
+    log_n = 20
+    N = 1 << log_n
+    nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
+    pool = B.Prover(0, 3)
+    c0 = pool.ctx(0)
+    rng = np.random.default_rng(20)
+    inf_a = (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8); inf_b = (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
+    na, nb, nk = int((inf_a == 0).sum()), int((inf_b == 0).sum()), nb_wires - nb_public
+    g1a, g1b, g1k, g1z, g2b = c0.gen_g1(na, 1), c0.gen_g1(nb, 2), c0.gen_g1(nk, 3), c0.gen_g1(N, 4), c0.gen_g2(nb, 5)
+    small = c0.gen_g1(3, 6).download((3, 8)); small2 = c0.gen_g2(2, 7).download((2, 16))
+    pk = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk),
+          "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb), "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0],
+          "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b}
+    pkh = c0.pk_load(pk, device_points=True)
+    wit = []
+    for w in range(3):
+        W = c0.gen_scalars(nb_wires, 100 + w, w % 2)
+        a = c0.gen_scalars(n_constraints, 200 + w, 1); b = c0.gen_scalars(n_constraints, 300 + w, 0)
+        c = c0.alloc(32 * n_constraints); c0.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)
+        wit.append((W, a, b, c))
+    rs = c0.gen_scalars(18, 400, 0).download((18, 4))
+    c0.sync()
+    tickets = [pool.submit(pkh, *(x.ptr for x in wit[j % 3]), rs[2 * j], rs[2 * j + 1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
+               for j in range(9)]
+    got = [pool.wait(t)[0]["raw"].copy() for t in tickets]
+    single = B.Context(0)
+    for j in range(9):
+        ref, _ = single.prove(pkh, *(x.ptr for x in wit[j % 3]), rs[2 * j], rs[2 * j + 1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
+        assert np.array_equal(ref["raw"], got[j]), j
+    assert not np.array_equal(got[0], got[1]) and not np.array_equal(got[0], got[3])   # different witness / different blinding
+    single.close()
+    c0.pk_free(pkh)
+    for d in (g1a, g1b, g1k, g1z, g2b) + tuple(x for w in wit for x in w):
+        d.free()
+    pool.close()
