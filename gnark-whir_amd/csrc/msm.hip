@@ -72,16 +72,41 @@ __global__ void k_msm_prep_windows(u32 nwin, u32 tb, u32 L, u32 *start, u32 *cnt
 }
 // ---------------------------------------------------------------- fixed-base MSM: two-pass bucket sort (msm2_core.cuh)
 static constexpr u32 MSM2_MAX_GROUPS = 4096;   // 2^(c-1-gbits) <= 2^(21-9)
-__global__ void __launch_bounds__(256) k_msm2_count(Msm2Shape s, const Fr *scalars, int montgomery, u32 *C1) {
-    __shared__ u32 lds[MSM2_MAX_GROUPS];
-    for (u32 g = threadIdx.x; g < s.ngroups; g += blockDim.x) lds[g] = 0;
+// workgroup = `per` consecutive slices (per * ngroups <= 8192 counters of LDS): the counters of a group are then written as
+// per * 4-B contiguous segments of C1[group][slice] instead of single words 4 * nslices bytes apart
+__global__ void __launch_bounds__(512) k_msm2_count(Msm2Shape s, const Fr *scalars, int montgomery, u32 per, u32 *C1) {
+    __shared__ u32 lds[8192];
+    const u32 s0 = blockIdx.x * per;
+    const u32 cnt = s0 + per <= s.nslices ? per : s.nslices - s0;
+    for (u32 k = threadIdx.x; k < per * s.ngroups; k += blockDim.x) lds[k] = 0;
     __syncthreads();
-    msm2_count_body(s, scalars, montgomery != 0, blockIdx.x, lds, threadIdx.x, blockDim.x);
+    for (u32 j = 0; j < cnt; j++) msm2_count_body(s, scalars, montgomery != 0, s0 + j, lds + j * s.ngroups, threadIdx.x, blockDim.x);
     __syncthreads();
-    for (u32 g = threadIdx.x; g < s.ngroups; g += blockDim.x) C1[(size_t)g * s.nslices + blockIdx.x] = lds[g];
+    for (u32 k = threadIdx.x; k < per * s.ngroups; k += blockDim.x) {
+        u32 g = k / per, j = k % per;
+        if (j < cnt) C1[(size_t)g * s.nslices + s0 + j] = lds[j * s.ngroups + g];
+    }
 }
-__device__ u32 block_exclusive_scan_256(u32 v, u32 *lds, u32 *total);
-__global__ void __launch_bounds__(256) k_msm2_partition(Msm2Shape s, const Fr *scalars, int montgomery, const u32 *S1, u32 cap, uint16_t *part_lo, u32 *part_val) {
+// exclusive scan over the values of threads 0..255 of a larger workgroup (Hillis-Steele); every thread of the workgroup calls it
+__device__ u32 block_exclusive_scan_first256(u32 v, u32 *lds, u32 *total) {
+    const u32 tid = threadIdx.x;
+    const bool in = tid < 256;
+    if (in) lds[tid] = v;
+    __syncthreads();
+    for (u32 off = 1; off < 256; off <<= 1) {
+        u32 a = in && tid >= off ? lds[tid - off] : 0;
+        __syncthreads();
+        if (in) lds[tid] += a;
+        __syncthreads();
+    }
+    u32 incl = in ? lds[tid] : 0;
+    *total = lds[255];
+    __syncthreads();
+    return incl - v;
+}
+static constexpr u32 MSM2_PART_THREADS = 512;   // one scalar per thread: 8 waves per workgroup hide the LDS-atomic latency of place/copy
+__global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape s, const Fr *scalars, int montgomery, const u32 *S1, u32 cap,
+                                                                      uint16_t *part_lo, u32 *part_val) {
     extern __shared__ u32 lds_u32[];
     u32 *hist = lds_u32, *loff = hist + s.ngroups, *gbase = loff + s.ngroups + 1, *tmp = gbase + s.ngroups, *stage_val = tmp + 256;
     uint16_t *stage_lo = (uint16_t *)(stage_val + cap);
@@ -92,9 +117,10 @@ __global__ void __launch_bounds__(256) k_msm2_partition(Msm2Shape s, const Fr *s
     u32 carry = 0;
     for (u32 base = 0; base < s.ngroups; base += 256) {   // loff = exclusive scan of hist; hist becomes the cursor
         u32 i = base + threadIdx.x;
-        u32 v = i < s.ngroups ? hist[i] : 0, total;
-        u32 ex = block_exclusive_scan_256(v, tmp, &total);
-        if (i < s.ngroups) { loff[i] = carry + ex; hist[i] = carry + ex; gbase[i] = S1[(size_t)i * s.nslices + blockIdx.x]; }
+        const bool mine = threadIdx.x < 256 && i < s.ngroups;
+        u32 v = mine ? hist[i] : 0, total;
+        u32 ex = block_exclusive_scan_first256(v, tmp, &total);
+        if (mine) { loff[i] = carry + ex; hist[i] = carry + ex; gbase[i] = S1[(size_t)i * s.nslices + blockIdx.x]; }
         carry += total;
     }
     if (threadIdx.x == 0) loff[s.ngroups] = carry;
@@ -124,9 +150,16 @@ __global__ void k_msm2_colsum(Msm2Shape s, const u32 *cstart, u32 *H2, u32 *tota
 __global__ void __launch_bounds__(1024) k_msm2_scatter2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const u32 *keystart, const u32 *H2x,
                                                         const uint16_t *part_lo, const u32 *part_val, u32 *sorted) {
     extern __shared__ u32 lds_u32[];
+    // XCD-aware chunk order: blocks with equal blockIdx % 8 share an XCD (observed round-robin placement; a speed choice only).
+    // XCD x walks the contiguous chunk range [x*Q, (x+1)*Q): its resident blocks then scatter into the same two or three
+    // groups' output windows (1.7 MB each at 2^19 buckets / 2^23 pairs), which stay in that XCD's 4 MB L2 until their lines
+    // are complete -- instead of every 4-B store of the launch going out as its own partial line.
+    const u32 total = cstart[s.ngroups], Q = (total + 7) / 8;
+    const u32 chunk_id = (blockIdx.x & 7) * Q + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= Q) return;
     u32 hi, b, e;
-    if (!msm2_chunk_range(s, gstart, cstart, blockIdx.x, hi, b, e)) return;
-    msm2_scatter2_init(s, keystart, H2x, blockIdx.x, hi, lds_u32, threadIdx.x, blockDim.x);
+    if (!msm2_chunk_range(s, gstart, cstart, chunk_id, hi, b, e)) return;
+    msm2_scatter2_init(s, keystart, H2x, chunk_id, hi, lds_u32, threadIdx.x, blockDim.x);
     __syncthreads();
     msm2_scatter2_move(part_lo, part_val, b, e, lds_u32, sorted, threadIdx.x, blockDim.x);
 }
@@ -332,7 +365,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     MsmKnobs *kn = knobs_of(ctx);
     if (c < 17 || c > 22) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: window bits must be 17..22");
     const u32 G = n ? (n + MSM2_SLICE - 1) / MSM2_SLICE : 1;   // pass-1 slices
-    const u32 chunk = kn->chunk ? kn->chunk : 16384;   // (gbits, chunk) sweep at 2^23 pairs, c = 20: tools/fixed_probe.py
+    const u32 chunk = kn->chunk ? kn->chunk : 8192;    // (gbits, chunk) sweep at 2^23 pairs, c = 20: tools/fixed_probe.py
     u32 gbits = kn->gbits ? kn->gbits : 11;
     if (gbits > 15) gbits = 15;
     while (((1u << (c - 1)) >> gbits) > MSM2_MAX_GROUPS) gbits++;
@@ -354,13 +387,15 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     u32 *H2 = (u32 *)sl.buf[B_H].p, *keystart = (u32 *)sl.buf[B_S].p, *total = keystart + s.nkeys + 1, *sorted = (u32 *)sl.buf[B_SORTED].p;
     const int mont = (flags & MI_MSM_SCALARS_CANONICAL) ? 0 : 1;
     hipStream_t st = sl.stream;
-    hipLaunchKernelGGL(k_msm2_count, dim3(G), dim3(256), 0, st, s, scalars, mont, C1);
+    u32 per = 8;   // slices per counting workgroup
+    while (per > 1 && per * s.ngroups > 8192) per >>= 1;
+    hipLaunchKernelGGL(k_msm2_count, dim3((G + per - 1) / per), dim3(512), 0, st, s, scalars, mont, per, C1);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, C1, (size_t)s.ngroups * G, S1, sl.buf[B_SCAN]));
     const u32 cap = ((n + G - 1) / G) * s.nwin;   // entries of one slice at most
     const size_t part_lds = ((size_t)3 * s.ngroups + 1 + 256 + cap) * 4 + (size_t)cap * 2;
     if (part_lds > 160 * 1024) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: pass-1 slice does not fit in LDS");
-    hipLaunchKernelGGL(k_msm2_partition, dim3(G), dim3(256), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val);
+    hipLaunchKernelGGL(k_msm2_partition, dim3(G), dim3(MSM2_PART_THREADS), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val);
     hipLaunchKernelGGL(k_msm2_chunk_count, dim3((s.ngroups + 63) / 64), dim3(64), 0, st, s, S1, gstart, nchunks);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, nchunks, s.ngroups, cstart, sl.buf[B_SCAN]));
@@ -368,7 +403,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, cstart, H2, total);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
-    hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound), dim3(1024), s.gsize * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
+    hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound + 8), dim3(1024), s.gsize * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[0], st));
     return MI_OK;

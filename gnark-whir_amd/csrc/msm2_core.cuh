@@ -10,9 +10,9 @@
 //   slices     pass 1 cuts the scalars into slices of <= MSM2_SLICE; a slice's entries fit an LDS staging area
 //   sort       two passes: (1) partition by hi = key >> gbits (2^(c-1-gbits) groups, long contiguous runs per slice);
 //              (2) inside a group, LDS counting sort by lo = key & (2^gbits - 1) over fixed-size chunks of the group.
-//              Narrow groups (gbits = 10..12) keep a chunk's stores to one bucket adjacent (chunk / 2^gbits entries in a
-//              row, merged in L2 instead of one 4-B write per line), shrink the chunk histograms 8..32x and let several
-//              chunk workgroups share a CU.
+//              Narrow groups (gbits = 10..12) shrink the chunk histograms 8..32x and a group's output window to an L2's
+//              size (the scatter walks the chunks XCD by XCD, msm.hip), and small chunks (8192) put 13 000 workgroups on
+//              the 256 CUs: 0.64 ms for 109 M entries against 1.6 ms with 2^15-bucket groups and 64 K-entry chunks.
 //   after that the item / level / bucket-reduce machinery of msm_core.cuh runs unchanged on nkeys = 2^(c-1), one window.
 #pragma once
 #include "msm_core.cuh"
