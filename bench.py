@@ -67,6 +67,7 @@ def main():
                     help="proofs kept in flight per GPU by the prover pool (mi_prover_*); 1 = strictly one proof at a time; "
                          "0 = 3 up to N=2^24, 1 above (a context's workspaces take about 1.2 KB x N of HBM)")
     ap.add_argument("--msm-plan", default="", help="tuning: c,L1,L2,seg,G for mi_debug_set_msm_plan on every context (0 = automatic)")
+    ap.add_argument("--fixed-base", default="", help="tuning: c_ak,c_b,c_z for mi_debug_set_prove_fixed_base before the key is loaded (0 = automatic, 1 = off)")
     ap.add_argument("--msm-group-bits", type=int, default=0, help="tuning: mi_debug_set_msm_group_bits on every context")
     ap.add_argument("--msm-chunk", type=int, default=0, help="tuning: mi_debug_set_msm_chunk on every context")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -120,6 +121,8 @@ def main():
           "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk), "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb),
           "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0], "delta2": small2[1],
           "infinity_a": inf_a, "infinity_b": inf_b}
+    if args.fixed_base:
+        assert pool.lib.mi_debug_set_prove_fixed_base(ctx.h, *[int(x) for x in args.fixed_base.split(",")]) == 0
     ctx.sync()
     t_load = time.perf_counter()
     pkh = ctx.pk_load(pk, device_points=True)   # includes building the fixed-base window tables (once per key)
