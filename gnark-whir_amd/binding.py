@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libmi355x_groth16.so")
 _LIB = None
 
 EXPORTS = [
-    "mi_init", "mi_shutdown", "mi_last_error", "mi_set_stream", "mi_pk_load", "mi_pk_load_dev", "mi_pk_free",
+    "mi_init", "mi_init_prio", "mi_shutdown", "mi_last_error", "mi_set_stream", "mi_pk_load", "mi_pk_load_dev", "mi_pk_free",
     "mi_ntt", "mi_ntt_dev", "mi_compute_h", "mi_compute_h_dev", "mi_msm_g1", "mi_msm_g1_dev", "mi_msm_g2",
     "mi_msm_g2_dev", "mi_groth16_prove", "mi_groth16_prove_dev", "mi_get_stats", "mi_g1_compress",
     "mi_g2_compress", "mi_proof_write", "mi_g1_sum", "mi_g2_sum", "mi_gen_scalars_dev", "mi_gen_g1_dev",

@@ -6,8 +6,9 @@
 
 extern "C" {
 
-int32_t mi_init(int device_id, mi_ctx **out) {
-    if (!out) return MI_EINVAL;
+int32_t mi_init(int device_id, mi_ctx **out) { return mi_init_prio(device_id, MI_PRIO_SOLO, out); }
+int32_t mi_init_prio(int device_id, int prio_scheme, mi_ctx **out) {
+    if (!out || prio_scheme < MI_PRIO_SOLO || prio_scheme > MI_PRIO_POOL_REST) return MI_EINVAL;
     *out = nullptr;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return MI_ENODEV;
@@ -22,7 +23,11 @@ int32_t mi_init(int device_id, mi_ctx **out) {
     {   // the context's stream carries computeH, the head of a proof's longest chain (h -> Z MSM): high priority (see msm.hip)
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi) != hipSuccess) { delete ctx; return MI_EHIP; }
+        ctx->prio_scheme = prio_scheme;
+        int ph = prio_hi;   // MI_PRIO_SOLO, MI_PRIO_POOL_FIRST
+        if (prio_scheme == MI_PRIO_POOL_SECOND) ph = 0;
+        if (prio_scheme == MI_PRIO_POOL_REST) ph = prio_lo;
+        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ph) != hipSuccess) { delete ctx; return MI_EHIP; }
     }
     ctx->own_stream = true;
     mi_ntt_state_init(ctx);

@@ -36,6 +36,7 @@ struct mi_ctx {
     DevBuf ws[24];
     MsmSlot msm[MI_MSM_SLOTS];          // MSM / prove workspaces, see msm.hip / prove.hip
     int cu_count = 256;
+    int prio_scheme = 0;      // MI_PRIO_*: how the context's streams rank (api.hip, msm.hip)
     uint32_t fixed_knob[3] = {0, 0, 0};  // prove's fixed-base tables for A+K / B / Z: 0 = automatic, 1 = never, 17..22 = forced (prove.hip)
 };
 
@@ -75,6 +76,14 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
 void mi_ntt_state_init(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);
 void mi_msm_state_init(mi_ctx *ctx);
+// Stream priority schemes (3 hardware levels; comment in msm.hip).  A context on its own ranks computeH high, the wire MSMs
+// normal and Z low.  The contexts of a prover pool are staggered on top of that: the first runs nearly as if alone, the
+// others fill what it leaves (28.2-28.4 vs 27.4 proofs/s with three in flight; two staggered contexts reach what three
+// equal ones did).
+enum { MI_PRIO_SOLO = 0,          // computeH high, A/B1/B2/K normal, Z low
+       MI_PRIO_POOL_FIRST = 1,    // computeH high, A/B1/B2/K high,   Z normal
+       MI_PRIO_POOL_SECOND = 2,   // computeH normal, A/B1/B2/K normal, Z low
+       MI_PRIO_POOL_REST = 3 };   // everything low
 void mi_msm_state_free(mi_ctx *ctx);
 // Asynchronous MSM on slot `slot` (curve 1 = G1, 2 = G2; device pointers).  sort_slot < 0: sort the scalars
 // here; otherwise reuse the sort already enqueued on that slot (same scalars, other bases).  wait_ev (may be

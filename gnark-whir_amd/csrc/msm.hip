@@ -270,8 +270,10 @@ void mi_msm_state_init(mi_ctx *ctx) {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     int idx = 0;
     for (auto &sl : ctx->msm) {
-        if (idx == 4) (void)hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, prio_lo);
-        else (void)hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+        int pw = 0, pz = prio_lo;   // wires, Z: MI_PRIO_SOLO, MI_PRIO_POOL_SECOND
+        if (ctx->prio_scheme == MI_PRIO_POOL_FIRST) { pw = prio_hi; pz = 0; }
+        if (ctx->prio_scheme == MI_PRIO_POOL_REST) pw = pz = prio_lo;
+        (void)hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, idx == 4 ? pz : pw);
         idx++;
         for (auto &e : sl.ev) (void)hipEventCreate(&e);
         (void)hipHostMalloc(&sl.host_wsum, 128 * 256 + 64);

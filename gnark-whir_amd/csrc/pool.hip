@@ -6,7 +6,8 @@
 // from many goroutines (the reference has no batching of its own: mt.go:496 is one call per proof), so the drop-in keeps
 // `in_flight` contexts -- each with its own streams, workspaces and a host worker thread -- and lets the GPU fill one
 // proof's head and tail with the bulk of another.  The proving key is read-only during prove and is shared.
-// Measured at N = 2^23 (WHIR mix): 49.0 ms/proof alone, 45.5 at 2 in flight, 44.1 at 3, 43.8 at 4.
+// The contexts' stream priorities are staggered (ctx.h MI_PRIO_*): the first context's proof runs nearly as if alone, the
+// others fill what it leaves.  Measured at N = 2^23 (WHIR mix): DESIGN.md 4 / 5.
 #include <hip/hip_runtime.h>
 #include "ctx.h"
 #include <condition_variable>
@@ -78,7 +79,7 @@ int32_t mi_prover_create(int device_id, uint32_t in_flight, mi_prover **out) {
     p->dev = device_id;
     for (uint32_t i = 0; i < in_flight; i++) {
         mi_ctx *c = nullptr;
-        int32_t rc = mi_init(device_id, &c);
+        int32_t rc = mi_init_prio(device_id, i == 0 ? MI_PRIO_POOL_FIRST : i == 1 ? MI_PRIO_POOL_SECOND : MI_PRIO_POOL_REST, &c);
         if (rc != MI_OK) {
             for (mi_ctx *q : p->ctx) mi_shutdown(q);
             delete p;

@@ -112,6 +112,11 @@ typedef struct mi_stats {
 
 /* ---- lifecycle ---- */
 int32_t mi_init(int device_id, mi_ctx **out);             /* replaces icicle device init      */
+/* mi_init with an explicit stream-priority scheme (the device has three levels): 0 = a context on its own (computeH high,
+ * the wire MSMs A/B1/B2/K normal, Z low: shortest single-proof latency) = mi_init; 1 / 2 / 3 = first / second / further
+ * context of a group that proves concurrently on one GPU (1: all high but Z normal; 2: normal, Z low; 3: all low), so that
+ * one proof runs nearly as if alone and the others fill what it leaves.  mi_prover_create staggers its contexts this way. */
+int32_t mi_init_prio(int device_id, int prio_scheme, mi_ctx **out);
 int32_t mi_shutdown(mi_ctx *ctx);
 const char *mi_last_error(mi_ctx *ctx);                   /* never NULL                       */
 /* Use the caller's HIP stream (a hipStream_t passed as void*) for all later work of ctx.  The context's own stream
