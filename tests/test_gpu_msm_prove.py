@@ -267,12 +267,13 @@ def test_batch_scalar_mul_vs_oracle(ctx):
     assert ctx.batch_scalar_mul(gen, sc[:0]).shape == (0, 8)
 
 
-def test_full_size_prove_equals_composition_of_primitives(ctx):
-    """BASELINE configs[1] size (N = 2^23, WHIR scalar mix): the fused multi-stream prove must equal the proof assembled
-    from the separately tested primitives (computeH, four G1 MSMs, one G2 MSM run one by one on the same device arrays)
-    plus O(1) point operations done by the oracle."""
+@pytest.mark.parametrize("log_n", [23, 25])
+def test_full_size_prove_equals_composition_of_primitives(ctx, log_n):
+    """BASELINE configs[1] size (N = 2^23, WHIR scalar mix) and N = 2^25: the fused multi-stream prove -- fixed-base tables
+    for all three MSM groups at 2^23, for Z and B only at 2^25 (A+K's do not fit the budget and stay generic) -- must equal
+    the proof assembled from the separately tested primitives (computeH, four generic G1 MSMs, one generic G2 MSM run one
+    by one on the same device arrays) plus O(1) point operations done by the oracle."""
     B = load_binding()
-    log_n = 23
     N = 1 << log_n
     nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
     rng = np.random.default_rng(7)
