@@ -70,6 +70,7 @@ def main():
                          "0 = 3 up to N=2^24, 1 above (a context's workspaces take about 1.2 KB x N of HBM)")
     ap.add_argument("--msm-plan", default="", help="tuning: c,L1,L2,seg,G for mi_debug_set_msm_plan on every context (0 = automatic)")
     ap.add_argument("--fixed-base", default="", help="tuning: c_ak,c_b,c_z for mi_debug_set_prove_fixed_base before the key is loaded (0 = automatic, 1 = off)")
+    ap.add_argument("--ntt-plan", default="", help="tuning: log_e,max_contig,max_strided[,threads] for mi_debug_set_ntt_plan / _threads on every context")
     ap.add_argument("--msm-group-bits", type=int, default=0, help="tuning: mi_debug_set_msm_group_bits on every context")
     ap.add_argument("--msm-chunk", type=int, default=0, help="tuning: mi_debug_set_msm_chunk on every context")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -100,6 +101,12 @@ def main():
     for i in range(pool.in_flight):
         assert pool.lib.mi_debug_set_msm_group_bits(pool.ctx(i).h, args.msm_group_bits) == 0
         assert pool.lib.mi_debug_set_msm_chunk(pool.ctx(i).h, args.msm_chunk) == 0
+    if args.ntt_plan:
+        np_ = [int(x) for x in args.ntt_plan.split(",")]
+        for i in range(pool.in_flight):
+            assert pool.lib.mi_debug_set_ntt_plan(pool.ctx(i).h, *np_[:3]) == 0
+            if len(np_) > 3:
+                assert pool.lib.mi_debug_set_ntt_threads(pool.ctx(i).h, np_[3]) == 0
     if args.msm_plan:
         plan = [int(x) for x in args.msm_plan.split(",")]
         for i in range(pool.in_flight):
