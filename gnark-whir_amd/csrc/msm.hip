@@ -65,11 +65,6 @@ __global__ void k_msm_prep_next(u32 nkeys, const u32 *prev_items, const u32 *pre
     u32 key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key < nkeys) msm_prep_next(prev_items, prev_item_start, L, start, cnt, items, key);
 }
-// keyed-by-window item decomposition of the bucket-reduce partials: window w owns [w*tb, (w+1)*tb)
-__global__ void k_msm_prep_windows(u32 nwin, u32 tb, u32 L, u32 *start, u32 *cnt, u32 *items) {
-    u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w < nwin) { start[w] = w * tb; cnt[w] = tb; items[w] = (tb + L - 1) / L; }
-}
 // ---------------------------------------------------------------- fixed-base MSM: two-pass bucket sort (msm2_core.cuh)
 static constexpr u32 MSM2_MAX_GROUPS = 4096;   // 2^(c-1-gbits) <= 2^(21-9)
 // workgroup = `per` consecutive slices (per * ngroups <= 8192 counters of LDS): the counters of a group are then written as
@@ -437,12 +432,21 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed));
     // bucket reduce -> per-window partials -> window sums -> pinned host memory
     const u32 tb = (s.nbuckets + seg - 1) / seg;
-    MI_TRY(mi_reserve(ctx, acc.buf[B_WIN], ((size_t)s.nwin * tb + s.nwin + 1) * ops.xyzz_bytes));
-    char *P = (char *)acc.buf[B_WIN].p, *wsum = P + (size_t)s.nwin * tb * ops.xyzz_bytes;
+    size_t win_pts = (size_t)s.nwin * tb + s.nwin + 1;
+    for (u32 k = tb; k > 1; k = (k + ops.sum_T - 1) / ops.sum_T) win_pts += (size_t)s.nwin * ((k + ops.sum_T - 1) / ops.sum_T);
+    MI_TRY(mi_reserve(ctx, acc.buf[B_WIN], win_pts * ops.xyzz_bytes));
+    char *P = (char *)acc.buf[B_WIN].p;
     ops.bucket_reduce(st, (tb + 63) / 64, s.nwin, bucket, s.nbuckets, seg, tb, P);
-    hipLaunchKernelGGL(k_msm_prep_windows, dim3(1), dim3(128), 0, st, s.nwin, tb, L2, A.start, A.cnt, A.items);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(run_levels(ctx, ops, acc, s.nwin, A, B, (u64)s.nwin * ((tb + L2 - 1) / L2) + 1, tb, L2, L2, nullptr, nullptr, P, wsum, false));
+    // window sums: LDS tree sums of sum_T partials per workgroup until one point per window is left ([w][0] layout = wsum[w])
+    char *cur = P, *next = P + (size_t)s.nwin * tb * ops.xyzz_bytes;
+    for (u32 k = tb; k > 1;) {
+        const u32 nout = (k + ops.sum_T - 1) / ops.sum_T;
+        ops.sum_tree(st, nout, s.nwin, cur, k, next);
+        cur = next; next += (size_t)s.nwin * nout * ops.xyzz_bytes; k = nout;
+    }
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    char *wsum = cur;
     MI_CHECK_HIP(ctx, hipMemcpyAsync(acc.host_wsum, wsum, ops.xyzz_bytes * s.nwin, hipMemcpyDeviceToHost, st));
     // number of sorted entries (= mixed additions of level 1) for the stats: keystart[nkeys]
     MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)acc.host_wsum + 128 * 256, (const u32 *)srt.buf[B_S].p + s.nkeys, 4, hipMemcpyDeviceToHost, st));

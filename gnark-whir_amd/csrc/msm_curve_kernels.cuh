@@ -48,6 +48,33 @@ template <class F>
 static void launch_bucket_reduce(hipStream_t st, unsigned grid_x, unsigned nwin, const void *bucket, u32 nbuckets, u32 seg, u32 tb, void *out) {
     hipLaunchKernelGGL(k_msm_bucket_reduce<F>, dim3(grid_x, nwin), dim3(64), 0, st, (const XYZZ<F> *)bucket, nbuckets, seg, tb, (XYZZ<F> *)out);
 }
+// Sum of the bucket-reduce partials of every window: one workgroup adds SumT<F> consecutive points by a tree in LDS
+// (log2 steps of one addition) instead of the item / level machinery's six launches of eight sequential additions each.
+template <class F> struct SumT { static constexpr int value = 256; };
+template <> struct SumT<Fp2> { static constexpr int value = 64; };   // the G2 addition wants > 256 VGPRs: one wave per workgroup
+template <class F>
+__global__ void __launch_bounds__(SumT<F>::value) k_msm_sum_tree(const XYZZ<F> *in, u32 n, u32 nout, XYZZ<F> *out) {
+    extern __shared__ unsigned char sum_tree_lds[];
+    XYZZ<F> *sh = reinterpret_cast<XYZZ<F> *>(sum_tree_lds);
+    constexpr u32 T = SumT<F>::value;
+    const u32 i = blockIdx.x * T + threadIdx.x, w = blockIdx.y;
+    sh[threadIdx.x] = i < n ? in[(size_t)w * n + i] : XYZZ<F>::inf();
+    __syncthreads();
+    for (u32 h = T / 2; h > 0; h >>= 1) {
+        if (threadIdx.x < h) {
+            XYZZ<F> a = sh[threadIdx.x];
+            xyzz_add(a, sh[threadIdx.x + h]);
+            sh[threadIdx.x] = a;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[(size_t)w * nout + blockIdx.x] = sh[0];
+}
+template <class F>
+static void launch_sum_tree(hipStream_t st, unsigned nout, unsigned nwin, const void *in, u32 n, void *out) {
+    hipLaunchKernelGGL(k_msm_sum_tree<F>, dim3(nout, nwin), dim3(SumT<F>::value), SumT<F>::value * sizeof(XYZZ<F>), st, (const XYZZ<F> *)in, n, nout,
+                       (XYZZ<F> *)out);
+}
 template <class F>
 __global__ void __launch_bounds__(64) k_msm2_precompute(const Affine<F> *base, Affine<F> *pre, u32 n, u32 c, u32 nwin) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;

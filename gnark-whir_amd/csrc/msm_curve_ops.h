@@ -13,6 +13,9 @@ struct MsmCurveOps {
     void (*accum_xyzz)(hipStream_t st, unsigned grid, const void *partial_in, const uint32_t *start, const uint32_t *cnt, const uint32_t *items,
                        const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out);
     void (*bucket_reduce)(hipStream_t st, unsigned grid_x, unsigned nwin, const void *bucket, uint32_t nbuckets, uint32_t seg, uint32_t tb, void *out);
+    // tree sum: block (bx, w) adds in[w*n + bx*sum_T .. + sum_T) in LDS and writes out[w*nout + bx]
+    uint32_t sum_T;
+    void (*sum_tree)(hipStream_t st, unsigned nout, unsigned nwin, const void *in, uint32_t n, void *out);
     void (*precompute)(hipStream_t st, const void *base, void *pre, uint32_t n, uint32_t c, uint32_t nwin);   // fixed-base window copies
     // total = sum_w 2^(c*w) * wsum[w] on the host; nwin == 0 yields the point at infinity
     void (*combine_windows)(const void *host_wsum, uint32_t nwin, uint32_t c, void *out_xyzz);
