@@ -198,27 +198,48 @@ __global__ void __launch_bounds__(256) k_scan_of_sums(u32 *block_sums, u32 nbloc
     }
     if (threadIdx.x == 0) block_sums[nblocks] = carry;
 }
-__global__ void __launch_bounds__(256) k_scan_final(const u32 *in, size_t m, const u32 *block_sums, u32 *out) {
+// mode 0: block_sums holds the exclusive scan of the block sums (+ the total at [gridDim.x]) -- after k_scan_of_sums
+// mode 1: a single block: no block sums at all
+// mode 2: block_sums holds the raw sums of <= 256 blocks: every workgroup scans them itself (saves the k_scan_of_sums launch)
+__global__ void __launch_bounds__(256) k_scan_final(const u32 *in, size_t m, const u32 *block_sums, u32 *out, int mode) {
     __shared__ u32 lds[256];
+    __shared__ u32 my_off;
+    u32 offset = 0, grand = 0;
+    if (mode == 0) { offset = block_sums[blockIdx.x]; grand = block_sums[gridDim.x]; }
+    if (mode == 2) {
+        u32 v = threadIdx.x < gridDim.x ? block_sums[threadIdx.x] : 0;
+        u32 ex = block_exclusive_scan_256(v, lds, &grand);
+        if (threadIdx.x == blockIdx.x) my_off = ex;
+        __syncthreads();
+        offset = my_off;
+    }
     size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     u32 v[SCAN_PER_THREAD], s = 0;
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) { v[k] = base + k < m ? in[base + k] : 0; s += v[k]; }
     u32 total;
-    u32 ex = block_exclusive_scan_256(s, lds, &total) + block_sums[blockIdx.x];
+    u32 ex = block_exclusive_scan_256(s, lds, &total) + offset;
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
         if (base + k < m) out[base + k] = ex;
         ex += v[k];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = block_sums[gridDim.x];
+    if (mode == 1) grand = total;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = grand;
 }
 static int32_t exclusive_scan(mi_ctx *ctx, hipStream_t st, const u32 *in, size_t m, u32 *out, DevBuf &tmp) {
     u32 nblocks = (u32)((m + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (nblocks == 0) nblocks = 1;
     MI_TRY(mi_reserve(ctx, tmp, (size_t)(nblocks + 1) * 4));
     u32 *bs = (u32 *)tmp.p;
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(256), 0, st, in, m, bs);
-    hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, st, bs, nblocks);
-    hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(256), 0, st, in, m, bs, out);
+    if (nblocks == 1) {
+        hipLaunchKernelGGL(k_scan_final, dim3(1), dim3(256), 0, st, in, m, bs, out, 1);
+    } else if (nblocks <= 256) {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(256), 0, st, in, m, bs);
+        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(256), 0, st, in, m, bs, out, 2);
+    } else {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(256), 0, st, in, m, bs);
+        hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, st, bs, nblocks);
+        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(256), 0, st, in, m, bs, out, 0);
+    }
     MI_CHECK_HIP(ctx, hipGetLastError());
     return MI_OK;
 }
