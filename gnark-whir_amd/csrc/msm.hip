@@ -225,6 +225,23 @@ __global__ void __launch_bounds__(256) k_scan_final(const u32 *in, size_t m, con
     if (mode == 1) grand = total;
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = grand;
 }
+// prep of the next level fused with the first half of its scan: thread = SCAN_PER_THREAD consecutive keys, as in k_scan_block_sums
+__global__ void __launch_bounds__(256) k_msm_prep_next_sums(u32 nkeys, const u32 *prev_items, const u32 *prev_item_start, u32 L, u32 *start, u32 *cnt,
+                                                            u32 *items, u32 *block_sums) {
+    __shared__ u32 lds[256];
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    u32 s = 0;
+    for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
+        if (base + k < nkeys) {
+            msm_prep_next(prev_items, prev_item_start, L, start, cnt, items, (u32)(base + k));
+            const u32 m = prev_items[base + k];
+            s += m > 1 ? (m + L - 1) / L : 0;
+        }
+    }
+    u32 total;
+    block_exclusive_scan_256(s, lds, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
 static int32_t exclusive_scan(mi_ctx *ctx, hipStream_t st, const u32 *in, size_t m, u32 *out, DevBuf &tmp) {
     u32 nblocks = (u32)((m + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (nblocks == 0) nblocks = 1;
@@ -317,8 +334,9 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
     u64 items_bound = first_items_bound;
     u64 m = max_count;  // bound on entries of the largest key at this level
     u32 L = L_first;
+    const u32 scan_blocks = (nkeys + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    MI_TRY(exclusive_scan(ctx, st, cur.items, nkeys, cur.item_start, sl.buf[B_SCAN]));
     for (u32 level = 0;; level++) {
-        MI_TRY(exclusive_scan(ctx, st, cur.items, nkeys, cur.item_start, sl.buf[B_SCAN]));
         DevBuf &pout_buf = sl.buf[(level & 1) ? B_PART1 : B_PART0];
         MI_TRY(mi_reserve(ctx, pout_buf, (items_bound + 1) * ops.xyzz_bytes));
         void *pout = pout_buf.p;
@@ -337,8 +355,19 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], st));
         u64 m_next = (m + L - 1) / L;  // entries of the largest key at the next level
         if (m_next <= 1) break;
-        hipLaunchKernelGGL(k_msm_prep_next, dim3((nkeys + 255) / 256), dim3(256), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt, nxt.items);
-        MI_CHECK_HIP(ctx, hipGetLastError());
+        // next level: (start, cnt, items) of the keys that go on, and the exclusive scan of their items
+        if (scan_blocks <= 256) {   // prep fused with the block sums, the scan of the sums fused with the final pass: two launches
+            MI_TRY(mi_reserve(ctx, sl.buf[B_SCAN], (size_t)(scan_blocks + 1) * 4));
+            u32 *bs = (u32 *)sl.buf[B_SCAN].p;
+            hipLaunchKernelGGL(k_msm_prep_next_sums, dim3(scan_blocks), dim3(256), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt,
+                               nxt.items, bs);
+            hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, nxt.items, (size_t)nkeys, bs, nxt.item_start, 2);
+            MI_CHECK_HIP(ctx, hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(k_msm_prep_next, dim3((nkeys + 255) / 256), dim3(256), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt, nxt.items);
+            MI_CHECK_HIP(ctx, hipGetLastError());
+            MI_TRY(exclusive_scan(ctx, st, nxt.items, nkeys, nxt.item_start, sl.buf[B_SCAN]));
+        }
         // items at the next level: every continuing key has >= 2 entries, so items <= entries/L + keys
         u64 nb = items_bound / L_next + (items_bound < nkeys ? items_bound : nkeys) + 1;
         items_bound = nb < items_bound ? nb : items_bound;
