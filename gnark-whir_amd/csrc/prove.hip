@@ -127,11 +127,23 @@ static int32_t pk_load_common(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, boo
             MI_CHECK_HIP(ctx, hipMalloc(dst, bytes ? bytes : 64));
             return mi_msm_precompute(ctx, curve, base, *dst, n, c);
         };
-        if (rc == MI_OK && pk->c_ak) rc = pre(&pk->pre_a, pk->a_full, d->nb_wires, 1, pk->c_ak);
-        if (rc == MI_OK && pk->c_ak) rc = pre(&pk->pre_k, pk->k_full, d->nb_wires, 1, pk->c_ak);
-        if (rc == MI_OK && pk->c_b) rc = pre(&pk->pre_b1, pk->g1_b, pk->n_b, 1, pk->c_b);
-        if (rc == MI_OK && pk->c_b) rc = pre(&pk->pre_b2, pk->g2_b, pk->n_b, 2, pk->c_b);
-        if (rc == MI_OK && pk->c_z) rc = pre(&pk->pre_z, pk->g1_z, N - 1, 1, pk->c_z);
+        // a group whose tables cannot be allocated after all (the budget is an estimate) falls back to the generic path
+        auto group = [&](u32 &c, void **t0, const void *b0, int curve0, void **t1, const void *b1, int curve1, size_t n) -> int32_t {
+            if (!c) return MI_OK;
+            int32_t r = pre(t0, b0, n, curve0, c);
+            if (r == MI_OK && t1) r = pre(t1, b1, n, curve1, c);
+            if (r == MI_ENOMEM) {
+                (void)hipGetLastError();
+                if (*t0) { (void)hipFree(*t0); *t0 = nullptr; }
+                if (t1 && *t1) { (void)hipFree(*t1); *t1 = nullptr; }
+                c = 0;
+                r = MI_OK;
+            }
+            return r;
+        };
+        if (rc == MI_OK) rc = group(pk->c_z, &pk->pre_z, pk->g1_z, 1, nullptr, nullptr, 0, N - 1);
+        if (rc == MI_OK) rc = group(pk->c_b, &pk->pre_b1, pk->g1_b, 1, &pk->pre_b2, pk->g2_b, 2, pk->n_b);
+        if (rc == MI_OK) rc = group(pk->c_ak, &pk->pre_a, pk->a_full, 1, &pk->pre_k, pk->k_full, 1, d->nb_wires);
     }
     if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pk upload sync failed"; rc = MI_EHIP; }
     if (rc != MI_OK) { mi_pk_free(ctx, pk); return rc; }
