@@ -267,10 +267,11 @@ def test_batch_scalar_mul_vs_oracle(ctx):
     assert ctx.batch_scalar_mul(gen, sc[:0]).shape == (0, 8)
 
 
-@pytest.mark.parametrize("log_n", [23, 25])
+@pytest.mark.parametrize("log_n", [23, 25, 26])
 def test_full_size_prove_equals_composition_of_primitives(ctx, log_n):
-    """BASELINE configs[1] size (N = 2^23, WHIR scalar mix) and N = 2^25: the fused multi-stream prove -- fixed-base tables
-    for all three MSM groups at 2^23, for Z and B only at 2^25 (A+K's do not fit the budget and stay generic) -- must equal
+    """BASELINE configs[1] size (N = 2^23, WHIR scalar mix), N = 2^25 and configs[2] size (2^26): the fused multi-stream
+    prove -- fixed-base tables for all three MSM groups at 2^23, for Z and B at 2^25, for Z alone at 2^26 (the others do not
+    fit the budget and stay generic) -- must equal
     the proof assembled from the separately tested primitives (computeH, four generic G1 MSMs, one generic G2 MSM run one
     by one on the same device arrays) plus O(1) point operations done by the oracle."""
     B = load_binding()
