@@ -36,6 +36,12 @@ def test_no_device_means_hard_failure_not_fallback():
     B = load_binding()
     with pytest.raises(B.MiError):
         B.Context(0)
+    with pytest.raises(B.MiError):      # the prover pool is a set of contexts: same hard failure, nothing leaked, no thread left behind
+        B.Prover(0, 3)
+    import ctypes as C
+    h = C.c_void_p()
+    assert B.load().mi_init_prio(0, 7, C.byref(h)) != 0 and not h.value          # unknown priority scheme
+    assert B.load().mi_prover_create(0, 0, C.byref(h)) != 0 and not h.value       # in_flight out of range
 
 
 def test_host_encoding_matches_oracle():
