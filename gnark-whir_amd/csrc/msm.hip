@@ -99,15 +99,23 @@ __device__ u32 block_exclusive_scan_first256(u32 v, u32 *lds, u32 *total) {
     __syncthreads();
     return incl - v;
 }
-static constexpr u32 MSM2_PART_THREADS = 512;   // one scalar per thread: 8 waves per workgroup hide the LDS-atomic latency of place/copy
+static constexpr u32 MSM2_PART_THREADS = MSM2_SLICE;   // one scalar per thread: 8 waves per workgroup hide the LDS-atomic latency of place/copy
 __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape s, const Fr *scalars, int montgomery, const u32 *S1, u32 cap,
                                                                       uint16_t *part_lo, u32 *part_val) {
     extern __shared__ u32 lds_u32[];
     u32 *hist = lds_u32, *loff = hist + s.ngroups, *gbase = loff + s.ngroups + 1, *tmp = gbase + s.ngroups, *stage_val = tmp + 256;
     uint16_t *stage_lo = (uint16_t *)(stage_val + cap);
     for (u32 g = threadIdx.x; g < s.ngroups; g += blockDim.x) hist[g] = 0;
+    // a slice has at most MSM2_SLICE = blockDim scalars: one per thread, loaded and made canonical once, kept in registers for
+    // both the count and the place phase
+    u32 begin, end;
+    msm2_slice_range(s, blockIdx.x, begin, end);
+    const u32 i = begin + threadIdx.x;
+    const bool have = i < end;
+    Msm2Digits dg;
+    if (have) dg.start(scalars[i], montgomery != 0);
     __syncthreads();
-    msm2_count_body(s, scalars, montgomery != 0, blockIdx.x, hist, threadIdx.x, blockDim.x);
+    if (have) msm2_count_one(s, dg, hist);
     __syncthreads();
     u32 carry = 0;
     for (u32 base = 0; base < s.ngroups; base += 256) {   // loff = exclusive scan of hist; hist becomes the cursor
@@ -120,7 +128,7 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
     }
     if (threadIdx.x == 0) loff[s.ngroups] = carry;
     __syncthreads();
-    msm2_stage_place_body(s, scalars, montgomery != 0, blockIdx.x, hist, stage_lo, stage_val, threadIdx.x, blockDim.x);
+    if (have) msm2_place_one(s, dg, i, hist, stage_lo, stage_val);
     __syncthreads();
     msm2_stage_copy_body(s, gbase, loff, stage_lo, stage_val, part_lo, part_val, threadIdx.x, blockDim.x);
 }

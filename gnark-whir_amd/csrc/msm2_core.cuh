@@ -58,16 +58,20 @@ struct Msm2Digits {
 };
 
 // ---- pass 1a: workgroup = slice g; LDS hist[ngroups]; C1[hi][g]
+// one scalar (already canonical in dg, restarted by the caller): its non-zero digits counted by group
+MI_HD void msm2_count_one(const Msm2Shape &s, Msm2Digits dg, u32 *lds) {
+    for (u32 w = 0; w < s.nwin; w++) {
+        int32_t d = dg.next(s);
+        if (d) MI_LDS_ATOMIC_ADD(&lds[((u32)(d < 0 ? -d : d) - 1) >> s.gbits], 1u);
+    }
+}
 MI_HD void msm2_count_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *lds, u32 tid, u32 nthr) {
     u32 begin, end;
     msm2_slice_range(s, g, begin, end);
     for (u32 i = begin + tid; i < end; i += nthr) {
         Msm2Digits dg;
         dg.start(scalars[i], montgomery);
-        for (u32 w = 0; w < s.nwin; w++) {
-            int32_t d = dg.next(s);
-            if (d) MI_LDS_ATOMIC_ADD(&lds[((u32)(d < 0 ? -d : d) - 1) >> s.gbits], 1u);
-        }
+        msm2_count_one(s, dg, lds);
     }
 }
 // ---- pass 1b: partition, staged through LDS so that the global stores are runs, not single entries.
@@ -75,6 +79,17 @@ MI_HD void msm2_count_body(const Msm2Shape &s, const Fr *scalars, bool montgomer
 // of the slice), cursor[hi] = loff[hi].  place: every entry goes to its group's run inside the LDS staging area;
 // copy: entry e of the staging area belongs to the group hi with loff[hi] <= e < loff[hi+1] and lands at
 // gbase[hi] + (e - loff[hi]), gbase[hi] = S1[hi * G + g]: consecutive e of a group are consecutive in part_lo / part_val.
+// one scalar i (canonical in dg): its entries go to their groups' runs of the staging area
+MI_HD void msm2_place_one(const Msm2Shape &s, Msm2Digits dg, u32 i, u32 *cursor, uint16_t *stage_lo, u32 *stage_val) {
+    for (u32 w = 0; w < s.nwin; w++) {
+        int32_t d = dg.next(s);
+        if (!d) continue;
+        u32 key = (u32)(d < 0 ? -d : d) - 1;
+        u32 pos = MI_LDS_ATOMIC_ADD(&cursor[key >> s.gbits], 1u);
+        stage_lo[pos] = (uint16_t)(key & (s.gsize - 1));
+        stage_val[pos] = (w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
+    }
+}
 MI_HD void msm2_stage_place_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *cursor, uint16_t *stage_lo, u32 *stage_val,
                                  u32 tid, u32 nthr) {
     u32 begin, end;
@@ -82,14 +97,7 @@ MI_HD void msm2_stage_place_body(const Msm2Shape &s, const Fr *scalars, bool mon
     for (u32 i = begin + tid; i < end; i += nthr) {
         Msm2Digits dg;
         dg.start(scalars[i], montgomery);
-        for (u32 w = 0; w < s.nwin; w++) {
-            int32_t d = dg.next(s);
-            if (!d) continue;
-            u32 key = (u32)(d < 0 ? -d : d) - 1;
-            u32 pos = MI_LDS_ATOMIC_ADD(&cursor[key >> s.gbits], 1u);
-            stage_lo[pos] = (uint16_t)(key & (s.gsize - 1));
-            stage_val[pos] = (w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
-        }
+        msm2_place_one(s, dg, i, cursor, stage_lo, stage_val);
     }
 }
 // gbase[hi] = S1[hi * G + g] (the slice's run of group hi in the partitioned arrays), loaded once per workgroup
