@@ -255,13 +255,21 @@ MI_HD void mac96_k(u64 &acc, u32 &c, u32 a, u32 k) {
     mac96(acc, c, a, k);
 #endif
 }
-// first product of a column: acc < 2^37 on entry, so the sum cannot wrap -> no carry word update
+// first product of a column, added without a carry-word update.  Only legal where the sum provably cannot wrap:
+// acc < 25 * 2^32 on entry, so the product must stay < 2^63 -- column 0 (acc = 0), m_(k-1)*p_1 in columns 1..7
+// (p_1 < 2^31 for both moduli), x_(k-7)*y_7 in columns >= 8 (top limb of any operand < 2p is < 2^31).  x_0*y_k is NOT
+// (round 1 used it: wrong products for limbs near 2^32, ~2^-60 per random product).  The host build of the tests
+// checks the no-wrap claim on every call (MI_CHECK_NOWRAP).
 MI_HD void mac96_first(u64 &acc, u32 a, u32 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     u64 cy;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=&s"(cy) : "v"(a), "v"(b));
 #else
-    acc += (u64)a * b;
+    u64 p = (u64)a * b;
+    acc += p;
+#if defined(MI_CHECK_NOWRAP)
+    if (acc < p) __builtin_trap();
+#endif
 #endif
 }
 
@@ -301,12 +309,13 @@ MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
     u32 m[8];
     Fe<P> r;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        mac96_first(acc, x.l[0], y.l[k]);
+    for (int k = 0; k < 8; k++) {   // same product order as the generated device columns (tools/gen_mont_cols.py)
+        if (k == 0) mac96_first(acc, x.l[0], y.l[0]);
+        else mac96_first(acc, m[k - 1], P::p[1]);
 #pragma unroll
-        for (int i = 1; i <= k; i++) mac96(acc, c, x.l[i], y.l[k - i]);
+        for (int i = k ? 0 : 1; i <= k; i++) mac96(acc, c, x.l[i], y.l[k - i]);
 #pragma unroll
-        for (int i = 0; i < k; i++) mac96_k(acc, c, m[i], P::p[k - i]);
+        for (int i = 0; i + 1 < k; i++) mac96_k(acc, c, m[i], P::p[k - i]);
         m[k] = (u32)acc * P::inv;
         mac96_k(acc, c, m[k], P::p[0]);
         acc = (acc >> 32) | ((u64)c << 32);
@@ -362,10 +371,16 @@ MI_HD Fe<P> fe_mul2_add(const Fe<P> &x, const Fe<P> &y, const Fe<P> &u, const Fe
     u32 c = 0;
     u32 m[8];
     Fe<P> r;
-    for (int k = 0; k < 15; k++) {
+    for (int k = 0; k < 15; k++) {   // first (carry-less) product of each column as on the device, see mac96_first
         int lo = k > 7 ? k - 7 : 0, hi = k < 7 ? k : 7;
-        for (int i = lo; i <= hi; i++) { mac96(acc, c, x.l[i], y.l[k - i]); mac96(acc, c, u.l[i], v.l[k - i]); }
-        for (int i = lo; i <= (k < 8 ? k - 1 : 7); i++) mac96(acc, c, m[i], P::p[k - i]);
+        if (k == 0) mac96_first(acc, x.l[0], y.l[0]);
+        else if (k < 8) mac96_first(acc, m[k - 1], P::p[1]);
+        else mac96_first(acc, x.l[k - 7], y.l[7]);
+        for (int i = lo; i <= hi; i++) {
+            if (!(k == 0 || (k >= 8 && i == lo))) mac96(acc, c, x.l[i], y.l[k - i]);
+            mac96(acc, c, u.l[i], v.l[k - i]);
+        }
+        for (int i = lo; i <= (k < 8 ? k - 2 : 7); i++) mac96(acc, c, m[i], P::p[k - i]);
         if (k < 8) { m[k] = (u32)acc * P::inv; mac96(acc, c, m[k], P::p[0]); } else r.l[k - 8] = (u32)acc;
         acc = (acc >> 32) | ((u64)c << 32);
         c = 0;

@@ -96,7 +96,10 @@ __global__ void k_field_op(int op, Fe<P> *z, const Fe<P> *x, const Fe<P> *y, siz
     case 2: r = a * b; break;
     case 3: r = fe_inv(a); break;
     case 4: r = fe_to_mont(a); break;
-    default: r = fe_from_mont(a); break;
+    case 5: r = fe_from_mont(a); break;
+    case 6: r = fe_mul2_add(a, b, b, a); break;   // 2ab/R   (dual-product columns)
+    case 7: r = fe_mul_sub(a, b, b, b); break;    // (ab - b^2)/R
+    default: r = fe_sqr(a); break;
     }
     z[i] = r;
 }
@@ -187,7 +190,7 @@ int32_t mi_gen_g2_dev(mi_ctx *ctx, mi_g2_affine *out_dev, size_t n, uint64_t see
     return MI_OK;
 }
 int32_t mi_field_op_dev(mi_ctx *ctx, int field, int op, void *z, const void *x, const void *y, size_t n) {
-    if (!ctx || op < 0 || op > 5 || field < 0 || field > 1 || ((!z || !x) && n)) return MI_EINVAL;
+    if (!ctx || op < 0 || op > 8 || field < 0 || field > 1 || ((!z || !x) && n)) return MI_EINVAL;
     if (!n) return MI_OK;
     if (field == 0) hipLaunchKernelGGL(k_field_op<FrParams>, dim3(grid_for(n, 128)), dim3(128), 0, ctx->stream, op, (Fr *)z, (const Fr *)x, (const Fr *)y, n);
     else hipLaunchKernelGGL(k_field_op<FpParams>, dim3(grid_for(n, 128)), dim3(128), 0, ctx->stream, op, (Fp *)z, (const Fp *)x, (const Fp *)y, n);

@@ -247,7 +247,8 @@ int32_t mi_gen_scalars_dev(mi_ctx *ctx, mi_fr *out_dev, size_t n, uint64_t seed,
 int32_t mi_gen_g1_dev(mi_ctx *ctx, mi_g1_affine *out_dev, size_t n, uint64_t seed);
 int32_t mi_gen_g2_dev(mi_ctx *ctx, mi_g2_affine *out_dev, size_t n, uint64_t seed);
 /* elementwise field ops for parity tests of the device field layer:
- * field: 0 = Fr, 1 = Fp; op: 0 add, 1 sub, 2 mul, 3 inv(x), 4 to_mont(x), 5 from_mont(x) */
+ * field: 0 = Fr, 1 = Fp; op: 0 add, 1 sub, 2 mul, 3 inv(x), 4 to_mont(x), 5 from_mont(x),
+ * 6 (xy + yx)/R and 7 (xy - yy)/R through the dual-product multiplier, 8 x^2 */
 int32_t mi_field_op_dev(mi_ctx *ctx, int field, int op, void *z_dev, const void *x_dev,
                         const void *y_dev, size_t n);
 /* out[i] = a[i] + b[i] on G1 (affine in, affine out; exercises add/double/inf cases) */

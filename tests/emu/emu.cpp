@@ -15,6 +15,9 @@ static void field_op(int op, Fe<P> *z, const Fe<P> *x, const Fe<P> *y, size_t n)
         case 4: z[i] = fe_to_mont(x[i]); break;
         case 5: z[i] = fe_from_mont(x[i]); break;
         case 6: z[i] = fe_neg(x[i]); break;
+        case 7: z[i] = fe_mul2_add(x[i], y[i], y[i], x[i]); break;            // 2xy/R
+        case 8: z[i] = fe_mul_sub(x[i], y[i], y[i], y[i]); break;             // (xy - y^2)/R
+        case 9: z[i] = fe_sqr(x[i]); break;
         }
     }
 }

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def emu():
     so = os.path.join(HERE, "emu", "libemu.so")
     src = os.path.join(HERE, "emu", "emu.cpp")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DMI_CHECK_NOWRAP", "-shared", "-fPIC", "-o", so, src])
     return C.CDLL(so)
 
 
@@ -38,6 +38,52 @@ def test_field_ops_bit_exact(emu):
         Z = np.zeros_like(X)
         emu.emu_field_op(field, 6, _p(Z), _p(X), _p(Y), C.c_size_t(len(xs)))
         assert np.array_equal(Z, cref.field_op(field, 1, np.zeros_like(X), X))
+
+
+def adversarial_mont_pairs(mod, seed, n_per=40):
+    """Raw Montgomery-form residues (< mod) whose 32-bit limbs hit 0xFFFFFFFF where a column's first product sits:
+    x.l[0] and y.l[k], k = 1..6 -- the vectors that broke round 1's carry-less first product (field.cuh:259)
+    -- plus all-ones low limbs on both sides."""
+    rng = P.SplitMix64(seed)
+    xs, ys = [], []
+    top = mod >> 224
+    def rnd():
+        v = rng.fr()
+        return (v & ((1 << 224) - 1)) | ((rng.next() % top) << 224)
+    for k in range(1, 7):
+        for _ in range(n_per):
+            x = rnd() | 0xFFFFFFFF
+            y = rnd() | (0xFFFFFFFF << (32 * k))
+            xs += [x, y]; ys += [y, x]
+    for _ in range(n_per):
+        x = rnd() | ((1 << 224) - 1); y = rnd() | ((1 << 224) - 1)
+        xs.append(x); ys.append(y)
+    assert all(v < mod for v in xs + ys)
+    return xs, ys
+
+
+def raw_arr(vals):
+    return np.array([cref.int_to_limbs(v) for v in vals], dtype=np.uint64).reshape(-1, 4)
+
+
+def test_montgomery_product_carry_edge_limbs(emu):
+    """operator*, fe_mul2_add, fe_mul_sub, fe_sqr on limbs of 0xFFFFFFFF against Python big integers (and the C oracle):
+    every product is x*y/R mod p exactly; the emu build traps if a carry-less first product ever wraps."""
+    Rinv = {P.R_MOD: pow(1 << 256, -1, P.R_MOD), P.Q_MOD: pow(1 << 256, -1, P.Q_MOD)}
+    for field, mod in ((0, P.R_MOD), (1, P.Q_MOD)):
+        xs, ys = adversarial_mont_pairs(mod, 77 + field)
+        X, Y = raw_arr(xs), raw_arr(ys)
+        ri = Rinv[mod]
+        want = {2: [x * y * ri % mod for x, y in zip(xs, ys)],
+                7: [2 * x * y * ri % mod for x, y in zip(xs, ys)],
+                8: [(x * y - y * y) * ri % mod for x, y in zip(xs, ys)],
+                9: [x * x * ri % mod for x in xs]}
+        for op, w in want.items():
+            Z = np.zeros_like(X)
+            emu.emu_field_op(field, op, _p(Z), _p(X), _p(Y), C.c_size_t(len(xs)))
+            got = [cref.limbs_to_int(r) for r in Z]
+            assert got == w, (field, op, sum(a != b for a, b in zip(got, w)))
+        assert np.array_equal(cref.field_op(field, 2, X, Y), raw_arr(want[2]))
 
 
 def test_curve_ops_bit_exact(emu):

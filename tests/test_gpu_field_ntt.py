@@ -34,6 +34,24 @@ def test_field_ops_bit_exact(ctx):
     assert np.array_equal(ctx.field_op(1, 2, X, Y), cref.field_op(1, 2, X, Y))
 
 
+def test_montgomery_product_carry_edge_limbs(ctx):
+    """Device multiplier (generated per-column asm, single and dual-product) on Montgomery residues with limbs of
+    0xFFFFFFFF where a column's first product sits -- the case round 1's carry-less first product got wrong
+    (field.cuh:259) -- against Python big integers."""
+    from test_device_headers_on_host import adversarial_mont_pairs, raw_arr
+    for field, mod in ((0, P.R_MOD), (1, P.Q_MOD)):
+        xs, ys = adversarial_mont_pairs(mod, 77 + field, n_per=200)
+        X, Y = raw_arr(xs), raw_arr(ys)
+        ri = pow(1 << 256, -1, mod)
+        want = {2: [x * y * ri % mod for x, y in zip(xs, ys)],
+                6: [2 * x * y * ri % mod for x, y in zip(xs, ys)],
+                7: [(x * y - y * y) * ri % mod for x, y in zip(xs, ys)],
+                8: [x * x * ri % mod for x in xs]}
+        for op, w in want.items():
+            got = [cref.limbs_to_int(r) for r in ctx.field_op(field, op, X, Y)]
+            assert got == w, (field, op, sum(a != b for a, b in zip(got, w)))
+
+
 def test_generators_match_oracle(ctx):
     n = 3000
     for dist in (0, 1):
