@@ -18,6 +18,7 @@ struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, 
     DevBuf buf[14];
     void *host_wsum = nullptr;
     uint32_t n = 0, c = 0, G = 0;
+    uint64_t stat_pairs = 0;    // (point, scalar) pairs this MSM really has (A and K run over per-wire expanded arrays with holes)
     uint32_t nwin_keys = 0;     // windows in the key space: ceil(256/c) for the generic MSM, 1 for the fixed-base one
     uint32_t nwin_digits = 0;   // digits per scalar = ceil(256/c)
     bool active = false, timed = false;
@@ -91,7 +92,7 @@ void mi_msm_state_free(mi_ctx *ctx);
 // returns the XYZZ result on the host.
 // precomp_c != 0: pts_dev holds the fixed-base window copies [ceil(256/c)][n] built by mi_msm_precompute (msm2_core.cuh).
 int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
-                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c = 0);
+                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c = 0, size_t stat_pairs = 0);
 // pre[w][i] = 2^(c*w) * base[i] for w < ceil(256/c) (affine), on ctx->stream.  pre must hold ceil(256/c) * n points.
 int32_t mi_msm_precompute(mi_ctx *ctx, int curve, const void *base_dev, void *pre_dev, size_t n, uint32_t c);
 int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host);

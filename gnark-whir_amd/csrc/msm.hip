@@ -523,7 +523,7 @@ static int32_t msm_finish(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, void
         float ms = 0;
         MI_CHECK_HIP(ctx, hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]));
         ctx->stats.g1_accum_kernel_ms += ms;
-        ctx->stats.g1_accum_pairs += sl.n;
+        ctx->stats.g1_accum_pairs += sl.stat_pairs;
         ctx->stats.g1_accum_launches += 1;
         ctx->stats.g1_accum_entries += *(const u32 *)((const char *)sl.host_wsum + 128 * 256);
     }
@@ -540,11 +540,12 @@ int32_t mi_msm_precompute(mi_ctx *ctx, int curve, const void *base_dev, void *pr
     return MI_OK;
 }
 int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
-                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c) {
+                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c, size_t stat_pairs) {
     if (slot < 0 || slot >= MI_MSM_SLOTS || sort_slot >= MI_MSM_SLOTS) return MI_EINVAL;
     if (n > ((size_t)1 << 27)) MI_FAIL(ctx, MI_EINVAL, "msm: n > 2^27 pairs per device not supported (shard the points)");
     MsmSlot &sl = ctx->msm[slot];
     sl.active = false;
+    sl.stat_pairs = stat_pairs ? stat_pairs : n;
     if (n == 0) return MI_OK;
     if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));

@@ -8,8 +8,16 @@
 // proof's head and tail with the bulk of another.  The proving key is read-only during prove and is shared.
 // The contexts' stream priorities are staggered (ctx.h MI_PRIO_*): the first context's proof runs nearly as if alone, the
 // others fill what it leaves.  Measured at N = 2^23 (WHIR mix): DESIGN.md 4 / 5.
+//
+// Host inputs (mi_prover_submit, the cgo path: W, a, b, c live in Go memory, mt.go:494-496) go through an UPLOAD STAGE of
+// their own: one uploader thread with its own copy stream moves the next job's four vectors into one of in_flight + 1
+// device input sets while the compute workers are busy with earlier proofs, and only then queues the job for a worker,
+// which runs the device-pointer path.  A copy from pageable memory holds the calling thread for its whole duration
+// (20 ms per 1.07 GB proof at N = 2^23): done by the worker itself (round 1) it lengthened every context's cycle and cost
+// 13 % of the throughput; on the uploader it overlaps the previous proofs' kernels.
 #include <hip/hip_runtime.h>
 #include "ctx.h"
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -28,8 +36,15 @@ struct Job {
     mi_proof_out *out = nullptr;
     mi_stats *stats = nullptr;
     int32_t rc = MI_OK;
-    bool done = false;
+    bool done = false, waited = false;
+    int set = -1;          // device input set a host job was staged into (released when the proof is done)
+    float h2d_ms = 0;      // wall-clock of the staging copies
     std::string err;
+};
+struct InputSet {          // W | a | b | c of one staged host job
+    void *p = nullptr;
+    size_t cap = 0;
+    bool busy = false;
 };
 }  // namespace
 
@@ -37,14 +52,30 @@ struct mi_prover {
     int dev = 0;
     std::vector<mi_ctx *> ctx;
     std::vector<std::thread> workers;
+    std::thread uploader;
+    hipStream_t copy_stream = nullptr;
+    std::vector<InputSet> sets;                 // in_flight + 1: one being filled while in_flight are being consumed
     std::mutex m;
-    std::condition_variable cv_work, cv_done;
-    std::deque<Job *> queue;
+    std::condition_variable cv_work, cv_done, cv_up;
+    std::deque<Job *> upq;                      // host jobs waiting for the upload stage
+    std::deque<Job *> queue;                    // jobs whose inputs are in HBM
     std::unordered_map<uint64_t, Job *> jobs;   // submitted, not yet collected by mi_prover_wait
     uint64_t next_id = 1;
-    bool stop = false;
+    bool stop = false, uploading = false;
     std::string err;
 };
+
+static void finish_job(mi_prover *p, Job *j, int32_t rc, const char *err) {
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        j->rc = rc;
+        if (rc != MI_OK) j->err = err ? err : "";
+        if (j->set >= 0) { p->sets[j->set].busy = false; j->set = -1; }
+        j->done = true;
+    }
+    p->cv_up.notify_all();
+    p->cv_done.notify_all();
+}
 
 static void worker_main(mi_prover *p, mi_ctx *ctx) {
     (void)hipSetDevice(p->dev);   // the current device is per host thread
@@ -52,20 +83,78 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
         Job *j;
         {
             std::unique_lock<std::mutex> lk(p->m);
-            p->cv_work.wait(lk, [&] { return p->stop || !p->queue.empty(); });
-            if (p->queue.empty()) return;   // stop requested and nothing left to run
+            // leave only when the upload stage can hand over nothing more either
+            p->cv_work.wait(lk, [&] { return !p->queue.empty() || (p->stop && p->upq.empty() && !p->uploading); });
+            if (p->queue.empty()) return;
             j = p->queue.front();
             p->queue.pop_front();
         }
-        int32_t rc = j->host ? mi_groth16_prove(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats)
-                             : mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
+        int32_t rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
+        if (rc == MI_OK && j->host && j->stats) j->stats->h2d_ms = j->h2d_ms;
+        finish_job(p, j, rc, rc != MI_OK ? mi_last_error(ctx) : nullptr);
+    }
+}
+
+// upload stage: host job -> device input set -> compute queue
+static void uploader_main(mi_prover *p) {
+    (void)hipSetDevice(p->dev);
+    for (;;) {
+        Job *j;
+        int si = -1;
+        {
+            std::unique_lock<std::mutex> lk(p->m);
+            p->cv_up.wait(lk, [&] {
+                if (p->upq.empty()) return p->stop;
+                for (size_t i = 0; i < p->sets.size(); i++) if (!p->sets[i].busy) return true;
+                return false;
+            });
+            if (p->upq.empty()) { lk.unlock(); p->cv_work.notify_all(); return; }
+            j = p->upq.front();
+            p->upq.pop_front();
+            for (size_t i = 0; i < p->sets.size(); i++) if (!p->sets[i].busy) { si = (int)i; break; }
+            p->sets[si].busy = true;
+            p->uploading = true;
+            j->set = si;
+        }
+        InputSet &set = p->sets[si];
+        const size_t wb = j->n_wires * sizeof(mi_fr), cb = j->n_constraints * sizeof(mi_fr), need = wb + 3 * cb + 128;
+        hipError_t e = hipSuccess;
+        const char *what = "";
+        if (need > set.cap) {   // grow-only, like every other workspace: no hipMalloc in steady state
+            if (set.p) { (void)hipFree(set.p); set.p = nullptr; set.cap = 0; }
+            e = hipMalloc(&set.p, need + need / 8);
+            what = "prover: hipMalloc of a device input set";
+            if (e == hipSuccess) set.cap = need + need / 8;
+        }
+        char *base = (char *)set.p;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (e == hipSuccess) {
+            what = "prover: upload of W, a, b, c";
+            if (wb) e = hipMemcpyAsync(base, j->W, wb, hipMemcpyHostToDevice, p->copy_stream);
+            if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb, j->a, cb, hipMemcpyHostToDevice, p->copy_stream);
+            if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + cb, j->b, cb, hipMemcpyHostToDevice, p->copy_stream);
+            if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + 2 * cb, j->c, cb, hipMemcpyHostToDevice, p->copy_stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(p->copy_stream);   // the job is handed over with its inputs resident
+        }
+        j->h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+            {
+                std::lock_guard<std::mutex> lk(p->m);
+                p->uploading = false;
+            }
+            finish_job(p, j, e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, msg.c_str());
+            p->cv_work.notify_all();
+            continue;
+        }
         {
             std::lock_guard<std::mutex> lk(p->m);
-            j->rc = rc;
-            if (rc != MI_OK) j->err = mi_last_error(ctx);
-            j->done = true;
+            j->W = (const mi_fr *)base; j->a = (const mi_fr *)(base + wb); j->b = (const mi_fr *)(base + wb + cb); j->c = (const mi_fr *)(base + wb + 2 * cb);
+            p->queue.push_back(j);
+            p->uploading = false;
         }
-        p->cv_done.notify_all();
+        p->cv_work.notify_all();
     }
 }
 
@@ -87,7 +176,16 @@ int32_t mi_prover_create(int device_id, uint32_t in_flight, mi_prover **out) {
         }
         p->ctx.push_back(c);
     }
+    (void)hipSetDevice(device_id);
+    if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        for (mi_ctx *q : p->ctx) mi_shutdown(q);
+        delete p;
+        return MI_EHIP;
+    }
+    p->sets.resize(in_flight + 1);
     for (mi_ctx *c : p->ctx) p->workers.emplace_back(worker_main, p, c);
+    p->uploader = std::thread(uploader_main, p);
     *out = p;
     return MI_OK;
 }
@@ -98,9 +196,15 @@ int32_t mi_prover_destroy(mi_prover *p) {
         std::lock_guard<std::mutex> lk(p->m);
         p->stop = true;   // queued jobs still run: their callers may be blocked in mi_prover_wait
     }
+    p->cv_up.notify_all();
     p->cv_work.notify_all();
+    p->uploader.join();
     for (auto &t : p->workers) t.join();
+    // every job has run by now and nothing references a caller's W/a/b/c/out/stats any more; tickets nobody waited on
+    // are dropped here (waiting on a destroyed pool is the caller's bug, like any use after free)
     (void)hipSetDevice(p->dev);
+    for (InputSet &s : p->sets) if (s.p) (void)hipFree(s.p);
+    if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     for (mi_ctx *c : p->ctx) mi_shutdown(c);
     for (auto &kv : p->jobs) delete kv.second;
     delete p;
@@ -111,13 +215,15 @@ uint32_t mi_prover_in_flight(const mi_prover *p) { return p ? (uint32_t)p->ctx.s
 mi_ctx *mi_prover_ctx(mi_prover *p, uint32_t i) { return p && i < p->ctx.size() ? p->ctx[i] : nullptr; }
 const char *mi_prover_last_error(mi_prover *p) {
     if (!p) return "null prover";
+    static thread_local std::string copy;   // the caller's own copy: p->err may change under another thread's wait
     std::lock_guard<std::mutex> lk(p->m);
-    return p->err.c_str();   // stable until the next failing mi_prover_wait on this pool
+    copy = p->err;
+    return copy.c_str();   // valid until this thread's next mi_prover_last_error
 }
 
 static int32_t submit(mi_prover *p, bool host, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                       size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket) {
-    if (!p || !pk || !r || !s || !out || !ticket) return MI_EINVAL;
+    if (!p || !pk || !r || !s || !out || !ticket || !W || !a || !b || !c) return MI_EINVAL;
     Job *j = new (std::nothrow) Job();
     if (!j) return MI_ENOMEM;
     j->host = host; j->pk = pk; j->W = W; j->a = a; j->b = b; j->c = c;
@@ -129,10 +235,10 @@ static int32_t submit(mi_prover *p, bool host, mi_pk *pk, const mi_fr *W, size_t
         if (p->stop) { delete j; return MI_EINVAL; }
         j->id = p->next_id++;
         p->jobs[j->id] = j;
-        p->queue.push_back(j);
+        (host ? p->upq : p->queue).push_back(j);
         *ticket = j->id;
     }
-    p->cv_work.notify_one();
+    if (host) p->cv_up.notify_one(); else p->cv_work.notify_one();
     return MI_OK;
 }
 
@@ -152,6 +258,8 @@ int32_t mi_prover_wait(mi_prover *p, uint64_t ticket) {
     auto it = p->jobs.find(ticket);
     if (it == p->jobs.end()) { p->err = "prover: unknown ticket"; return MI_EINVAL; }
     Job *j = it->second;
+    if (j->waited) { p->err = "prover: ticket is already being waited on"; return MI_EINVAL; }   // each ticket: exactly one waiter
+    j->waited = true;
     p->cv_done.wait(lk, [&] { return j->done; });
     int32_t rc = j->rc;
     if (rc != MI_OK) p->err = j->err;

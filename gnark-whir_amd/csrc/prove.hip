@@ -285,11 +285,11 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
         // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
         if (pk->pre_a) {
-            MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->pre_a, W, pk->nb_wires, 0, ev[2], true, pk->c_ak));
-            return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, 0, nullptr, true, pk->c_ak);
+            MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->pre_a, W, pk->nb_wires, 0, ev[2], true, pk->c_ak, pk->n_a));
+            return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, 0, nullptr, true, pk->c_ak, pk->n_k);
         }
-        MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, 0, ev[2], true));
-        return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, 0, nullptr, true);
+        MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, 0, ev[2], true, 0, pk->n_a));
+        return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, 0, nullptr, true, 0, pk->n_k);
     };
     // Stream plan: computeH on the caller's stream; MSM A, B1, B2, K, Z on slots 0..4 (own streams).  The latency-bound
     // tails (levels >= 2, bucket reduce, scans) of one MSM overlap the throughput-bound accumulation of the others.
