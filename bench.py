@@ -56,6 +56,62 @@ def cpu_baseline(pk_host, W, a, b, c, r, s, log_n, gpu_proof_bytes):
             "proof_bytes_match": True}
 
 
+def _guard(result, fn, *a):
+    try:
+        fn(*a)
+    except BaseException as e:   # reported in the line, never fatal for the proofs/s measurement
+        result["error"] = f"{type(e).__name__}: {e}"
+
+
+def sharded_msm_section(B, torch, dist, rank, local_rank, world, log_n_msm, steps, result):
+    """BASELINE configs[4]: ONE G1 MSM of 2^log_n_msm pairs, bases point-sharded over the ranks (one per GPU), through the C-ABI's
+    device group (mi_group_create_rank + mi_msm_g1_sharded_dev, csrc/group.hip): mode 0 = all-gather of per-rank partial sums,
+    mode 1 = reduce-scatter of bucket sums (grouped ncclSend / ncclRecv) before the bucket reduce.  Strong scaling: total work
+    fixed.  Fills `result` (a dict) in place so that a watchdog can give up on it."""
+    import numpy as np
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        uid = torch.tensor(list(B.Group.unique_id()), dtype=torch.uint8)
+    if dist is not None:
+        dev = torch.device("cuda", local_rank)
+        t = uid.to(dev); dist.broadcast(t, src=0); uid = t.cpu()
+    g = B.Group.rank(local_rank, rank, world, bytes(uid.tolist()))
+    try:
+        n = 1 << log_n_msm
+        lo, hi = B.shard_range(n, world, rank)
+        c = g.ctx(0)
+        pts = c.gen_g1(hi - lo, 4242 + 17 * rank); sc = c.gen_scalars(hi - lo, 2424 + 17 * rank, 0)
+        c.sync()
+        out = {}
+        for mode in (0, 1):
+            ref = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)   # warm-up: sizes the workspaces
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                got = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([dt], device=torch.device("cuda", local_rank), dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            assert np.array_equal(got, ref)
+            out[mode] = (got, dt)
+        agree = bool(np.array_equal(out[0][0], out[1][0]))
+        result.update({"workload": f"one G1 MSM, 2^{log_n_msm} uniform pairs, bases point-sharded over {world} rank(s) (BASELINE configs[4])",
+                       "scaling": "strong", "transport": g.transport(), "steps": steps,
+                       "mode0_partial_sums_pts_per_s": n * steps / out[0][1], "mode0_ms": out[0][1] / steps * 1e3,
+                       "mode1_bucket_exchange_pts_per_s": n * steps / out[1][1], "mode1_ms": out[1][1] / steps * 1e3,
+                       "modes_agree": agree, "done": True})
+        pts.free(); sc.free()
+    finally:
+        g.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +129,7 @@ def main():
     ap.add_argument("--ntt-plan", default="", help="tuning: log_e,max_contig,max_strided[,threads] for mi_debug_set_ntt_plan / _threads on every context")
     ap.add_argument("--msm-group-bits", type=int, default=0, help="tuning: mi_debug_set_msm_group_bits on every context")
     ap.add_argument("--msm-chunk", type=int, default=0, help="tuning: mi_debug_set_msm_chunk on every context")
+    ap.add_argument("--sharded-msm-log-n", type=int, default=26, help="configs[4]: size of the point-sharded G1 MSM run after the proofs (0 = skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank control-flow rehearsal on a 1-GPU box: every rank uses device 0 and the collectives run over gloo")
     args = ap.parse_args()
@@ -212,6 +269,18 @@ def main():
                 raise SystemExit("bench.py: a host-input proof differs from the device-input proof of the same inputs")
         host_rate, host_ms = args.steps * world / dth, dth / args.steps * 1e3
 
+    # configs[4]: one G1 MSM point-sharded over the ranks through the C-ABI's device group (RCCL).  Bounded by a watchdog: a
+    # stuck collective must not cost the run its proofs/s line.
+    sharded = {"done": False}
+    if args.sharded_msm_log_n and not args.rehearse_on_one_gpu:
+        import threading
+        th = threading.Thread(target=lambda: _guard(sharded, sharded_msm_section, B, torch, dist, rank, local_rank, world,
+                                                    args.sharded_msm_log_n, 3, sharded), daemon=True)
+        th.start()
+        th.join(timeout=150)
+        if th.is_alive():
+            sharded["error"] = "timeout after 150 s (collective stuck?)"
+
     # the same kernel measured alone (no other stream competing for the CUs): one uniform-scalar G1 MSM over pk.G1.Z
     solo = None
     if rank == 0:
@@ -263,6 +332,8 @@ def main():
             "single_proof_latency_ms": serial_ms,
             # PCIe-inclusive: the same K steps with W, a, b, c handed over as host pointers (the cgo path); proofs byte-equal
             "value_host_inputs": host_rate, "ms_per_step_host_inputs": host_ms,
+            # BASELINE configs[4] (one MSM point-sharded over the ranks, strong scaling); n_gpus = 1: the same code path with one rank
+            "sharded_msm": sharded,
             "proofs_validated": f"{len(timed_proofs)} timed + {0 if host_rate is None else args.steps} host-input proofs byte-equal to the untimed serial proof",
             "pk_load_s": t_load,
             "hbm_in_use_gb": (lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info()),
@@ -295,6 +366,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pk_host, dl(W, nb_wires, 4), dl(a, n_constraints, 4), dl(b, n_constraints, 4),
                                                 dl(c, n_constraints, 4), rs[0], rs[1], log_n, serial_bytes)
         print(json.dumps(line), flush=True)
+    if sharded.get("error", "").startswith("timeout"):
+        os._exit(0)   # a rank is stuck inside a collective: do not wait for it in destroy_process_group
     if dist is not None:
         dist.destroy_process_group()
     ctx.pk_free(pkh)

@@ -24,9 +24,12 @@ EXPORTS = [
     "mi_msm_precompute_g1_dev", "mi_msm_precompute_g2_dev", "mi_msm_g1_fixed_dev", "mi_msm_g2_fixed_dev",
     "mi_batch_scalar_mul_g1", "mi_batch_scalar_mul_g1_dev", "mi_batch_scalar_mul_g2", "mi_batch_scalar_mul_g2_dev",
     "mi_pedersen_pk_load", "mi_pedersen_pk_free", "mi_pedersen_commit", "mi_pedersen_prove_knowledge", "mi_pedersen_fold",
-    "mi_debug_set_prove_fixed_base", "mi_debug_set_msm_group_bits",
+    "mi_debug_set_prove_fixed_base", "mi_debug_set_msm_group_bits", "mi_debug_inject_hip_failure",
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
     "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait",
+    "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
+    "mi_group_last_error", "mi_group_transport", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
+    "mi_groth16_prove_sharded", "mi_msm_g1_sharded", "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
 ]
 
 
@@ -69,6 +72,8 @@ def load():
         _LIB.mi_prover_last_error.restype = C.c_char_p
         _LIB.mi_prover_ctx.restype = C.c_void_p
         _LIB.mi_prover_in_flight.restype = C.c_uint32
+        _LIB.mi_group_ctx.restype = C.c_void_p
+        _LIB.mi_group_last_error.restype = C.c_char_p
     return _LIB
 
 
@@ -354,6 +359,113 @@ class Prover:
     def close(self):
         if self.h:
             self.lib.mi_prover_destroy(self.h)
+            self.h = None
+
+
+def shard_range(total, world, rank):
+    """slice [lo, hi) of rank `rank`: the same cut as the library's (csrc/group.hip range_of)"""
+    return total * rank // world, total * (rank + 1) // world
+
+
+def _fill_pk_desc(pk: dict):
+    """whole-key descriptor over HOST arrays (mi_pk_load / mi_pk_load_sharded)"""
+    d = PkDesc(); keep = []
+    d.log_n, d.nb_public, d.nb_wires = pk["log_n"], pk["nb_public"], pk["nb_wires"]
+    for name in ("g1_a", "g1_b", "g1_k", "g1_z", "g2_b"):
+        arr = _u64(pk[name]); keep.append(arr)
+        setattr(d, name, arr.ctypes.data); setattr(d, "n_" + name, arr.shape[0])
+    for name, k in (("alpha1", 8), ("beta1", 8), ("delta1", 8), ("beta2", 16), ("delta2", 16)):
+        setattr(d, name, (C.c_uint64 * k)(*[int(v) for v in _u64(pk[name]).reshape(-1)]))
+    ia = np.ascontiguousarray(pk["infinity_a"], dtype=np.uint8); ib = np.ascontiguousarray(pk["infinity_b"], dtype=np.uint8)
+    keep += [ia, ib]
+    d.infinity_a, d.infinity_b = ia.ctypes.data, ib.ctypes.data
+    cw = pk.get("committed_wires")
+    if cw is not None and len(cw):
+        cw = np.ascontiguousarray(cw, dtype=np.uint32); keep.append(cw)
+        d.committed_wires, d.n_committed = cw.ctypes.data, cw.shape[0]
+    return d, keep
+
+
+class Group:
+    """Several GPUs behind one handle (mi_group_*, include/mi355x_groth16.h): the point-sharded prove and MSM of SURVEY 8e.
+    Group([0, 1, ...]) = all ranks in this process (what a Go caller uses); Group.rank(dev, rank, world, id) = one rank per
+    process (torch.distributed.run): the 128-byte id comes from Group.unique_id() on rank 0 through the caller's own channel."""
+
+    def __init__(self, dev_ids=None, _h=None):
+        self.lib = load()
+        if _h is not None:
+            self.h = _h
+        else:
+            arr = (C.c_int * len(dev_ids))(*dev_ids); h = C.c_void_p()
+            rc = self.lib.mi_group_create(arr, C.c_int(len(dev_ids)), C.byref(h))
+            if rc != 0:
+                raise MiError(f"mi_group_create failed: {rc} (no gfx950 device? the product has no CPU path)")
+            self.h = h
+        self.world = int(self.lib.mi_group_world(self.h)); self.n_local = int(self.lib.mi_group_local(self.h))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        if load().mi_group_unique_id(buf) != 0:
+            raise MiError("mi_group_unique_id failed")
+        return bytes(buf)
+
+    @classmethod
+    def rank(cls, device_id, rank, world, uid: bytes):
+        h = C.c_void_p(); buf = (C.c_uint8 * 128)(*uid)
+        rc = load().mi_group_create_rank(C.c_int(device_id), C.c_int(rank), C.c_int(world), buf, C.byref(h))
+        if rc != 0:
+            raise MiError(f"mi_group_create_rank failed: {rc}")
+        return cls(_h=h)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise MiError(f"rc={rc}: {self.lib.mi_group_last_error(self.h).decode()}")
+
+    def ctx(self, i=0) -> "Context":
+        p = self.lib.mi_group_ctx(self.h, C.c_int(i))
+        if not p:
+            raise MiError("mi_group_ctx: index out of range")
+        return Context(_borrowed=p)
+
+    def transport(self):
+        return {1: "rccl", 2: "peer-copy"}[int(self.lib.mi_group_transport(self.h))]
+
+    def exchange_selftest(self, nbytes=4096):
+        self._ck(self.lib.mi_group_exchange_selftest(self.h, C.c_size_t(nbytes)))
+
+    def pk_load(self, pk: dict):
+        d, keep = _fill_pk_desc(pk); h = C.c_void_p()
+        self._ck(self.lib.mi_pk_load_sharded(self.h, C.byref(d), C.byref(h)))
+        return h
+
+    def pk_free(self, spk):
+        self._ck(self.lib.mi_pk_sharded_free(self.h, spk))
+
+    def prove(self, spk, W, a, b, c, r, s, mode=0):
+        out = np.zeros(32, np.uint64); st = Stats()
+        W, a, b, c, r, s = (_u64(x) for x in (W, a, b, c, r, s))
+        self._ck(self.lib.mi_groth16_prove_sharded(self.h, spk, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c), C.c_size_t(a.shape[0]),
+                                                   _p(r), _p(s), C.c_uint32(mode), _p(out), C.byref(st)))
+        return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
+
+    def msm_g1(self, pts, sc, flags=0, mode=0):
+        out = np.zeros(12, np.uint64); pts, sc = _u64(pts), _u64(sc)
+        self._ck(self.lib.mi_msm_g1_sharded(self.h, _p(pts), _p(sc), C.c_size_t(pts.shape[0]), C.c_uint32(flags), C.c_uint32(mode), _p(out)))
+        return out
+
+    def msm_dev(self, pts_ptrs, sc_ptrs, n_local, n_total, flags=0, mode=0, g2=False):
+        """pairs already resident: one device pointer / count per LOCAL rank"""
+        k = len(n_local)
+        pp = (C.c_void_p * k)(*[int(p) for p in pts_ptrs]); ss = (C.c_void_p * k)(*[int(p) for p in sc_ptrs]); nn = (C.c_size_t * k)(*n_local)
+        out = np.zeros(24 if g2 else 12, np.uint64)
+        f = self.lib.mi_msm_g2_sharded_dev if g2 else self.lib.mi_msm_g1_sharded_dev
+        self._ck(f(self.h, pp, ss, nn, C.c_size_t(n_total), C.c_uint32(flags), C.c_uint32(mode), _p(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.mi_group_destroy(self.h)
             self.h = None
 
 

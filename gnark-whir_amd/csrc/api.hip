@@ -4,8 +4,11 @@
 #include "curve.cuh"
 #include <cstring>
 
+std::atomic<int> mi_fault_countdown{0};
+
 extern "C" {
 
+int32_t mi_debug_inject_hip_failure(int32_t nth) { mi_fault_countdown.store(nth > 0 ? nth : 0); return MI_OK; }
 int32_t mi_init(int device_id, mi_ctx **out) { return mi_init_prio(device_id, MI_PRIO_SOLO, out); }
 int32_t mi_init_prio(int device_id, int prio_scheme, mi_ctx **out) {
     if (!out || prio_scheme < MI_PRIO_SOLO || prio_scheme > MI_PRIO_POOL_REST) return MI_EINVAL;
@@ -27,25 +30,27 @@ int32_t mi_init_prio(int device_id, int prio_scheme, mi_ctx **out) {
         int ph = prio_hi;   // MI_PRIO_SOLO, MI_PRIO_POOL_FIRST
         if (prio_scheme == MI_PRIO_POOL_SECOND) ph = 0;
         if (prio_scheme == MI_PRIO_POOL_REST) ph = prio_lo;
-        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ph) != hipSuccess) { delete ctx; return MI_EHIP; }
+        if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ph) != hipSuccess) { (void)hipGetLastError(); delete ctx; return MI_EHIP; }
     }
     ctx->own_stream = true;
     mi_ntt_state_init(ctx);
-    mi_msm_state_init(ctx);
+    // from here on a failure unwinds through mi_shutdown: it frees exactly what exists (null handles are skipped)
+    int32_t rc = mi_msm_state_init(ctx);
     for (auto &e : ctx->ev)
-        if (hipEventCreate(&e) != hipSuccess) { delete ctx; return MI_EHIP; }
+        if (rc == MI_OK && hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); rc = MI_EHIP; }
+    if (rc != MI_OK) { mi_shutdown(ctx); return rc; }
     *out = ctx;
     return MI_OK;
 }
 int32_t mi_shutdown(mi_ctx *ctx) {
     if (!ctx) return MI_EINVAL;
-    hipSetDevice(ctx->dev);
-    hipStreamSynchronize(ctx->stream);
-    for (auto &b : ctx->ws) if (b.p) hipFree(b.p);
+    (void)hipSetDevice(ctx->dev);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->ws) if (b.p) (void)hipFree(b.p);
     mi_ntt_state_free(ctx);
     mi_msm_state_free(ctx);
-    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MI_OK;
 }
@@ -53,7 +58,7 @@ const char *mi_last_error(mi_ctx *ctx) { return ctx ? ctx->err.c_str() : "null c
 int32_t mi_set_stream(mi_ctx *ctx, void *hip_stream) {
     if (!ctx) return MI_EINVAL;
     MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return MI_OK;

@@ -14,7 +14,7 @@ struct DevBuf {             // growable device scratch owned by the ctx (no hipM
 #define MI_MSM_SLOTS 6
 struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, workspaces, pinned result
     hipStream_t stream = nullptr;
-    hipEvent_t ev[5]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job
+    hipEvent_t ev[6]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job, 5: bucket sums ready (deferred reduce)
     DevBuf buf[14];
     void *host_wsum = nullptr;
     uint32_t n = 0, c = 0, G = 0;
@@ -22,6 +22,9 @@ struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, 
     uint32_t nwin_keys = 0;     // windows in the key space: ceil(256/c) for the generic MSM, 1 for the fixed-base one
     uint32_t nwin_digits = 0;   // digits per scalar = ceil(256/c)
     bool active = false, timed = false;
+    bool deferred = false;      // accumulate stage done up to the bucket sums, reduce not yet enqueued (MI_MSM_DEFER_REDUCE)
+    uint32_t tail_seg = 0;      // buckets per bucket-reduce thread
+    const uint32_t *entries_src = nullptr;   // device word holding the number of sorted entries (stats)
 };
 
 struct mi_ctx {
@@ -41,9 +44,17 @@ struct mi_ctx {
     uint32_t fixed_knob[3] = {0, 0, 0};  // prove's fixed-base tables for A+K / B / Z: 0 = automatic, 1 = never, 17..22 = forced (prove.hip)
 };
 
+// Fault injection for the error-path tests (mi_debug_inject_hip_failure, api.hip): the n-th MI_CHECK_HIP from now reports
+// hipErrorUnknown INSTEAD of running its call.  Disabled (<= 0) it costs one relaxed atomic load per checked call.
+#include <atomic>
+extern std::atomic<int> mi_fault_countdown;
+static inline bool mi_fault_hit() {
+    if (mi_fault_countdown.load(std::memory_order_relaxed) <= 0) return false;
+    return mi_fault_countdown.fetch_sub(1, std::memory_order_relaxed) == 1;
+}
 #define MI_CHECK_HIP(ctx, call)                                                                       \
     do {                                                                                              \
-        hipError_t e__ = (call);                                                                      \
+        hipError_t e__ = mi_fault_hit() ? hipErrorUnknown : (call);                                   \
         if (e__ != hipSuccess) {                                                                      \
             (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                          \
             return e__ == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP;                                  \
@@ -76,7 +87,7 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
                               size_t n_constraints, mi_fr *h_out);
 void mi_ntt_state_init(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);
-void mi_msm_state_init(mi_ctx *ctx);
+int32_t mi_msm_state_init(mi_ctx *ctx);   // MI_OK or the first failing HIP call; partial state is freed by mi_msm_state_free
 // Stream priority schemes (3 hardware levels; comment in msm.hip).  A context on its own ranks computeH high, the wire MSMs
 // normal and Z low.  The contexts of a prover pool are staggered on top of that: the first runs nearly as if alone, the
 // others fill what it leaves (28.2-28.4 vs 27.4 proofs/s with three in flight; two staggered contexts reach what three
@@ -92,7 +103,23 @@ void mi_msm_state_free(mi_ctx *ctx);
 // returns the XYZZ result on the host.
 // precomp_c != 0: pts_dev holds the fixed-base window copies [ceil(256/c)][n] built by mi_msm_precompute (msm2_core.cuh).
 int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
-                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c = 0, size_t stat_pairs = 0);
+                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c = 0, size_t stat_pairs = 0,
+                       uint32_t generic_c = 0 /* window bits of the generic path when the parts of a sharded MSM must agree (0 = from n) */);
 // pre[w][i] = 2^(c*w) * base[i] for w < ceil(256/c) (affine), on ctx->stream.  pre must hold ceil(256/c) * n points.
 int32_t mi_msm_precompute(mi_ctx *ctx, int curve, const void *base_dev, void *pre_dev, size_t n, uint32_t c);
 int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host);
+// Internal flag of mi_msm_enqueue (next to MI_MSM_SCALARS_CANONICAL): stop at the bucket sums.  mi_msm_bucket_view then
+// exposes them, mi_msm_reduce_enqueue runs the rest (bucket reduce, window sums, copy to the host) and mi_msm_finish collects.
+#define MI_MSM_DEFER_REDUCE 0x100u
+struct MsmBucketView {
+    void *bucket = nullptr;     // XYZZ[nkeys] on the slot's device; null for an empty MSM
+    size_t nkeys = 0, xyzz_bytes = 0;
+    uint32_t seg = 0, c = 0, nwin = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr; // recorded on `stream` after the last accumulate level
+};
+int32_t mi_msm_bucket_view(mi_ctx *ctx, int slot, int curve, MsmBucketView *v);
+int32_t mi_msm_reduce_enqueue(mi_ctx *ctx, int slot, int curve);
+uint32_t mi_msm_auto_c(size_t n);   // the generic path's window bits for n pairs
+const struct MsmCurveOps &mi_msm_ops(int curve);
+

@@ -293,7 +293,7 @@ static MsmShape key_shape(const MsmSlot &sl) {
     return s;
 }
 
-void mi_msm_state_init(mi_ctx *ctx) {
+int32_t mi_msm_state_init(mi_ctx *ctx) {
     new (ctx->msm_knobs) MsmKnobs();
     // the c = 16 histogram / cursor image is 128 KiB of LDS (gfx950 allows 160 KiB per workgroup)
     (void)hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -314,11 +314,14 @@ void mi_msm_state_init(mi_ctx *ctx) {
         int pw = 0, pz = prio_lo;   // wires, Z: MI_PRIO_SOLO, MI_PRIO_POOL_SECOND
         if (ctx->prio_scheme == MI_PRIO_POOL_FIRST) { pw = prio_hi; pz = 0; }
         if (ctx->prio_scheme == MI_PRIO_POOL_REST) pw = pz = prio_lo;
-        (void)hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, idx == 4 ? pz : pw);
+        // every failure is reported: a null stream / event / host_wsum would otherwise surface much later as a memcpy into
+        // null (msm_accum_enqueue).  The caller (mi_init_prio) unwinds through mi_shutdown, which frees what was created.
+        MI_CHECK_HIP(ctx, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, idx == 4 ? pz : pw));
         idx++;
-        for (auto &e : sl.ev) (void)hipEventCreate(&e);
-        (void)hipHostMalloc(&sl.host_wsum, 128 * 256 + 64);
+        for (auto &e : sl.ev) MI_CHECK_HIP(ctx, hipEventCreate(&e));
+        MI_CHECK_HIP(ctx, hipHostMalloc(&sl.host_wsum, 128 * 256 + 64));
     }
+    return MI_OK;
 }
 void mi_msm_state_free(mi_ctx *ctx) {
     for (auto &sl : ctx->msm) {
@@ -386,10 +389,10 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
 }
 
 // sort stage on slot sl: digits + counting sort of (key -> point index | sign).  Records sl.ev[0].
-static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags) {
+static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 generic_c) {
     MsmKnobs *kn = knobs_of(ctx);
     sl.n = n;
-    sl.c = kn->c ? kn->c : auto_c(n);
+    sl.c = kn->c ? kn->c : (generic_c >= 2 && generic_c <= 16 ? generic_c : auto_c(n));
     sl.G = kn->G ? kn->G : (n / 8192 > 64 ? 64 : (n / 8192 ? n / 8192 : 1));
     const MsmShape s = slot_shape(sl);
     sl.nwin_keys = sl.nwin_digits = s.nwin;
@@ -465,7 +468,8 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
 }
 
 // accumulate stage on slot acc, reading the sort of slot srt (may be the same slot)
-static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &srt, MsmSlot &acc, const void *pts, bool timed) {
+static int32_t msm_tail_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &acc);
+static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &srt, MsmSlot &acc, const void *pts, bool timed, bool defer_reduce) {
     MsmKnobs *kn = knobs_of(ctx);
     acc.n = srt.n; acc.c = srt.c; acc.G = srt.G; acc.nwin_keys = srt.nwin_keys; acc.nwin_digits = srt.nwin_digits;
     const MsmShape s = key_shape(srt);
@@ -488,7 +492,24 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     // largest possible bucket: one entry per scalar and window of the key space it collects
     const u64 max_count = (u64)(srt.nwin_digits / srt.nwin_keys) * n;
     MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed));
-    // bucket reduce -> per-window partials -> window sums -> pinned host memory
+    // everything below reads the bucket sums only: a point-sharded MSM (group.hip, SURVEY 8e option ii) stops here, exchanges
+    // bucket slices between the devices and calls mi_msm_reduce_enqueue afterwards
+    acc.tail_seg = seg;
+    acc.entries_src = (const u32 *)srt.buf[B_S].p + s.nkeys;
+    acc.timed = timed;
+    acc.deferred = defer_reduce;
+    if (defer_reduce) {
+        MI_CHECK_HIP(ctx, hipEventRecord(acc.ev[5], st));
+        return MI_OK;
+    }
+    return msm_tail_enqueue(ctx, ops, acc);
+}
+// bucket reduce -> per-window partials -> window sums -> pinned host memory
+static int32_t msm_tail_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &acc) {
+    const MsmShape s = key_shape(acc);
+    const u32 seg = acc.tail_seg;
+    hipStream_t st = acc.stream;
+    void *bucket = acc.buf[B_BUCKET].p;
     const u32 tb = (s.nbuckets + seg - 1) / seg;
     size_t win_pts = (size_t)s.nwin * tb + s.nwin + 1;
     for (u32 k = tb; k > 1; k = (k + ops.sum_T - 1) / ops.sum_T) win_pts += (size_t)s.nwin * ((k + ops.sum_T - 1) / ops.sum_T);
@@ -507,14 +528,15 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     char *wsum = cur;
     MI_CHECK_HIP(ctx, hipMemcpyAsync(acc.host_wsum, wsum, ops.xyzz_bytes * s.nwin, hipMemcpyDeviceToHost, st));
     // number of sorted entries (= mixed additions of level 1) for the stats: keystart[nkeys]
-    MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)acc.host_wsum + 128 * 256, (const u32 *)srt.buf[B_S].p + s.nkeys, 4, hipMemcpyDeviceToHost, st));
+    MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)acc.host_wsum + 128 * 256, acc.entries_src, 4, hipMemcpyDeviceToHost, st));
     MI_CHECK_HIP(ctx, hipEventRecord(acc.ev[4], st));
-    acc.timed = timed;
+    acc.deferred = false;
     acc.active = true;
     return MI_OK;
 }
 
 static int32_t msm_finish(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, void *out) {
+    if (sl.deferred) MI_FAIL(ctx, MI_EINVAL, "msm: finish before the deferred reduce was enqueued");
     if (!sl.active) { ops.combine_windows(nullptr, 0, 0, out); return MI_OK; }   // zero windows -> infinity
     MI_CHECK_HIP(ctx, hipStreamSynchronize(sl.stream));
     const MsmShape s = key_shape(sl);
@@ -540,20 +562,42 @@ int32_t mi_msm_precompute(mi_ctx *ctx, int curve, const void *base_dev, void *pr
     return MI_OK;
 }
 int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
-                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c, size_t stat_pairs) {
+                       uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c, size_t stat_pairs, uint32_t generic_c) {
     if (slot < 0 || slot >= MI_MSM_SLOTS || sort_slot >= MI_MSM_SLOTS) return MI_EINVAL;
     if (n > ((size_t)1 << 27)) MI_FAIL(ctx, MI_EINVAL, "msm: n > 2^27 pairs per device not supported (shard the points)");
     MsmSlot &sl = ctx->msm[slot];
     sl.active = false;
+    sl.deferred = false;
     sl.stat_pairs = stat_pairs ? stat_pairs : n;
+    const bool defer = (flags & MI_MSM_DEFER_REDUCE) != 0;
+    flags &= ~MI_MSM_DEFER_REDUCE;
     if (n == 0) return MI_OK;
     if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
     MsmSlot &srt = sort_slot >= 0 ? ctx->msm[sort_slot] : sl;
     if (sort_slot < 0 && precomp_c) MI_TRY(msm2_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, precomp_c));
-    else if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags));
+    else if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, generic_c));
     else if (srt.n != n) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
-    return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed);
+    return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed, defer);
+}
+uint32_t mi_msm_auto_c(size_t n) { return auto_c(n ? (u32)n : 1u); }
+const MsmCurveOps &mi_msm_ops(int curve) { return curve == 1 ? msm_g1_ops() : msm_g2_ops(); }
+int32_t mi_msm_reduce_enqueue(mi_ctx *ctx, int slot, int curve) {
+    if (slot < 0 || slot >= MI_MSM_SLOTS) return MI_EINVAL;
+    MsmSlot &sl = ctx->msm[slot];
+    if (!sl.deferred) return MI_OK;   // an empty MSM (n == 0) never got as far as its buckets
+    return msm_tail_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), sl);
+}
+int32_t mi_msm_bucket_view(mi_ctx *ctx, int slot, int curve, MsmBucketView *v) {
+    if (slot < 0 || slot >= MI_MSM_SLOTS || !v) return MI_EINVAL;
+    MsmSlot &sl = ctx->msm[slot];
+    const MsmCurveOps &ops = curve == 1 ? msm_g1_ops() : msm_g2_ops();
+    *v = MsmBucketView{};
+    if (!sl.deferred) return MI_OK;
+    const MsmShape s = key_shape(sl);
+    v->bucket = sl.buf[B_BUCKET].p; v->nkeys = s.nkeys; v->xyzz_bytes = ops.xyzz_bytes; v->seg = sl.tail_seg;
+    v->stream = sl.stream; v->ready = sl.ev[5]; v->c = s.c; v->nwin = s.nwin;
+    return MI_OK;
 }
 int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host) {
     if (slot < 0 || slot >= MI_MSM_SLOTS) return MI_EINVAL;

@@ -75,6 +75,20 @@ static void launch_sum_tree(hipStream_t st, unsigned nout, unsigned nwin, const 
     hipLaunchKernelGGL(k_msm_sum_tree<F>, dim3(nout, nwin), dim3(SumT<F>::value), SumT<F>::value * sizeof(XYZZ<F>), st, (const XYZZ<F> *)in, n, nout,
                        (XYZZ<F> *)out);
 }
+// Point-sharded MSM, SURVEY 8e option ii: own[i] += sum_p recv[p * own_len + i] -- the bucket sums the other devices hold for
+// the keys this device owns, added to its own before the bucket reduce.
+template <class F>
+__global__ void __launch_bounds__(64) k_msm_sum_slices(XYZZ<F> *own, const XYZZ<F> *recv, u32 n_peers, u32 own_len) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= own_len) return;
+    XYZZ<F> acc = own[i];
+    for (u32 p = 0; p < n_peers; p++) xyzz_add(acc, recv[(size_t)p * own_len + i]);
+    own[i] = acc;
+}
+template <class F>
+static void launch_sum_slices(hipStream_t st, void *own, const void *recv, u32 n_peers, u32 own_len) {
+    if (own_len) hipLaunchKernelGGL(k_msm_sum_slices<F>, dim3((own_len + 63) / 64), dim3(64), 0, st, (XYZZ<F> *)own, (const XYZZ<F> *)recv, n_peers, own_len);
+}
 template <class F>
 __global__ void __launch_bounds__(64) k_msm2_precompute(const Affine<F> *base, Affine<F> *pre, u32 n, u32 c, u32 nwin) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -19,6 +19,8 @@ struct MsmCurveOps {
     void (*precompute)(hipStream_t st, const void *base, void *pre, uint32_t n, uint32_t c, uint32_t nwin);   // fixed-base window copies
     // total = sum_w 2^(c*w) * wsum[w] on the host; nwin == 0 yields the point at infinity
     void (*combine_windows)(const void *host_wsum, uint32_t nwin, uint32_t c, void *out_xyzz);
+    // own[i] += sum_p recv[p * own_len + i]  (XYZZ; bucket slices received from the other devices of a sharded MSM)
+    void (*sum_slices)(hipStream_t st, void *own, const void *recv, uint32_t n_peers, uint32_t own_len);
 };
 const MsmCurveOps &msm_g1_ops();   // msm_g1.hip
 const MsmCurveOps &msm_g2_ops();   // msm_g2.hip

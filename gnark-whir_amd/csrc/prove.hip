@@ -6,31 +6,10 @@
 //                public / committed wire sets into device gather-index arrays (row a7).
 //   prove        computeH on the device -> three gathers of W -> five MSMs -> O(1)-point blinding and
 //                assembly on the host (Ar, Bs1, Krs, Bs exactly as prove.go composes them).
-#include "ctx.h"
-#include "curve.cuh"
+#include "prove_internal.h"
 #include <cstring>
 #include <vector>
 #include <chrono>
-#include <future>
-
-struct mi_pk {
-    u32 log_n = 0, nb_public = 0;
-    u64 nb_wires = 0;
-    void *g1_a = nullptr, *g1_b = nullptr, *g1_k = nullptr, *g1_z = nullptr, *g2_b = nullptr;
-    u64 n_a = 0, n_b = 0, n_k = 0, n_z = 0;
-    bool owns_points = false;
-    u32 *idx_a = nullptr, *idx_b = nullptr, *idx_k = nullptr;  // wire index of every A / B / K point
-    // pk.G1.A and pk.G1.K re-expanded to one slot per wire (zero = infinity where the wire has no point): both are multiplied
-    // by W itself, so ONE sort of W serves both MSMs and neither needs a gather (prove.hip, step 5)
-    G1Aff *a_full = nullptr, *k_full = nullptr;
-    // Fixed-base window copies 2^(c*w) * P (msm2_core.cuh) of the bases, per group of MSMs that share a sort: A+K, B1+B2, Z.
-    // c = 0: the group runs the generic path on the plain bases.  A group with tables no longer keeps its plain copy
-    // (pre[0] is the base array) unless the caller owns it.
-    u32 c_ak = 0, c_b = 0, c_z = 0;
-    void *pre_a = nullptr, *pre_k = nullptr, *pre_b1 = nullptr, *pre_b2 = nullptr, *pre_z = nullptr;
-    G1Aff alpha1, beta1, delta1;
-    G2Aff beta2, delta2;
-};
 
 __global__ void k_expand_points(G1Aff *full, const G1Aff *compact, const u32 *idx, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,33 +26,44 @@ static int32_t upload(mi_ctx *ctx, void **dst, const void *src, size_t bytes) {
     return MI_OK;
 }
 
-static int32_t pk_load_common(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points) {
+int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr) {
     if (!ctx || !d || !out) return MI_EINVAL;
     *out = nullptr;
+    if (sr && device_points) return MI_EINVAL;
     if (d->log_n > 28 || d->nb_public > d->nb_wires || !d->infinity_a || !d->infinity_b) MI_FAIL(ctx, MI_EINVAL, "pk: bad header");
     const u64 N = (u64)1 << d->log_n;
     if (d->n_g1_z + 1 < N) MI_FAIL(ctx, MI_EINVAL, "pk: G1.Z needs at least 2^log_n - 1 points");
     if (d->nb_wires >= ((u64)1 << 31)) MI_FAIL(ctx, MI_EINVAL, "pk: too many wires");
     if (d->n_g2_b != d->n_g1_b) MI_FAIL(ctx, MI_EINVAL, "pk: G1.B and G2.B differ in length");
     // gather indices from the static masks (prove.go: wireValuesA/B filters; K drops public + committed)
+    // a part of a sharded key keeps the wires [w_lo, w_hi) (indices relative to w_lo) and the points those wires own:
+    // a0 / b0 / k0 = points of earlier wires = offset of this part's slice in the caller's arrays
+    const u64 w_lo = sr ? sr->w_lo : 0, w_hi = sr ? sr->w_hi : d->nb_wires;
+    const u64 z_lo = sr ? sr->z_lo : 0, z_hi = sr ? sr->z_hi : N - 1;
+    if (w_lo > w_hi || w_hi > d->nb_wires || z_lo > z_hi || z_hi > N - 1) MI_FAIL(ctx, MI_EINVAL, "pk: bad shard range");
     std::vector<u32> ia, ib, ik;
-    ia.reserve(d->n_g1_a); ib.reserve(d->n_g1_b); ik.reserve(d->n_g1_k);
-    u64 ci = 0;
+    u64 ci = 0, ca = 0, cb = 0, ck = 0, a0 = 0, b0 = 0, k0 = 0;
     for (u64 j = 0; j < d->nb_wires; j++) {
-        if (!d->infinity_a[j]) ia.push_back((u32)j);
-        if (!d->infinity_b[j]) ib.push_back((u32)j);
+        const bool in = j >= w_lo && j < w_hi;
+        if (j == w_lo) { a0 = ca; b0 = cb; k0 = ck; }
+        if (!d->infinity_a[j]) { ca++; if (in) ia.push_back((u32)(j - w_lo)); }
+        if (!d->infinity_b[j]) { cb++; if (in) ib.push_back((u32)(j - w_lo)); }
         if (j >= d->nb_public) {
             while (ci < d->n_committed && d->committed_wires[ci] < j) ci++;
             if (ci < d->n_committed && d->committed_wires[ci] == j) continue;
-            ik.push_back((u32)j);
+            ck++;
+            if (in) ik.push_back((u32)(j - w_lo));
         }
     }
-    if (ia.size() != d->n_g1_a || ib.size() != d->n_g1_b || ik.size() != d->n_g1_k)
+    if (w_lo >= d->nb_wires) { a0 = ca; b0 = cb; k0 = ck; }
+    if (ca != d->n_g1_a || cb != d->n_g1_b || ck != d->n_g1_k)
         MI_FAIL(ctx, MI_EINVAL, "pk: point counts do not match the infinity masks / public / committed wire sets");
     mi_pk *pk = new (std::nothrow) mi_pk();
     if (!pk) return MI_ENOMEM;
-    pk->log_n = d->log_n; pk->nb_public = d->nb_public; pk->nb_wires = d->nb_wires;
-    pk->n_a = d->n_g1_a; pk->n_b = d->n_g1_b; pk->n_k = d->n_g1_k; pk->n_z = d->n_g1_z;
+    pk->log_n = d->log_n; pk->nb_wires = w_hi - w_lo;
+    pk->nb_public = (u32)(d->nb_public <= w_lo ? 0 : (d->nb_public >= w_hi ? w_hi - w_lo : d->nb_public - w_lo));
+    pk->n_a = ia.size(); pk->n_b = ib.size(); pk->n_k = ik.size(); pk->n_z = sr ? z_hi - z_lo : d->n_g1_z;
+    pk->wire_lo = w_lo; pk->z_lo = z_lo; pk->n_z_msm = z_hi - z_lo;
     std::memcpy(&pk->alpha1, &d->alpha1, 64); std::memcpy(&pk->beta1, &d->beta1, 64); std::memcpy(&pk->delta1, &d->delta1, 64);
     std::memcpy(&pk->beta2, &d->beta2, 128); std::memcpy(&pk->delta2, &d->delta2, 128);
     int32_t rc = MI_OK;
@@ -81,18 +71,18 @@ static int32_t pk_load_common(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, boo
         pk->g1_a = (void *)d->g1_a; pk->g1_b = (void *)d->g1_b; pk->g1_k = (void *)d->g1_k; pk->g1_z = (void *)d->g1_z; pk->g2_b = (void *)d->g2_b;
     } else {
         pk->owns_points = true;
-        if (rc == MI_OK) rc = upload(ctx, &pk->g1_a, d->g1_a, d->n_g1_a * 64);
-        if (rc == MI_OK) rc = upload(ctx, &pk->g1_b, d->g1_b, d->n_g1_b * 64);
-        if (rc == MI_OK) rc = upload(ctx, &pk->g1_k, d->g1_k, d->n_g1_k * 64);
-        if (rc == MI_OK) rc = upload(ctx, &pk->g1_z, d->g1_z, d->n_g1_z * 64);
-        if (rc == MI_OK) rc = upload(ctx, &pk->g2_b, d->g2_b, d->n_g2_b * 128);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g1_a, d->g1_a + a0, pk->n_a * 64);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g1_b, d->g1_b + b0, pk->n_b * 64);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g1_k, d->g1_k + k0, pk->n_k * 64);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g1_z, d->g1_z + z_lo, pk->n_z * 64);
+        if (rc == MI_OK) rc = upload(ctx, &pk->g2_b, d->g2_b + b0, pk->n_b * 128);
     }
     if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_a, ia.data(), ia.size() * 4);
     if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_b, ib.data(), ib.size() * 4);
     if (rc == MI_OK) rc = upload(ctx, (void **)&pk->idx_k, ik.data(), ik.size() * 4);
     // expanded per-wire copies of A and K
     auto expand = [&](G1Aff **full, const void *compact, const u32 *idx, size_t n) -> int32_t {
-        const size_t bytes = (size_t)d->nb_wires * sizeof(G1Aff);
+        const size_t bytes = (size_t)pk->nb_wires * sizeof(G1Aff);
         MI_CHECK_HIP(ctx, hipMalloc((void **)full, bytes ? bytes : 64));
         MI_CHECK_HIP(ctx, hipMemsetAsync(*full, 0, bytes, ctx->stream));
         if (n) hipLaunchKernelGGL(k_expand_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, *full, (const G1Aff *)compact, idx, n);
@@ -119,9 +109,9 @@ static int32_t pk_load_common(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, boo
             budget -= need;
             return c_auto;
         };
-        pk->c_z = choose(ctx->fixed_knob[2], 20, N - 1, (N - 1) * sizeof(G1Aff));
+        pk->c_z = choose(ctx->fixed_knob[2], 20, pk->n_z_msm, pk->n_z_msm * sizeof(G1Aff));
         pk->c_b = choose(ctx->fixed_knob[1], 18, pk->n_b, pk->n_b * (sizeof(G1Aff) + sizeof(G2Aff)));
-        pk->c_ak = choose(ctx->fixed_knob[0], 19, d->nb_wires, d->nb_wires * 2 * sizeof(G1Aff));
+        pk->c_ak = choose(ctx->fixed_knob[0], 19, pk->nb_wires, pk->nb_wires * 2 * sizeof(G1Aff));
         auto pre = [&](void **dst, const void *base, size_t n, int curve, u32 c) -> int32_t {
             const size_t bytes = nwin_of(c) * n * (curve == 1 ? sizeof(G1Aff) : sizeof(G2Aff));
             MI_CHECK_HIP(ctx, hipMalloc(dst, bytes ? bytes : 64));
@@ -141,9 +131,9 @@ static int32_t pk_load_common(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, boo
             }
             return r;
         };
-        if (rc == MI_OK) rc = group(pk->c_z, &pk->pre_z, pk->g1_z, 1, nullptr, nullptr, 0, N - 1);
+        if (rc == MI_OK) rc = group(pk->c_z, &pk->pre_z, pk->g1_z, 1, nullptr, nullptr, 0, pk->n_z_msm);
         if (rc == MI_OK) rc = group(pk->c_b, &pk->pre_b1, pk->g1_b, 1, &pk->pre_b2, pk->g2_b, 2, pk->n_b);
-        if (rc == MI_OK) rc = group(pk->c_ak, &pk->pre_a, pk->a_full, 1, &pk->pre_k, pk->k_full, 1, d->nb_wires);
+        if (rc == MI_OK) rc = group(pk->c_ak, &pk->pre_a, pk->a_full, 1, &pk->pre_k, pk->k_full, 1, pk->nb_wires);
     }
     if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pk upload sync failed"; rc = MI_EHIP; }
     if (rc != MI_OK) { mi_pk_free(ctx, pk); return rc; }
@@ -228,9 +218,9 @@ int32_t mi_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *chal
 }
 int32_t mi_pk_load(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out) {
     if (d && (!d->g1_a && d->n_g1_a)) return MI_EINVAL;
-    return pk_load_common(ctx, d, out, false);
+    return mi_pk_load_range(ctx, d, out, false, nullptr);
 }
-int32_t mi_pk_load_dev(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out) { return pk_load_common(ctx, d, out, true); }
+int32_t mi_pk_load_dev(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out) { return mi_pk_load_range(ctx, d, out, true, nullptr); }
 int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
     if (!ctx || !pk) return MI_EINVAL;
     (void)hipStreamSynchronize(ctx->stream);
@@ -243,6 +233,77 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
 
 }  // extern "C"
 
+// ---------------------------------------------------------------- the pieces of a proof (shared with group.hip)
+// step 5 + the wire MSMs: they depend on W only (ev_w = "W is on the device")
+int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
+    const uint32_t df = defer ? MI_MSM_DEFER_REDUCE : 0;
+    // wireValuesB by the static gather indices, on its MSM's stream; B2 (G2) shares B1's sort (same scalars)
+    MI_TRY(mi_reserve(ctx, ctx->ws[17], (pk->n_b + 1) * sizeof(Fr)));
+    hipStream_t st = ctx->msm[1].stream;
+    if (ev_w) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, ev_w, 0));
+    if (pk->n_b) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((pk->n_b + 255) / 256)), dim3(256), 0, st, (Fr *)ctx->ws[17].p, (const Fr *)W, pk->idx_b, pk->n_b);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    if (pk->pre_b1) {
+        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, df, nullptr, true, pk->c_b));
+        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, df, nullptr, false, pk->c_b));
+    } else {
+        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df, nullptr, true, 0, 0, pk->gen_c_b));
+        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, df, nullptr, false));
+    }
+    // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
+    // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
+    if (pk->pre_a) {
+        MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->pre_a, W, pk->nb_wires, df, ev_w, true, pk->c_ak, pk->n_a));
+        return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, df, nullptr, true, pk->c_ak, pk->n_k);
+    }
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, df, ev_w, true, 0, pk->n_a, pk->gen_c_ak));
+    return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, df, nullptr, true, 0, pk->n_k);
+}
+// the Z MSM over this key's h coefficients against the bit-reversed pk.G1.Z (ev_h = "h is ready")
+int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h, hipEvent_t ev_h, bool defer) {
+    const uint32_t df = defer ? MI_MSM_DEFER_REDUCE : 0;
+    if (pk->pre_z) return mi_msm_enqueue(ctx, 4, -1, 1, pk->pre_z, h, pk->n_z_msm, df, ev_h, true, pk->c_z);
+    return mi_msm_enqueue(ctx, 4, -1, 1, pk->g1_z, h, pk->n_z_msm, df, ev_h, true, 0, 0, pk->gen_c_z);
+}
+
+void ProofAssembler::start(const mi_pk *pk_, const mi_fr *r_m, const mi_fr *s_m) {
+    pk = pk_;
+    Fr r, s;
+    std::memcpy(&r, r_m, 32); std::memcpy(&s, s_m, 32);
+    rc = fe_from_mont(r); sc = fe_from_mont(s); krc = fe_from_mont(fe_neg(r * s));
+    // (independent 256-bit scalar multiplications: one host thread each; for small circuits they are the longest chain)
+    f_r = std::async(std::launch::async, [this] { return host_scalar_mul<Fp>(pk->delta1, rc); });
+    f_s = std::async(std::launch::async, [this] { return host_scalar_mul<Fp>(pk->delta1, sc); });
+    f_kr = std::async(std::launch::async, [this] { return host_scalar_mul<Fp>(pk->delta1, krc); });
+    s_delta2 = host_scalar_mul<Fp2>(pk->delta2, sc);
+    r_delta = f_r.get(); s_delta = f_s.get(); kr_delta = f_kr.get();
+}
+void ProofAssembler::have_a_b1(const G1X &msm_a, const G1X &msm_b1) {
+    G1X ar = msm_a;
+    xyzz_madd(ar, pk->alpha1, false);
+    xyzz_add(ar, r_delta);
+    G1X bs1 = msm_b1;
+    xyzz_madd(bs1, pk->beta1, false);
+    xyzz_add(bs1, s_delta);
+    ar_aff = xyzz_to_affine(ar); bs1_aff = xyzz_to_affine(bs1);
+    f_sar = std::async(std::launch::async, [this] { return host_scalar_mul<Fp>(ar_aff, sc); });   // overlaps the remaining MSMs
+    r_bs1 = host_scalar_mul<Fp>(bs1_aff, rc);
+}
+void ProofAssembler::finish(const G1X &msm_k, const G2X &msm_b2, const G1X &msm_z, mi_proof_out *out) {
+    G1X s_ar = f_sar.get();
+    G1X krs = msm_k;
+    xyzz_add(krs, msm_z);
+    xyzz_add(krs, kr_delta);
+    xyzz_add(krs, s_ar);
+    xyzz_add(krs, r_bs1);
+    G2X bs = msm_b2;
+    xyzz_madd(bs, pk->beta2, false);
+    xyzz_add(bs, s_delta2);
+    G1Aff krs_aff = xyzz_to_affine(krs);
+    G2Aff bs_aff = xyzz_to_affine(bs);
+    std::memcpy(&out->ar, &ar_aff, 64); std::memcpy(&out->bs, &bs_aff, 128); std::memcpy(&out->krs, &krs_aff, 64);
+}
+
 // Host-pointer inputs of mi_groth16_prove (null for the device-pointer entry point).
 struct HostInputs { const mi_fr *W, *a, *b, *c; };
 
@@ -251,6 +312,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
                             size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, mi_proof_out *out, mi_stats *stats, const HostInputs *host) {
     if (!ctx || !pk || !W || !a || !b || !c || !r_m || !s_m || !out) return MI_EINVAL;
     const size_t N = (size_t)1 << pk->log_n;
+    if (pk->wire_lo || pk->n_z_msm != N - 1) MI_FAIL(ctx, MI_EINVAL, "prove: this key is one part of a sharded key (use mi_groth16_prove_sharded)");
     if (n_wires != pk->nb_wires || n_constraints > N) MI_FAIL(ctx, MI_EINVAL, "prove: witness size does not match the proving key");
     std::memset(&ctx->stats, 0, sizeof(ctx->stats));
     const auto t_begin = std::chrono::steady_clock::now();
@@ -264,40 +326,13 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     auto enqueue_h_and_z = [&]() -> int32_t {
         MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, c, n_constraints, (mi_fr *)h));
         MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
-        if (pk->pre_z) return mi_msm_enqueue(ctx, 4, -1, 1, pk->pre_z, h, N - 1, 0, ev[3], true, pk->c_z);
-        return mi_msm_enqueue(ctx, 4, -1, 1, pk->g1_z, h, N - 1, 0, ev[3], true);
+        return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);
     };
-    // step 5 + the wire MSMs: they depend on W only (ev[2] = "W is on the device")
-    auto enqueue_wire_msms = [&]() -> int32_t {
-        // wireValuesB by the static gather indices, on its MSM's stream; B2 (G2) shares B1's sort (same scalars)
-        MI_TRY(mi_reserve(ctx, ctx->ws[17], (pk->n_b + 1) * sizeof(Fr)));
-        hipStream_t st = ctx->msm[1].stream;
-        MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, ev[2], 0));
-        if (pk->n_b) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((pk->n_b + 255) / 256)), dim3(256), 0, st, (Fr *)ctx->ws[17].p, (const Fr *)W, pk->idx_b, pk->n_b);
-        MI_CHECK_HIP(ctx, hipGetLastError());
-        if (pk->pre_b1) {
-            MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, 0, nullptr, true, pk->c_b));
-            MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, 0, nullptr, false, pk->c_b));
-        } else {
-        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, 0, nullptr, true));
-        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, 0, nullptr, false));
-        }
-        // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
-        // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
-        if (pk->pre_a) {
-            MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->pre_a, W, pk->nb_wires, 0, ev[2], true, pk->c_ak, pk->n_a));
-            return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, 0, nullptr, true, pk->c_ak, pk->n_k);
-        }
-        MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, 0, ev[2], true, 0, pk->n_a));
-        return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, 0, nullptr, true, 0, pk->n_k);
-    };
-    // Stream plan: computeH on the caller's stream; MSM A, B1, B2, K, Z on slots 0..4 (own streams).  The latency-bound
-    // tails (levels >= 2, bucket reduce, scans) of one MSM overlap the throughput-bound accumulation of the others.
     if (!host) {
         // inputs already in HBM: computeH heads the longest chain (h -> Z MSM), so it is enqueued first
         MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
         MI_TRY(enqueue_h_and_z());
-        MI_TRY(enqueue_wire_msms());
+        MI_TRY(mi_prove_enqueue_wire_msms(ctx, pk, W, ev[2]));
     } else {
         // inputs in host memory (the cgo path): upload W, start the wire MSMs, and upload a, b, c WHILE they run; the
         // PCIe time of a, b, c (3/4 of the bytes) disappears behind the MSMs instead of preceding the whole proof
@@ -305,7 +340,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         MI_CHECK_HIP(ctx, hipEventRecord(ev[10], ctx->stream));
         MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)W, host->W, wb, hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-        MI_TRY(enqueue_wire_msms());
+        MI_TRY(mi_prove_enqueue_wire_msms(ctx, pk, W, ev[2]));
         MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)a, host->a, cb, hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)b, host->b, cb, hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)c, host->c, cb, hipMemcpyHostToDevice, ctx->stream));
@@ -313,47 +348,21 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         MI_TRY(enqueue_h_and_z());
     }
     // step 6 while the GPU works: blinding multiples of delta on the host (O(1) points)
-    Fr r, s;
-    std::memcpy(&r, r_m, 32); std::memcpy(&s, s_m, 32);
-    Fr rc = fe_from_mont(r), sc = fe_from_mont(s), krc = fe_from_mont(fe_neg(r * s));
-    // (independent 256-bit scalar multiplications: one host thread each; for small circuits they are the longest chain)
-    auto f_r = std::async(std::launch::async, [&] { return host_scalar_mul<Fp>(pk->delta1, rc); });
-    auto f_s = std::async(std::launch::async, [&] { return host_scalar_mul<Fp>(pk->delta1, sc); });
-    auto f_kr = std::async(std::launch::async, [&] { return host_scalar_mul<Fp>(pk->delta1, krc); });
-    G2X s_delta2 = host_scalar_mul<Fp2>(pk->delta2, sc);
-    G1X r_delta = f_r.get(), s_delta = f_s.get(), kr_delta = f_kr.get();
+    ProofAssembler as;
+    as.start(pk, r_m, s_m);
     // step 7: collect the five MSMs
     G1X msm_a, msm_b1, msm_k, msm_z;
     G2X msm_b2;
     MI_TRY(mi_msm_finish(ctx, 0, 1, &msm_a));
     MI_TRY(mi_msm_finish(ctx, 1, 1, &msm_b1));
     const auto t_asm0 = std::chrono::steady_clock::now();
-    G1X ar = msm_a;
-    xyzz_madd(ar, pk->alpha1, false);
-    xyzz_add(ar, r_delta);
-    G1X bs1 = msm_b1;
-    xyzz_madd(bs1, pk->beta1, false);
-    xyzz_add(bs1, s_delta);
-    G1Aff ar_aff = xyzz_to_affine(ar), bs1_aff = xyzz_to_affine(bs1);
-    auto f_sar = std::async(std::launch::async, [&] { return host_scalar_mul<Fp>(ar_aff, sc); });   // overlaps the remaining MSMs
-    G1X r_bs1 = host_scalar_mul<Fp>(bs1_aff, rc);
-    G1X s_ar = f_sar.get();
+    as.have_a_b1(msm_a, msm_b1);
     MI_TRY(mi_msm_finish(ctx, 3, 1, &msm_k));
     MI_TRY(mi_msm_finish(ctx, 2, 2, &msm_b2));
     MI_TRY(mi_msm_finish(ctx, 4, 1, &msm_z));
     MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const auto t_gpu_done = std::chrono::steady_clock::now();
-    G1X krs = msm_k;
-    xyzz_add(krs, msm_z);
-    xyzz_add(krs, kr_delta);
-    xyzz_add(krs, s_ar);
-    xyzz_add(krs, r_bs1);
-    G2X bs = msm_b2;
-    xyzz_madd(bs, pk->beta2, false);
-    xyzz_add(bs, s_delta2);
-    G1Aff krs_aff = xyzz_to_affine(krs);
-    G2Aff bs_aff = xyzz_to_affine(bs);
-    std::memcpy(&out->ar, &ar_aff, 64); std::memcpy(&out->bs, &bs_aff, 128); std::memcpy(&out->krs, &krs_aff, 64);
+    as.finish(msm_k, msm_b2, msm_z, out);
     const auto t_end = std::chrono::steady_clock::now();
     mi_stats &st = ctx->stats;
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {

@@ -1,0 +1,53 @@
+// Internals of the prove path shared by prove.hip (one device) and group.hip (point-sharded over several devices).
+#pragma once
+#include "ctx.h"
+#include "curve.cuh"
+#include <future>
+
+struct mi_pk {
+    u32 log_n = 0, nb_public = 0;
+    u64 nb_wires = 0;
+    void *g1_a = nullptr, *g1_b = nullptr, *g1_k = nullptr, *g1_z = nullptr, *g2_b = nullptr;
+    u64 n_a = 0, n_b = 0, n_k = 0, n_z = 0;
+    bool owns_points = false;
+    u32 *idx_a = nullptr, *idx_b = nullptr, *idx_k = nullptr;  // wire index of every A / B / K point
+    // pk.G1.A and pk.G1.K re-expanded to one slot per wire (zero = infinity where the wire has no point): both are multiplied
+    // by W itself, so ONE sort of W serves both MSMs and neither needs a gather (prove.hip, step 5)
+    G1Aff *a_full = nullptr, *k_full = nullptr;
+    // Fixed-base window copies 2^(c*w) * P (msm2_core.cuh) of the bases, per group of MSMs that share a sort: A+K, B1+B2, Z.
+    // c = 0: the group runs the generic path on the plain bases.  A group with tables no longer keeps its plain copy
+    // (pre[0] is the base array) unless the caller owns it.
+    u32 c_ak = 0, c_b = 0, c_z = 0;
+    void *pre_a = nullptr, *pre_k = nullptr, *pre_b1 = nullptr, *pre_b2 = nullptr, *pre_z = nullptr;
+    G1Aff alpha1, beta1, delta1;
+    G2Aff beta2, delta2;
+    // A part of a point-sharded key (group.hip) covers wires [wire_lo, wire_lo + nb_wires) and the Z pairs
+    // [z_lo, z_lo + n_z_msm) of the 2^log_n - 1; a whole key has wire_lo = z_lo = 0 and n_z_msm = 2^log_n - 1.
+    u64 wire_lo = 0, z_lo = 0, n_z_msm = 0;
+    u32 gen_c_ak = 0, gen_c_b = 0, gen_c_z = 0;   // generic-path window bits the parts of a sharded key agree on (0 = from n)
+};
+
+
+struct ShardRange { u64 w_lo, w_hi, z_lo, z_hi; };   // wires [w_lo, w_hi), Z pairs [z_lo, z_hi)
+// mi_pk_load / mi_pk_load_dev (sr == nullptr) or one part of a sharded key (host arrays only)
+int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr);
+// The wire MSMs (A, B1, B2, K on slots 0..3) over W_dev = this key's wire range, ordered after ev_w; the Z MSM (slot 4) over
+// h_dev = this key's first h coefficient, ordered after ev_h.  defer_reduce: stop each MSM at its bucket sums (group.hip
+// exchanges them between devices before the reduce, SURVEY 8e option ii).
+int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hipEvent_t ev_w, bool defer_reduce = false);
+int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h_dev, hipEvent_t ev_h, bool defer_reduce = false);
+
+// Blinding and assembly of Ar, Bs, Krs from the five MSM sums, exactly as gnark's prove.go composes them (row a9); host
+// code over O(1) points.  start() launches the multiples of delta on host threads while the GPU works; have_a_b1() needs
+// only the A and B1 sums and starts s*Ar, r*Bs1; finish() takes the rest.
+struct ProofAssembler {
+    const mi_pk *pk = nullptr;
+    Fr rc, sc, krc;
+    std::future<G1X> f_r, f_s, f_kr, f_sar;
+    G2X s_delta2;
+    G1X r_delta, s_delta, kr_delta, r_bs1;
+    G1Aff ar_aff, bs1_aff;
+    void start(const mi_pk *pk_, const mi_fr *r_m, const mi_fr *s_m);
+    void have_a_b1(const G1X &msm_a, const G1X &msm_b1);
+    void finish(const G1X &msm_k, const G2X &msm_b2, const G1X &msm_z, mi_proof_out *out);
+};

@@ -203,6 +203,51 @@ int32_t mi_prover_submit_dev(mi_prover *p, mi_pk *pk, const mi_fr *W_dev, size_t
                              const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket);
 int32_t mi_prover_wait(mi_prover *p, uint64_t ticket);
 
+/* ---- device groups: one proof / one MSM point-sharded over several GPUs (BASELINE configs[4]).
+ * The reference's single call groth16.Prove (mt.go:496) knows no devices; a Go caller that wants one proof spread over the
+ * 8 MI355X of a node binds these.  pk points are static, so mi_pk_load_sharded cuts the wires
+ * (and the N - 1 pairs of the Z MSM) into `world` contiguous ranges and keeps slice r of pk.G1.{A,B,K,Z} / pk.G2.B resident
+ * on rank r; per proof only scalars move (W slices from the host, h slices device to device from the lead rank, which runs
+ * computeH: NTT = replicas only).  EC addition is not an RCCL reduce op, so the exchange is byte-typed:
+ *   mode 0  every rank finishes Pippenger locally; one partial sum per MSM is combined (host additions in one process,
+ *           ncclAllGather(ncclUint8) with one rank per process);
+ *   mode 1  "all-reduce of partial bucket sums": every rank stops at its bucket sums, rank r receives the keys it owns from
+ *           every other rank (reduce-scatter as grouped ncclSend / ncclRecv, one hop on the xGMI mesh), adds them, reduces
+ *           its slice; the per-rank results are combined as in mode 0.
+ * Results are bit-identical to the unsharded entry points.  Calls on one group must not overlap. ---- */
+typedef struct mi_group mi_group;
+typedef struct mi_pk_sharded mi_pk_sharded;
+/* all ranks in this process, one context per entry of dev_ids (SURVEY 8b proposed mi_init(dev_ids, n_dev, ...)).  Distinct
+ * devices: RCCL communicator (ncclCommInitAll).  A device named twice (1-GPU rehearsal): same-process peer copies. */
+int32_t mi_group_create(const int *dev_ids, int n_dev, mi_group **out);
+/* one rank per process: id = mi_group_unique_id() from rank 0, handed to the others by the caller's own channel */
+int32_t mi_group_unique_id(uint8_t id[128]);
+int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t id[128], mi_group **out);
+int32_t mi_group_destroy(mi_group *g);
+int32_t mi_group_world(const mi_group *g);
+int32_t mi_group_local(const mi_group *g);                 /* ranks held by this process */
+mi_ctx *mi_group_ctx(mi_group *g, int local_rank);         /* for mi_dev_* / generators on that rank's device */
+const char *mi_group_last_error(mi_group *g);
+int32_t mi_group_transport(const mi_group *g);             /* 1 = RCCL, 2 = peer copies */
+/* transport check: every rank sends `bytes` patterned bytes to every rank (itself included) and verifies what it received */
+int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes);
+/* desc: the same whole-key descriptor as mi_pk_load (host arrays) */
+int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *desc, mi_pk_sharded **out);
+int32_t mi_pk_sharded_free(mi_group *g, mi_pk_sharded *pk);
+/* single-process groups; arguments as mi_groth16_prove */
+int32_t mi_groth16_prove_sharded(mi_group *g, mi_pk_sharded *pk, const mi_fr *W, size_t n_wires,
+                                 const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
+                                 const mi_fr *r, const mi_fr *s, uint32_t mode, mi_proof_out *out, mi_stats *stats_or_null);
+/* one MSM over host arrays cut into contiguous slices (single-process groups) */
+int32_t mi_msm_g1_sharded(mi_group *g, const mi_g1_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags,
+                          uint32_t mode, mi_g1_jac *out);
+/* one MSM whose pairs already sit on the ranks' devices: arrays of mi_group_local() device pointers / counts; n_total = pairs
+ * over ALL ranks (every rank passes the same value: it fixes the common window width).  Every rank receives the result. */
+int32_t mi_msm_g1_sharded_dev(mi_group *g, const mi_g1_affine *const *pts_dev, const mi_fr *const *scalars_dev,
+                              const size_t *n_local, size_t n_total, uint32_t flags, uint32_t mode, mi_g1_jac *out);
+int32_t mi_msm_g2_sharded_dev(mi_group *g, const mi_g2_affine *const *pts_dev, const mi_fr *const *scalars_dev,
+                              const size_t *n_local, size_t n_total, uint32_t flags, uint32_t mode, mi_g2_jac *out);
+
 /* ---- Proof.WriteTo / point encoding (row a12), pure host code ---- */
 void mi_g1_compress(const mi_g1_affine *p, uint8_t out[32]);
 void mi_g2_compress(const mi_g2_affine *p, uint8_t out[64]);
@@ -276,6 +321,9 @@ int32_t mi_debug_set_msm_group_bits(mi_ctx *ctx, uint32_t gbits);   /* fixed-bas
  * 0 = automatic (tables when the MSM has >= 2^20 points and they fit in a third of the free device memory),
  * 1 = never, 17..22 = that width whatever the size */
 int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, uint32_t c_z);
+/* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
+ * running; 0 disarms.  Used to prove that init / load / prove unwind without leaks or crashes. */
+int32_t mi_debug_inject_hip_failure(int32_t nth);
 /* raw device memory helpers so hosts without a HIP binding (ctypes, cgo) can stage data */
 int32_t mi_dev_alloc(mi_ctx *ctx, size_t bytes, void **out_dev);
 int32_t mi_dev_free(mi_ctx *ctx, void *dev);
