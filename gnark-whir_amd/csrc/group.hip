@@ -36,7 +36,7 @@ struct mi_group {
     std::vector<mi_ctx *> ctx;     // one context per local rank
     std::vector<ncclComm_t> comm;  // RCCL communicator per local rank; empty = peer copies inside this process
     std::vector<hipStream_t> xs;   // per local rank: the exchange stream (sends, receives, slice sums)
-    std::vector<hipEvent_t> ev_x, ev_done, ev_h;
+    std::vector<hipEvent_t> ev_x, ev_in, ev_done, ev_h;
     std::vector<DevBuf> recv;      // per local rank: bucket slices received from the other ranks
     std::vector<DevBuf> stage;     // per local rank: small staging area for the partial-sum all-gather
     std::string err;
@@ -73,7 +73,14 @@ static int32_t run_xfers(mi_group *g, const std::vector<Xfer> &xs_list, const st
         G_NCCL(g, ncclGroupEnd());
         return MI_OK;
     }
-    // same process, no communicator (a device named twice): peer copies on the source's stream, then every stream waits for all
+    // same process, no communicator (a device named twice): peer copies on the source's stream, then every stream waits for all.
+    // A copy is issued by its SOURCE into the destination's buffer, so the sources must first wait for whatever the destinations
+    // still do with those buffers (the slice sums of the previous exchange): a stream-level barrier on entry as well.
+    for (int i = 0; i < g->n_local(); i++) { (void)hipSetDevice(g->dev[i]); G_HIP(g, hipEventRecord(g->ev_in[i], xs[i])); }
+    for (int i = 0; i < g->n_local(); i++) {
+        (void)hipSetDevice(g->dev[i]);
+        for (int j = 0; j < g->n_local(); j++) if (j != i) G_HIP(g, hipStreamWaitEvent(xs[i], g->ev_in[j], 0));
+    }
     for (const Xfer &x : xs_list) {
         if (!x.bytes) continue;
         if (!g->local(x.src) || !g->local(x.dst)) G_FAIL(g, MI_EINVAL, "group: peer-copy transport reached a remote rank");
@@ -93,12 +100,13 @@ static int32_t run_xfers(mi_group *g, const std::vector<Xfer> &xs_list, const st
 // ---------------------------------------------------------------- lifecycle
 static int32_t group_finish_init(mi_group *g) {
     const int n = g->n_local();
-    g->xs.assign(n, nullptr); g->ev_x.assign(n, nullptr); g->ev_done.assign(n, nullptr); g->ev_h.assign(n, nullptr);
+    g->xs.assign(n, nullptr); g->ev_x.assign(n, nullptr); g->ev_in.assign(n, nullptr); g->ev_done.assign(n, nullptr); g->ev_h.assign(n, nullptr);
     g->recv.assign(n, DevBuf{}); g->stage.assign(n, DevBuf{});
     for (int i = 0; i < n; i++) {
         (void)hipSetDevice(g->dev[i]);
         G_HIP(g, hipStreamCreateWithFlags(&g->xs[i], hipStreamNonBlocking));
         G_HIP(g, hipEventCreateWithFlags(&g->ev_x[i], hipEventDisableTiming));
+        G_HIP(g, hipEventCreateWithFlags(&g->ev_in[i], hipEventDisableTiming));
         G_HIP(g, hipEventCreateWithFlags(&g->ev_done[i], hipEventDisableTiming));
         G_HIP(g, hipEventCreateWithFlags(&g->ev_h[i], hipEventDisableTiming));
     }
@@ -114,7 +122,7 @@ int32_t mi_group_destroy(mi_group *g) {
         if (g->ctx[i]) (void)hipStreamSynchronize(g->ctx[i]->stream);
         if (i < (int)g->xs.size() && g->xs[i]) { (void)hipStreamSynchronize(g->xs[i]); (void)hipStreamDestroy(g->xs[i]); }
         if (i < (int)g->comm.size() && g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
-        for (auto *v : {&g->ev_x, &g->ev_done, &g->ev_h}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
+        for (auto *v : {&g->ev_x, &g->ev_in, &g->ev_done, &g->ev_h}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
         if (i < (int)g->recv.size() && g->recv[i].p) (void)hipFree(g->recv[i].p);
         if (i < (int)g->stage.size() && g->stage[i].p) (void)hipFree(g->stage[i].p);
         if (g->ctx[i]) mi_shutdown(g->ctx[i]);
@@ -410,13 +418,44 @@ int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *d, mi_pk_sharded **out
         if (nb > max_b) max_b = nb;
         if (zhi - zlo > max_z) max_z = zhi - zlo;
     }
+    // ONE fixed-base plan for all parts (mode 1 exchanges buckets, so the parts must cut their scalars alike; and a part just
+    // under the 2^20-point threshold next to one just over it would otherwise pick different paths): the rule of mi_pk_load
+    // (prove.hip: tables for an MSM of >= 2^20 points while they fit in a third of the free memory, smallest group first),
+    // applied to the LARGEST part and the tightest device, then forced on every context through its knobs.  Knobs the caller
+    // set (mi_debug_set_prove_fixed_base) are kept.
+    u32 plan[3] = {1, 1, 1};   // A+K, B, Z: 1 = no tables
+    {
+        size_t budget = ~(size_t)0;
+        for (int i = 0; i < nl; i++) {
+            (void)hipSetDevice(g->dev[i]);
+            size_t fr = 0, tot = 0, sharers = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
+            for (int j = 0; j < nl; j++) sharers += g->dev[j] == g->dev[i] ? 1 : 0;
+            fr = fr / 3 / sharers;
+            if (fr < budget) budget = fr;
+        }
+        auto nwin_of = [](u32 c) { return (size_t)((256 + c - 1) / c); };
+        auto choose = [&](u32 c_auto, u64 n_max, size_t bytes_per_point) -> u32 {
+            const size_t need = nwin_of(c_auto) * n_max * bytes_per_point;
+            if (n_max < ((u64)1 << 20) || need > budget) return 1;
+            budget -= need;
+            return c_auto;
+        };
+        plan[2] = choose(20, max_z, sizeof(G1Aff));
+        plan[1] = choose(18, max_b, sizeof(G1Aff) + sizeof(G2Aff));
+        plan[0] = choose(19, max_w, 2 * sizeof(G1Aff));
+    }
     std::vector<int32_t> rcs(nl, MI_OK);
     std::vector<std::thread> th;
     for (int i = 0; i < nl; i++) th.emplace_back([&, i] {   // uploads (and table builds) of the parts run side by side, one host thread per device
         (void)hipSetDevice(g->dev[i]);
+        mi_ctx *ctx = g->ctx[i];
         ShardRange sr;
         range_of(d->nb_wires, W, g->rank0 + i, sr.w_lo, sr.w_hi); range_of(N - 1, W, g->rank0 + i, sr.z_lo, sr.z_hi);
-        rcs[i] = mi_pk_load_range(g->ctx[i], d, &spk->part[i], false, &sr);
+        u32 saved[3];
+        for (int k = 0; k < 3; k++) { saved[k] = ctx->fixed_knob[k]; if (!saved[k]) ctx->fixed_knob[k] = plan[k]; }
+        rcs[i] = mi_pk_load_range(ctx, d, &spk->part[i], false, &sr);
+        for (int k = 0; k < 3; k++) ctx->fixed_knob[k] = saved[k];
     });
     for (auto &t : th) t.join();
     for (int i = 0; i < nl; i++) if (rcs[i] != MI_OK) { g->err = mi_last_error(g->ctx[i]); int32_t rc = rcs[i]; mi_pk_sharded_free(g, spk); return rc; }
