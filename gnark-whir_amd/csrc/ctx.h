@@ -35,7 +35,7 @@ struct mi_ctx {
     mi_stats stats{};
     hipEvent_t ev[24]{};
     // scratch
-    alignas(16) unsigned char ntt_state[256];  // NttState (ntt.hip): root tables + plan knobs
+    alignas(16) unsigned char ntt_state[384];  // NttState (ntt.hip): root tables + plan knobs
     alignas(16) unsigned char msm_knobs[64];   // MsmKnobs (msm.hip)
     DevBuf ws[24];
     MsmSlot msm[MI_MSM_SLOTS];          // MSM / prove workspaces, see msm.hip / prove.hip

@@ -11,7 +11,7 @@
 // Bound: HBM for the load/store (64 B per element per pass), VALU (one 256-bit Montgomery product
 // per butterfly) for the stages -- see DESIGN.md for the measured split.
 #include "ctx.h"
-#include "ntt_tile.cuh"
+#include "ntt_wave.cuh"
 #include <cstring>
 
 struct NttState {
@@ -21,25 +21,35 @@ struct NttState {
     Fr *g_lo = nullptr, *g_hi = nullptr, *gi_lo = nullptr, *gi_hi = nullptr, *ninv = nullptr;
     Fr *g_hi_n = nullptr, *gi_hi_nd = nullptr;   // computeH-internal: g^(j 2^h) / N  and  g^-(j 2^h) / N * den
     u32 tw_h = 0;
+    // computeH's direct factor tables in the data's layout (NttPass::tw_direct / sc_direct), N entries each, built for one
+    // (log_n, first radix): twiddles of the M = N pass for the inverse and the forward root, coset shifts g^bitrev(i) / N and
+    // g^-bitrev(i) * den / N.  4 x 32 B x N of HBM (1 GiB at N = 2^23) buy 11 of computeH's ~107 products per element.
+    Fr *d_tw_inv = nullptr, *d_tw_fwd = nullptr, *d_sc_fwd = nullptr, *d_sc_inv = nullptr;
+    u32 d_log_n = 0xffffffffu, d_log_r0 = 0, d_npass = 0;
+    u32 direct_min_log_n = 12;   // below this the tables are not worth a launch
     // plan knobs (mi_debug_set_ntt_plan)
     // defaults from the tools/tune.py sweep at N = 2^23: 2^9-element tiles (16 KiB of LDS, 8 workgroups of 256
     // threads per CU), radices 2^7 * 2^7 * 2^9: 1.46 ms per transform vs 1.99 ms for 2^11 tiles
     u32 log_e = 9, max_contig = 9, max_strided = 7, threads = 256;
+    u32 wave_stages = 1;   // passes of radix >= 2^7 run their last / first seven stages in registers (k_ntt_pass_wave); 0 = all through LDS
 };
 static NttState *state_of(mi_ctx *ctx) {
-    static_assert(sizeof(NttState) <= 256, "NttState lives in ctx->ntt_state");
+    static_assert(sizeof(NttState) <= 384, "NttState lives in ctx->ntt_state");
     return reinterpret_cast<NttState *>(ctx->ntt_state);
 }
 
 __global__ void k_ntt_pass(Fr *dst, const Fr *src, NttPass p, NttTables t);
+__global__ void k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t);
 void mi_ntt_state_init(mi_ctx *ctx) {
+    static_assert(sizeof(NttState) <= sizeof(ctx->ntt_state), "NttState lives in ctx->ntt_state");
     new (ctx->ntt_state) NttState();
     (void)hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_pass_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
     Fr **all[] = {&st->small_f, &st->small_i, &st->tw64k_f, &st->tw64k_i, &st->g_hi_n, &st->gi_hi_nd, &st->tw_lo_f, &st->tw_hi_f, &st->tw_lo_i, &st->tw_hi_i,
-                  &st->g_lo, &st->g_hi, &st->gi_lo, &st->gi_hi, &st->ninv};
+                  &st->g_lo, &st->g_hi, &st->gi_lo, &st->gi_hi, &st->ninv, &st->d_tw_inv, &st->d_tw_fwd, &st->d_sc_fwd, &st->d_sc_inv};
     for (Fr **p : all) if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
@@ -67,6 +77,60 @@ __global__ void __launch_bounds__(1024) k_ntt_pass(Fr *dst, const Fr *src, NttPa
         __syncthreads();
     }
     ntt_tile_store(p, t, dst, tile, threadIdx.x, blockDim.x, lds);
+}
+
+// The same pass with the seven stages at distance <= 64 of every 128-row group done in REGISTERS by one wavefront
+// (ntt_wave.cuh): the tile makes two LDS round trips (in and out of the registers) plus one per stage at distance >= 128,
+// instead of one per stage, and two barriers plus one per such stage.  Needs log_r >= 7.
+__global__ void __launch_bounds__(256) k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t) {
+    extern __shared__ U4 lds[];
+    const u64 tile = blockIdx.x;
+    const u32 PL = ntt_plane_slots(p);
+    ntt_tile_load(p, t, src, tile, threadIdx.x, blockDim.x, lds);
+    __syncthreads();
+    if (!p.dit)   // DIF: distances R/2 ... 128 first
+        for (u32 s = 0; s + 7 < p.log_r; s++) {
+            ntt_tile_stage(p, t, s, threadIdx.x, blockDim.x, lds);
+            __syncthreads();
+        }
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const u32 nsub = 1u << (p.log_r + p.log_c - 7);
+    for (u32 sb = wave; sb < nsub; sb += nwaves) {   // sub-block = 128 consecutive rows of one column: touched by this wave only
+        const u32 col = sb & ((1u << p.log_c) - 1), base = (sb >> p.log_c) << 7;
+        u32 ra, rb, wa, wb;
+        if (!p.dit) { ra = base + lane; rb = ra + 64; wa = base + 2 * lane; wb = wa + 1; }
+        else { ra = base + 2 * lane; rb = ra + 1; wa = base + lane; wb = wa + 64; }
+        Fr x0 = lds_get(lds, PL, ntt_lds_slot(p, ra, col)), x1 = lds_get(lds, PL, ntt_lds_slot(p, rb, col));
+        wave_ntt128(x0, x1, lane, p.dit != 0, t.small);
+        lds_put(lds, PL, ntt_lds_slot(p, wa, col), x0);
+        lds_put(lds, PL, ntt_lds_slot(p, wb, col), x1);
+    }
+    __syncthreads();
+    if (p.dit)    // DIT: distances 128 ... R/2 last
+        for (u32 s = 7; s < p.log_r; s++) {
+            ntt_tile_stage(p, t, s, threadIdx.x, blockDim.x, lds);
+            __syncthreads();
+        }
+    ntt_tile_store(p, t, dst, tile, threadIdx.x, blockDim.x, lds);
+}
+
+// direct factor tables (NttPass::tw_direct / sc_direct), one thread per entry, square-and-multiply
+__global__ void k_tw_layout(Fr *out, u32 log_n, u32 log_r, Fr w) {   // the M = N pass: element g = (rho << log_s) | lo
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (1u << log_n)) return;
+    const u32 log_s = log_n - log_r;
+    u32 e = (g & ((1u << log_s) - 1)) * bitrev_u32(g >> log_s, log_r);   // < N
+    Fr acc = Fr::one(), b = w;
+    while (e) { if (e & 1) acc = acc * b; b = fe_sqr(b); e >>= 1; }
+    out[g] = acc;
+}
+__global__ void k_sc_layout(Fr *out, u32 log_n, Fr base, Fr c) {     // out[i] = c * base^bitrev_N(i)
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << log_n)) return;
+    u32 e = bitrev_u32(i, log_n);
+    Fr acc = c, b = base;
+    while (e) { if (e & 1) acc = acc * b; b = fe_sqr(b); e >>= 1; }
+    out[i] = acc;
 }
 
 // a[i] = a[i]*b[i] - c[i]      (computeH's pointwise step; its den factor is folded into the last transform)
@@ -135,6 +199,42 @@ static int32_t ensure_tables(mi_ctx *ctx, u32 log_n) {
     return MI_OK;
 }
 
+// computeH's direct tables for (log_n, current plan); a failure to allocate them only means the composed-table path runs
+static int32_t ensure_direct(mi_ctx *ctx, u32 log_n) {
+    NttState *st = state_of(ctx);
+    const NttPlan pl = ntt_make_plan(log_n, st->max_contig, st->max_strided);
+    if (st->d_log_n == log_n && st->d_log_r0 == pl.log_r[0] && st->d_npass == pl.n_pass) return MI_OK;
+    Fr **four[] = {&st->d_tw_inv, &st->d_tw_fwd, &st->d_sc_fwd, &st->d_sc_inv};
+    for (Fr **p : four) if (*p) { (void)hipFree(*p); *p = nullptr; }
+    st->d_log_n = 0xffffffffu;
+    if (log_n < st->direct_min_log_n) return MI_OK;
+    MI_TRY(ensure_tables(ctx, log_n));
+    const size_t bytes = sizeof(Fr) << log_n;
+    for (Fr **p : four)
+        if (hipMalloc((void **)p, bytes) != hipSuccess) {   // no room: stay on the composed tables
+            (void)hipGetLastError();
+            for (Fr **q : four) if (*q) { (void)hipFree(*q); *q = nullptr; }
+            return MI_OK;
+        }
+    const Fr w = domain_generator(log_n), wi = fe_inv(w), g = fe_from_u32<FrParams>(5), gi = fe_inv(g);
+    Fr nn = Fr::zero();
+    nn.l[0] = (u32)(1u << log_n);
+    const Fr ninv = fe_inv(fe_to_mont(nn));
+    Fr gn = g;
+    for (u32 k = 0; k < log_n; k++) gn = fe_sqr(gn);
+    const Fr den = fe_inv(gn - Fr::one());
+    const unsigned blocks = (unsigned)(((size_t)1 << log_n) + 255) / 256;
+    if (pl.n_pass > 1) {
+        hipLaunchKernelGGL(k_tw_layout, dim3(blocks), dim3(256), 0, ctx->stream, st->d_tw_inv, log_n, pl.log_r[0], wi);
+        hipLaunchKernelGGL(k_tw_layout, dim3(blocks), dim3(256), 0, ctx->stream, st->d_tw_fwd, log_n, pl.log_r[0], w);
+    }
+    hipLaunchKernelGGL(k_sc_layout, dim3(blocks), dim3(256), 0, ctx->stream, st->d_sc_fwd, log_n, g, ninv);          // variant 2
+    hipLaunchKernelGGL(k_sc_layout, dim3(blocks), dim3(256), 0, ctx->stream, st->d_sc_inv, log_n, gi, ninv * den);   // variant 3
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    st->d_log_n = log_n; st->d_log_r0 = pl.log_r[0]; st->d_npass = pl.n_pass;
+    return MI_OK;
+}
+
 // One transform of size 2^log_n: dst <- NTT(src[0..n_valid) zero padded).  dst == src allowed.
 // variant (computeH only): 1 = inverse without the 1/N scaling; 2 = forward coset with 1/N folded into the shift tables;
 // 3 = inverse coset with den folded into its scaling.  0 = exactly fft.Domain's FFT / FFTInverse.
@@ -174,13 +274,21 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
             p.scale = store_scale;
         }
         p.n_valid = step == 0 ? n_valid : (1u << log_n);
+        // computeH's direct tables (variant != 0 only): the twiddle of the M = N pass, the coset shift of the contiguous pass
+        const bool direct = variant != 0 && st->d_log_n == log_n && st->d_sc_fwd;
+        if (direct && p.twiddle && i == 0 && pl.n_pass > 1) p.tw_direct = inverse ? st->d_tw_inv : st->d_tw_fwd;
+        if (direct && variant == 2 && p.scale == 1) p.sc_direct = st->d_sc_fwd;
+        if (direct && variant == 3 && p.scale == 3) p.sc_direct = st->d_sc_inv;
+        const bool wave = p.log_r >= 7 && st->wave_stages;
+        p.lds_pad = wave && p.log_s != 0 ? 1 : 0;
         u32 tiles = 1u << (log_n - p.log_r - p.log_c);
-        size_t lds_bytes = (size_t)32 << (p.log_r + p.log_c);
+        size_t lds_bytes = (size_t)32 * ntt_plane_slots(p);
         u32 E = 1u << (p.log_r + p.log_c);
         // one butterfly per thread per stage when the tile allows: 64 KiB of LDS admits two workgroups per CU,
         // so 1024-thread workgroups are what fills the SIMDs (8 waves each) and hides the mad->addc chains
         u32 threads = E / 2 >= st->threads ? st->threads : (E / 2 >= 64 ? E / 2 : 64);
-        hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(threads), lds_bytes, ctx->stream, dst, cur_src, p, t);
+        if (wave) hipLaunchKernelGGL(k_ntt_pass_wave, dim3(tiles), dim3(threads > 256 ? 256 : threads), lds_bytes, ctx->stream, dst, cur_src, p, t);
+        else hipLaunchKernelGGL(k_ntt_pass, dim3(tiles), dim3(threads), lds_bytes, ctx->stream, dst, cur_src, p, t);
         MI_CHECK_HIP(ctx, hipGetLastError());
         cur_src = dst;
         ctx->stats.ntt_launches++;
@@ -196,6 +304,7 @@ int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t 
 int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                               size_t n_constraints, mi_fr *h_out) {
     const size_t n = (size_t)1 << log_n;
+    MI_TRY(ensure_direct(ctx, log_n));
     MI_TRY(mi_reserve(ctx, ctx->ws[0], n * sizeof(Fr)));
     MI_TRY(mi_reserve(ctx, ctx->ws[1], n * sizeof(Fr)));
     Fr *A = (Fr *)h_out, *B = (Fr *)ctx->ws[0].p, *C = (Fr *)ctx->ws[1].p;
@@ -224,6 +333,13 @@ int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, 
         return MI_EINVAL;
     NttState *st = state_of(ctx);
     st->log_e = log_e; st->max_contig = max_contig; st->max_strided = max_strided;
+    return MI_OK;
+}
+int32_t mi_debug_set_ntt_wave_stages(mi_ctx *ctx, uint32_t on, uint32_t direct_min_log_n) {
+    if (!ctx || on > 1) return MI_EINVAL;
+    NttState *st = state_of(ctx);
+    st->wave_stages = on; st->direct_min_log_n = direct_min_log_n;
+    st->d_npass = 0;   // force the next computeH to re-decide about its direct tables
     return MI_OK;
 }
 int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads) {

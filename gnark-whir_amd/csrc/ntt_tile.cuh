@@ -22,7 +22,8 @@
 #pragma once
 #include "field.cuh"
 
-struct U4 { u32 x, y, z, w; };  // 16-byte LDS slot (uint4 without pulling hip headers into host builds)
+struct alignas(16) U4 { u32 x, y, z, w; };  // 16-byte LDS slot (uint4 without pulling hip headers into host builds); the alignment is what lets
+                                            // the compiler use ds_read_b128 / ds_write_b128 (round 1's unaligned struct compiled to ds_read2_b32 pairs)
 
 struct NttTables {
     const Fr *small;    // small[j] = w_4096^j, j < 2048  (in-tile butterfly twiddles for every radix <= 2^12)
@@ -45,6 +46,13 @@ struct NttPass {
                     // 4 store * sc[i]; 5 store * sc_hi[0] (constant).  Constant factors (1/N, and inside computeH
                     // the 1/N of the preceding inverse transform or den) ride in sc_hi for free
     u32 n_valid;    // loads at global index >= n_valid read as zero (fused zero padding)
+    u32 lds_pad;    // strided passes: one unused slot after the C columns of every row (C + 1 slots per row): a wave reading a
+                    // column (stride C slots = 64 B at C = 4) then walks all banks instead of four of them
+    // Direct factor tables IN THE DATA'S LAYOUT (element g multiplies table[g]; coalesced with the data itself), or null:
+    // tw_direct replaces the inter-pass twiddle formed from two tables by one product, sc_direct the coset / 1/N / den scaling.
+    // One product per element instead of two, for 32 B of extra traffic per element on a VALU-bound pass.
+    const Fr *tw_direct;
+    const Fr *sc_direct;
 };
 
 MI_HD u32 bitrev_u32(u32 x, u32 bits) {
@@ -70,7 +78,11 @@ MI_HD u64 ntt_global_index(const NttPass &p, u64 tile, u32 rho, u32 col) {
     return (hi << (p.log_r + p.log_s)) + ((u64)rho << p.log_s) + lo0 + col;
 }
 MI_HD u32 ntt_lds_slot(const NttPass &p, u32 rho, u32 col) {
-    return p.log_s == 0 ? (col << p.log_r) + rho : (rho << p.log_c) + col;
+    return p.log_s == 0 ? (col << p.log_r) + rho : rho * ((1u << p.log_c) + p.lds_pad) + col;
+}
+// slots of one plane of the tile's LDS image (the two planes hold the low / high 16 bytes of every element)
+MI_HD u32 ntt_plane_slots(const NttPass &p) {
+    return p.log_s == 0 ? 1u << (p.log_r + p.log_c) : ((1u << p.log_c) + p.lds_pad) << p.log_r;
 }
 MI_HD void lds_put(U4 *lds, u32 plane_elems, u32 slot, const Fr &v) {
     lds[slot] = U4{v.l[0], v.l[1], v.l[2], v.l[3]};
@@ -83,13 +95,33 @@ MI_HD Fr lds_get(const U4 *lds, u32 plane_elems, u32 slot) {
     v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
     return v;
 }
-// inter-pass twiddle of (rho, lo): w_M^(lo * bitrev_R(rho)) = w_N^((lo * bitrev_R(rho)) << (log_n - log_m))
-MI_HD Fr ntt_interpass_twiddle(const NttPass &p, const NttTables &t, u32 rho, u64 g) {
-    u32 lo = (u32)(g & (((u64)1 << p.log_s) - 1));
-    u32 x = lo * bitrev_u32(rho, p.log_r);                      // exponent of w_M, x < M
-    const u32 log_m = p.log_r + p.log_s;
-    if (t.tw_64k && log_m <= 16) return t.tw_64k[x << (16 - log_m)];   // w_M^x = w_65536^(x * 65536/M)
-    return pow_from_tables(t.tw_lo, t.tw_hi, t.tw_h, x << (p.log_n - log_m));
+// (inter-pass twiddle of (rho, lo): w_M^(lo * bitrev_R(rho)) = w_N^((lo * bitrev_R(rho)) << (log_n - log_m)), see ntt_edge_factor)
+// The ONE factor (if any) an element is multiplied by on its way into the tile (phase 0: coset / constant pre-scale, DIT
+// pre-twiddle) or out of it (phase 1: DIF post-twiddle, inverse / coset post-scale).  A pass never has a scale and a twiddle on
+// the same side (the scales sit on the contiguous pass's load or store, or on the side opposite to the twiddle), so each phase
+// has one composing product site and one applying product site -- the product is ~330 instructions and is inlined.
+MI_HD bool ntt_edge_factor(const NttPass &p, const NttTables &t, u32 rho, u64 g, u32 phase, Fr &f) {
+    const bool sc = phase == 0 ? (p.scale == 1 || p.scale == 2) : p.scale >= 3;
+    const bool tw = p.twiddle && (phase == 0) == (p.dit != 0);
+    const Fr *lo, *hi;
+    u32 e;
+    if (sc) {
+        if (p.scale == 5) { f = t.sc_hi[0]; return true; }
+        if (p.sc_direct) { f = p.sc_direct[g]; return true; }
+        e = (p.scale == 1 || p.scale == 3) ? bitrev_u32((u32)g, p.log_n) : (u32)g;
+        lo = t.sc_lo; hi = t.sc_hi;
+    } else if (tw) {
+        const u32 log_m = p.log_r + p.log_s;
+        if (p.tw_direct) { f = p.tw_direct[g & (((u64)1 << log_m) - 1)]; return true; }
+        const u32 x = (u32)(g & (((u64)1 << p.log_s) - 1)) * bitrev_u32(rho, p.log_r);   // exponent of w_M, x < M
+        if (t.tw_64k && log_m <= 16) { f = t.tw_64k[x << (16 - log_m)]; return true; }   // w_M^x = w_65536^(x * 65536/M)
+        e = x << (p.log_n - log_m);
+        lo = t.tw_lo; hi = t.tw_hi;
+    } else {
+        return false;
+    }
+    f = pow_from_tables(lo, hi, t.tw_h, e);
+    return true;
 }
 
 // phase 1: global -> LDS (+ fused zero padding, coset pre-scale, DIT pre-twiddle)
@@ -101,11 +133,9 @@ MI_HD void ntt_tile_load(const NttPass &p, const NttTables &t, const Fr *data, u
         if (p.log_s == 0) { rho = e & ((1u << p.log_r) - 1); col = e >> p.log_r; }
         else { col = e & ((1u << p.log_c) - 1); rho = e >> p.log_c; }
         u64 g = ntt_global_index(p, tile, rho, col);
-        Fr v = g < p.n_valid ? data[g] : Fr::zero();
-        if (p.scale == 1) v = v * pow_from_tables(t.sc_lo, t.sc_hi, t.tw_h, bitrev_u32((u32)g, p.log_n));
-        else if (p.scale == 2) v = v * pow_from_tables(t.sc_lo, t.sc_hi, t.tw_h, (u32)g);
-        if (p.dit && p.twiddle) v = v * ntt_interpass_twiddle(p, t, rho, g);
-        lds_put(lds, E, ntt_lds_slot(p, rho, col), v);
+        Fr v = g < p.n_valid ? data[g] : Fr::zero(), f;
+        if (ntt_edge_factor(p, t, rho, g, 0, f)) v = v * f;
+        lds_put(lds, ntt_plane_slots(p), ntt_lds_slot(p, rho, col), v);
     }
 }
 // phase 2: one radix-2 stage over the rows.  stage = 0 .. log_r-1 in execution order.
@@ -123,18 +153,18 @@ MI_HD void ntt_tile_stage(const NttPass &p, const NttTables &t, u32 stage, u32 t
         u32 r0 = ((q >> log_d) << (log_d + 1)) + j;
         u32 r1 = r0 + d;
         u32 s0 = ntt_lds_slot(p, r0, col), s1 = ntt_lds_slot(p, r1, col);
-        Fr x = lds_get(lds, E, s0), y = lds_get(lds, E, s1);
+        const u32 PL = ntt_plane_slots(p);
+        Fr x = lds_get(lds, PL, s0), y = lds_get(lds, PL, s1);
         // twiddle w_(2d)^j = w_4096^(j * 2048/d)
         const Fr &w = t.small[j << (11 - log_d)];
+        Fr a = p.dit ? y : x - y;   // one product site for both butterflies
+        if (j) a = a * w;
         if (p.dit) {
-            if (j) y = y * w;
-            lds_put(lds, E, s0, x + y);
-            lds_put(lds, E, s1, x - y);
+            lds_put(lds, PL, s0, x + a);
+            lds_put(lds, PL, s1, x - a);
         } else {
-            Fr dd = x - y;
-            if (j) dd = dd * w;
-            lds_put(lds, E, s0, x + y);
-            lds_put(lds, E, s1, dd);
+            lds_put(lds, PL, s0, x + y);
+            lds_put(lds, PL, s1, a);
         }
     }
 }
@@ -146,11 +176,8 @@ MI_HD void ntt_tile_store(const NttPass &p, const NttTables &t, Fr *data, u64 ti
         if (p.log_s == 0) { rho = e & ((1u << p.log_r) - 1); col = e >> p.log_r; }
         else { col = e & ((1u << p.log_c) - 1); rho = e >> p.log_c; }
         u64 g = ntt_global_index(p, tile, rho, col);
-        Fr v = lds_get(lds, E, ntt_lds_slot(p, rho, col));
-        if (!p.dit && p.twiddle) v = v * ntt_interpass_twiddle(p, t, rho, g);
-        if (p.scale == 3) v = v * pow_from_tables(t.sc_lo, t.sc_hi, t.tw_h, bitrev_u32((u32)g, p.log_n));
-        else if (p.scale == 4) v = v * pow_from_tables(t.sc_lo, t.sc_hi, t.tw_h, (u32)g);
-        else if (p.scale == 5) v = v * t.sc_hi[0];
+        Fr v = lds_get(lds, ntt_plane_slots(p), ntt_lds_slot(p, rho, col)), f;
+        if (ntt_edge_factor(p, t, rho, g, 1, f)) v = v * f;
         data[g] = v;
     }
 }

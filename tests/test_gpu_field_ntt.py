@@ -172,3 +172,22 @@ def test_invalid_arguments_are_rejected_not_executed(ctx):
     assert ctx.lib.mi_debug_set_msm_plan(ctx.h, 8, 1, 8, 0, 0) != 0      # items of one entry never converge
     assert ctx.lib.mi_debug_set_ntt_plan(ctx.h, 13, 9, 7) != 0
     assert b"" == b"" and ctx.lib.mi_last_error(ctx.h) is not None
+
+
+@pytest.mark.parametrize("log_n", [7, 9, 13, 16, 18])
+def test_ntt_register_and_lds_stage_paths_agree_with_oracle(ctx, log_n):
+    """every mode with the wavefront-register stages (default for radices >= 2^7) and with every stage through LDS; computeH with
+    and without its data-layout twiddle / coset tables"""
+    n = 1 << log_n
+    a = cref.gen_scalars(n, 400 + log_n, 0)
+    want = {f: cref.ntt(a, log_n, f) for f in range(8)}
+    b = cref.gen_scalars(n, 401 + log_n, 1); c = cref.field_op(0, 2, a, b)
+    want_h = cref.compute_h(log_n, a[: n - 3], b[: n - 3], c[: n - 3])
+    try:
+        for on, dmin in ((1, 7), (0, 29), (1, 29), (0, 7)):
+            assert ctx.lib.mi_debug_set_ntt_wave_stages(ctx.h, on, dmin) == 0
+            for f in range(8):
+                assert np.array_equal(ctx.ntt(a, log_n, f), want[f]), (on, f)
+            assert np.array_equal(ctx.compute_h(log_n, a[: n - 3], b[: n - 3], c[: n - 3]), want_h), (on, dmin)
+    finally:
+        assert ctx.lib.mi_debug_set_ntt_wave_stages(ctx.h, 1, 12) == 0
