@@ -31,6 +31,7 @@ EXPORTS = [
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
     "mi_group_last_error", "mi_group_transport", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
     "mi_groth16_prove_sharded", "mi_msm_g1_sharded", "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
+    "mi_pk_raw_inspect", "mi_pk_load_raw",
 ]
 
 
@@ -45,6 +46,21 @@ class PkDesc(C.Structure):
         ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p),
         ("committed_wires", C.c_void_p), ("n_committed", C.c_uint64),
     ]
+
+
+class PkRawInfo(C.Structure):
+    _fields_ = [("log_n", C.c_uint32), ("n_commitment_keys", C.c_uint32)] + [(n, C.c_uint64) for n in (
+        "nb_wires", "n_g1_a", "n_g1_b", "n_g1_z", "n_g1_k", "n_g2_b", "off_alpha1", "off_g1_a", "off_g1_b", "off_g1_z", "off_g1_k",
+        "off_beta2", "off_g2_b", "off_infinity_a", "off_infinity_b")] + [
+        ("n_basis", C.c_uint64 * 16), ("off_basis", C.c_uint64 * 16), ("off_basis_exp_sigma", C.c_uint64 * 16)]
+
+
+def pk_raw_inspect(blob: bytes):
+    """section offsets / counts of a gnark ProvingKey.WriteRawTo stream (host only); raises MiError if the layout does not parse"""
+    info = PkRawInfo(); buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+    if load().mi_pk_raw_inspect(buf, C.c_size_t(len(blob)), C.byref(info)) != 0:
+        raise MiError("mi_pk_raw_inspect: not a gnark v0.11.0 ProvingKey.WriteRawTo stream (as recalled)")
+    return info
 
 
 class Stats(C.Structure):
@@ -265,6 +281,15 @@ class Context:
         f = self.lib.mi_pk_load_dev if device_points else self.lib.mi_pk_load
         self._ck(f(self.h, C.byref(d), C.byref(h)))
         return h
+
+    def pk_load_raw(self, blob: bytes, nb_public, committed_wires=None):
+        """gnark ProvingKey.WriteRawTo stream -> (device-resident key, [Pedersen key handles])"""
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob); h = C.c_void_p()
+        ped = (C.c_void_p * 16)(); nped = C.c_uint32()
+        cw = None if committed_wires is None or not len(committed_wires) else np.ascontiguousarray(committed_wires, dtype=np.uint32)
+        self._ck(self.lib.mi_pk_load_raw(self.h, buf, C.c_size_t(len(blob)), C.c_uint32(nb_public), _p(cw), C.c_size_t(0 if cw is None else cw.shape[0]),
+                                         C.byref(h), ped, C.byref(nped)))
+        return h, [C.c_void_p(ped[i]) for i in range(nped.value)]
 
     def pk_free(self, pkh):
         self._ck(self.lib.mi_pk_free(self.h, pkh))

@@ -26,7 +26,7 @@ static int32_t upload(mi_ctx *ctx, void **dst, const void *src, size_t bytes) {
     return MI_OK;
 }
 
-int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr) {
+int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr, bool adopt) {
     if (!ctx || !d || !out) return MI_EINVAL;
     *out = nullptr;
     if (sr && device_points) return MI_EINVAL;
@@ -69,6 +69,7 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
     int32_t rc = MI_OK;
     if (device_points) {
         pk->g1_a = (void *)d->g1_a; pk->g1_b = (void *)d->g1_b; pk->g1_k = (void *)d->g1_k; pk->g1_z = (void *)d->g1_z; pk->g2_b = (void *)d->g2_b;
+        pk->owns_points = adopt;   // mi_pk_load_raw hands its converted arrays over; on failure they stay the caller's (below)
     } else {
         pk->owns_points = true;
         if (rc == MI_OK) rc = upload(ctx, &pk->g1_a, d->g1_a + a0, pk->n_a * 64);
@@ -136,7 +137,7 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
         if (rc == MI_OK) rc = group(pk->c_ak, &pk->pre_a, pk->a_full, 1, &pk->pre_k, pk->k_full, 1, pk->nb_wires);
     }
     if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pk upload sync failed"; rc = MI_EHIP; }
-    if (rc != MI_OK) { mi_pk_free(ctx, pk); return rc; }
+    if (rc != MI_OK) { if (device_points) pk->owns_points = false; mi_pk_free(ctx, pk); return rc; }
     // the compact A and K copies are not needed any more when the library owns them; nor are plain bases that have tables
     if (pk->owns_points) { (void)hipFree(pk->g1_a); (void)hipFree(pk->g1_k); pk->g1_a = pk->g1_k = nullptr; }
     if (pk->c_ak) { (void)hipFree(pk->a_full); (void)hipFree(pk->k_full); pk->a_full = pk->k_full = nullptr; }
@@ -180,6 +181,14 @@ int32_t mi_pedersen_pk_load(mi_ctx *ctx, const mi_g1_affine *basis, const mi_g1_
     if (rc == MI_OK) rc = upload(ctx, &pk->basis_exp_sigma, basis_exp_sigma, n * 64);
     if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pedersen key upload failed"; rc = MI_EHIP; }
     if (rc != MI_OK) { mi_pedersen_pk_free(ctx, pk); return rc; }
+    *out = pk;
+    return MI_OK;
+}
+int32_t mi_pedersen_pk_adopt(mi_ctx *ctx, void *basis_dev, void *basis_exp_sigma_dev, size_t n, mi_pedersen_pk **out) {
+    if (!ctx || !out) return MI_EINVAL;
+    mi_pedersen_pk *pk = new (std::nothrow) mi_pedersen_pk();
+    if (!pk) return MI_ENOMEM;
+    pk->basis = basis_dev; pk->basis_exp_sigma = basis_exp_sigma_dev; pk->n = n;
     *out = pk;
     return MI_OK;
 }

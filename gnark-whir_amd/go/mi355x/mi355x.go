@@ -36,6 +36,7 @@ import (
 	"github.com/consensys/gnark/constraint"
 	cs "github.com/consensys/gnark/constraint/bn254"
 	"github.com/consensys/gnark/constraint/solver"
+	fcs "github.com/consensys/gnark/frontend/cs"
 )
 
 // ProvingKey embeds gnark's key and the device-resident handle (cf. icicle_bn254.ProvingKey).
@@ -76,11 +77,12 @@ func (pk *ProvingKey) setup(r1cs *cs.R1CS, device int) error {
 		d.log_n = C.uint32_t(log2(pk.Domain.Cardinality))
 		d.nb_public = C.uint32_t(r1cs.GetNbPublicVariables())
 		d.nb_wires = C.uint64_t(len(pk.InfinityA))
-		d.g1_a, d.n_g1_a = (*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.A[0])), C.uint64_t(len(pk.G1.A))
-		d.g1_b, d.n_g1_b = (*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.B[0])), C.uint64_t(len(pk.G1.B))
-		d.g1_k, d.n_g1_k = (*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.K[0])), C.uint64_t(len(pk.G1.K))
-		d.g1_z, d.n_g1_z = (*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Z[0])), C.uint64_t(len(pk.G1.Z))
-		d.g2_b, d.n_g2_b = (*C.mi_g2_affine)(unsafe.Pointer(&pk.G2.B[0])), C.uint64_t(len(pk.G2.B))
+		// &s[0] panics on an empty slice (all-public circuits have no K points, tiny ones may lack A or B): g1/g2 guard it
+		d.g1_a, d.n_g1_a = g1(pk.G1.A), C.uint64_t(len(pk.G1.A))
+		d.g1_b, d.n_g1_b = g1(pk.G1.B), C.uint64_t(len(pk.G1.B))
+		d.g1_k, d.n_g1_k = g1(pk.G1.K), C.uint64_t(len(pk.G1.K))
+		d.g1_z, d.n_g1_z = g1(pk.G1.Z), C.uint64_t(len(pk.G1.Z))
+		d.g2_b, d.n_g2_b = g2(pk.G2.B), C.uint64_t(len(pk.G2.B))
 		d.alpha1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Alpha))
 		d.beta1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Beta))
 		d.delta1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Delta))
@@ -115,36 +117,55 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 	proof := &groth16_bn254.Proof{Commitments: make([]bn254.G1Affine, len(commitmentInfo))}
 	privateCommittedValues := make([][]fr.Element, len(commitmentInfo))
 
-	// BSB22 commitment hint: the Pedersen MSM runs mid-solve through the same device MSM (SURVEY 8f N1)
+	// BSB22 commitment hint, as gnark v0.11.0 prove.go registers it: ONE override on the placeholder hint id; in[0] is the
+	// commitment's index i, the next len(PublicAndCommitmentCommitted) inputs are hashed with the commitment, the rest are the
+	// private committed values.  (gnark <= v0.9 registered one override per commitmentInfo[i].HintID instead: if this does
+	// not compile against the module cache at hand, that is the other shape -- same body, i captured per closure.)
+	// The Pedersen MSM runs mid-solve on the device (mi_pedersen_commit, SURVEY 8f N1); the hash-to-field stays in Go and uses
+	// the CONFIGURED opt.HashToFieldFn over constraint.SerializeCommitment(commitment, hashed, ...), exactly like prove.go --
+	// round 1's shim hashed only the commitment point, which breaks every circuit with public committed inputs (the WHIR
+	// circuit has them: mtUtilities.go:92,452).
 	solverOpts := opt.SolverOpts[:len(opt.SolverOpts):len(opt.SolverOpts)]
-	solverOpts = append(solverOpts, solver.OverrideHint(commitmentInfo.GetHintID(0), func(_ *big.Int, in []*big.Int, out []*big.Int) error {
-		// NOTE: one override per commitment in gnark; shown for the single-commitment WHIR circuit
-		i := 0
-		nPriv := len(commitmentInfo[i].PrivateCommitted)
-		vals := make([]fr.Element, nPriv)
-		for j, v := range in[len(in)-nPriv:] {
-			vals[j].SetBigInt(v)
-		}
-		privateCommittedValues[i] = vals
-		// device-resident Pedersen key (mi_pedersen_pk_load once per key, see pedersenKey below)
-		pk.mu.Lock()
-		defer pk.mu.Unlock()
-		ppk, err := pk.pedersenKey(i)
-		if err != nil {
-			return err
-		}
-		if rc := C.mi_pedersen_commit(pk.ctx, ppk, (*C.mi_fr)(unsafe.Pointer(&vals[0])), C.size_t(len(vals)),
-			(*C.mi_g1_affine)(unsafe.Pointer(&proof.Commitments[i]))); rc != C.MI_OK {
-			return status(pk.ctx, rc)
-		}
-		// challenge = HashToField(commitment || public committed), DST "bsb22-commitment" (stays in Go)
-		hashed, err := fr.Hash(proof.Commitments[i].Marshal(), []byte(constraint.CommitmentDst), 1)
-		if err != nil {
-			return err
-		}
-		hashed[0].BigInt(out[0])
-		return nil
-	}))
+	if len(commitmentInfo) > 0 {
+		bsb22ID := solver.GetHintID(fcs.Bsb22CommitmentComputePlaceholder)
+		solverOpts = append(solverOpts, solver.OverrideHint(bsb22ID, func(_ *big.Int, in []*big.Int, out []*big.Int) error {
+			i := int(in[0].Int64())
+			if i < 0 || i >= len(commitmentInfo) {
+				return fmt.Errorf("mi355x: commitment index %d out of range", i)
+			}
+			in = in[1:]
+			hashed := in[:len(commitmentInfo[i].PublicAndCommitmentCommitted)]
+			committed := in[len(hashed):]
+			vals := make([]fr.Element, len(commitmentInfo[i].PrivateCommitted))
+			for j, inJ := range committed {
+				vals[j].SetBigInt(inJ)
+			}
+			privateCommittedValues[i] = vals
+			if len(vals) > 0 { // an empty commitment is the point at infinity (the zero value already there)
+				pk.mu.Lock()
+				ppk, err := pk.pedersenKey(i)
+				if err == nil {
+					err = status(pk.ctx, C.mi_pedersen_commit(pk.ctx, ppk, (*C.mi_fr)(unsafe.Pointer(&vals[0])), C.size_t(len(vals)),
+						(*C.mi_g1_affine)(unsafe.Pointer(&proof.Commitments[i]))))
+				}
+				pk.mu.Unlock()
+				if err != nil {
+					return err
+				}
+			}
+			opt.HashToFieldFn.Write(constraint.SerializeCommitment(proof.Commitments[i].Marshal(), hashed, (fr.Bits-1)/8+1))
+			hashBts := opt.HashToFieldFn.Sum(nil)
+			opt.HashToFieldFn.Reset()
+			nbBuf := fr.Bytes
+			if opt.HashToFieldFn.Size() < fr.Bytes {
+				nbBuf = opt.HashToFieldFn.Size()
+			}
+			var res fr.Element
+			res.SetBytes(hashBts[:nbBuf])
+			res.BigInt(out[0])
+			return nil
+		}))
+	}
 
 	_solution, err := r1cs.Solve(fullWitness, solverOpts...)
 	if err != nil {
@@ -153,9 +174,19 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 	solution := _solution.(*cs.R1CSSolution)
 	W, a, b, c := []fr.Element(solution.W), []fr.Element(solution.A), []fr.Element(solution.B), []fr.Element(solution.C)
 
-	// CommitmentPok (ProveKnowledge + Fold) stays on gnark's CPU code path: O(#committed) work.
+	// CommitmentPok as prove.go builds it: challenge = fr.Hash(commitment WIRE VALUES, "G16-BSB22"), then
+	// pedersen.BatchProve = sum_i challenge^i * ProveKnowledge_i; both MSMs on the device (mi_pedersen_prove_knowledge),
+	// the fold over len(commitmentInfo) points on the host (mi_pedersen_fold).
 	if len(commitmentInfo) > 0 {
-		if proof.CommitmentPok, err = foldedPok(pk, privateCommittedValues, proof.Commitments); err != nil {
+		commitmentsSerialized := make([]byte, fr.Bytes*len(commitmentInfo))
+		for i := range commitmentInfo {
+			copy(commitmentsSerialized[fr.Bytes*i:], W[commitmentInfo[i].CommitmentIndex].Marshal())
+		}
+		challenge, err := fr.Hash(commitmentsSerialized, []byte("G16-BSB22"), 1)
+		if err != nil {
+			return nil, err
+		}
+		if proof.CommitmentPok, err = pk.batchProve(privateCommittedValues, challenge[0]); err != nil {
 			return nil, err
 		}
 	}
@@ -175,6 +206,9 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 	out := (*C.mi_proof_out)(C.malloc(C.size_t(unsafe.Sizeof(C.mi_proof_out{}))))
 	defer C.free(unsafe.Pointer(out))
 	var pin runtime.Pinner // W, a, b, c are read by the worker thread until mi_prover_wait returns
+	if len(W) == 0 || len(a) == 0 {
+		return nil, errors.New("mi355x: empty solution")
+	}
 	pin.Pin(&W[0]); pin.Pin(&a[0]); pin.Pin(&b[0]); pin.Pin(&c[0])
 	defer pin.Unpin()
 	var ticket C.uint64_t
@@ -211,7 +245,49 @@ func (pk *ProvingKey) pedersenKey(i int) (*C.mi_pedersen_pk, error) {
 	return pk.ped[i], nil
 }
 
+// batchProve is pedersen.BatchProve (gnark-crypto ecc/bn254/fr/pedersen) with the MSMs on the device:
+// sum_i challenge^i * (sum_j values[i][j] * BasisExpSigma_i[j]).
+func (pk *ProvingKey) batchProve(values [][]fr.Element, challenge fr.Element) (bn254.G1Affine, error) {
+	poks := make([]bn254.G1Affine, len(values))
+	pk.mu.Lock()
+	defer pk.mu.Unlock()
+	for i := range values {
+		if len(values[i]) == 0 {
+			continue // infinity
+		}
+		ppk, err := pk.pedersenKey(i)
+		if err != nil {
+			return bn254.G1Affine{}, err
+		}
+		if err := status(pk.ctx, C.mi_pedersen_prove_knowledge(pk.ctx, ppk, (*C.mi_fr)(unsafe.Pointer(&values[i][0])), C.size_t(len(values[i])),
+			(*C.mi_g1_affine)(unsafe.Pointer(&poks[i])))); err != nil {
+			return bn254.G1Affine{}, err
+		}
+	}
+	var out bn254.G1Affine
+	if len(poks) == 0 {
+		return out, nil
+	}
+	if rc := C.mi_pedersen_fold((*C.mi_g1_affine)(unsafe.Pointer(&poks[0])), C.size_t(len(poks)), (*C.mi_fr)(unsafe.Pointer(&challenge)),
+		(*C.mi_g1_affine)(unsafe.Pointer(&out))); rc != C.MI_OK {
+		return out, fmt.Errorf("mi355x: mi_pedersen_fold rc=%d", int(rc))
+	}
+	return out, nil
+}
+
 func log2(n uint64) int { k := 0; for (uint64(1) << k) < n { k++ }; return k }
 
-var _ = errors.New
+func g1(s []bn254.G1Affine) *C.mi_g1_affine {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.mi_g1_affine)(unsafe.Pointer(&s[0]))
+}
+func g2(s []bn254.G2Affine) *C.mi_g2_affine {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.mi_g2_affine)(unsafe.Pointer(&s[0]))
+}
+
 var _ = hash_to_field.New

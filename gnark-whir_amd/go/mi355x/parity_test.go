@@ -21,9 +21,11 @@ import (
 	cs "github.com/consensys/gnark/constraint/bn254"
 	"github.com/consensys/gnark/frontend"
 	"github.com/consensys/gnark/frontend/cs/r1cs"
+	"github.com/consensys/gnark/std/lookup/logderivlookup"
 )
 
-// cubic: x^3 + x + 5 == y (no commitment; a circuit with api.Commit would exercise the Pedersen path of prove.go too).
+// cubic: x^3 + x + 5 == y (no commitment); committed (below) adds api.Commit over a public and a private wire plus a lookup,
+// i.e. the Pedersen / SerializeCommitment / BatchProve path of prove.go that the WHIR verifier circuit takes.
 type cubic struct {
 	X frontend.Variable
 	Y frontend.Variable `gnark:",public"`
@@ -32,6 +34,27 @@ type cubic struct {
 func (c *cubic) Define(api frontend.API) error {
 	x3 := api.Mul(c.X, c.X, c.X)
 	api.AssertIsEqual(c.Y, api.Add(x3, c.X, 5))
+	return nil
+}
+
+type committed struct {
+	X   frontend.Variable
+	Idx frontend.Variable
+	Y   frontend.Variable `gnark:",public"`
+}
+
+func (c *committed) Define(api frontend.API) error {
+	t := logderivlookup.New(api) // what /root/reference/utilities/utilities.go:189 does: forces a BSB22 commitment
+	for i := 0; i < 8; i++ {
+		t.Insert(i * i)
+	}
+	v := t.Lookup(c.Idx)[0]
+	cm, err := api.(frontend.Committer).Commit(c.X, c.Y) // one private and one PUBLIC committed wire: the hashed prefix is not empty
+	if err != nil {
+		return err
+	}
+	api.AssertIsDifferent(cm, 0)
+	api.AssertIsEqual(c.Y, api.Add(api.Mul(c.X, c.X, c.X), c.X, v))
 	return nil
 }
 
@@ -54,7 +77,12 @@ func withSeed(seed uint64, f func()) {
 }
 
 func TestProofBytesMatchGnarkCPU(t *testing.T) {
-	ccs, err := frontend.Compile(ecc.BN254.ScalarField(), r1cs.NewBuilder, &cubic{})
+	t.Run("cubic", func(t *testing.T) { proveBoth(t, &cubic{}, &cubic{X: 3, Y: 35}) })
+	t.Run("commit+lookup", func(t *testing.T) { proveBoth(t, &committed{}, &committed{X: 3, Idx: 5, Y: 27 + 3 + 25}) })
+}
+
+func proveBoth(t *testing.T, circuit, assignment frontend.Circuit) {
+	ccs, err := frontend.Compile(ecc.BN254.ScalarField(), r1cs.NewBuilder, circuit)
 	if err != nil {
 		t.Fatal(err)
 	}
@@ -62,7 +90,7 @@ func TestProofBytesMatchGnarkCPU(t *testing.T) {
 	if err != nil {
 		t.Fatal(err)
 	}
-	w, err := frontend.NewWitness(&cubic{X: 3, Y: 35}, ecc.BN254.ScalarField())
+	w, err := frontend.NewWitness(assignment, ecc.BN254.ScalarField())
 	if err != nil {
 		t.Fatal(err)
 	}

@@ -131,6 +131,24 @@ int32_t mi_pk_load_dev(mi_ctx *ctx, const mi_pk_desc *desc, mi_pk **out);  /* po
         committed_wires stay host pointers                                                    */
 int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk);
 
+/* ---- proving key from gnark's own serialisation: the stream groth16 bn254 ProvingKey.WriteRawTo writes
+ * (gnark v0.11.0, go.mod:6; the reference itself re-runs Setup on every run, mt.go:448, and never writes one).
+ * LAYOUT RECALLED, UNVERIFIED -- spelled out in oracle/pk_raw.py and csrc/pk_raw.hip; the parser cross-checks every count and
+ * refuses anything else with MI_EINVAL.  nb_public and the wires removed from the K MSM come from the constraint system, not
+ * from the key file.  ped_out (room for MI_PK_RAW_MAX_COMMITMENTS handles, may be NULL) receives the key's Pedersen
+ * commitment keys for mi_pedersen_*; free them with mi_pedersen_pk_free. ---- */
+#define MI_PK_RAW_MAX_COMMITMENTS 16
+typedef struct mi_pk_raw_info {
+    uint32_t log_n, n_commitment_keys;
+    uint64_t nb_wires, n_g1_a, n_g1_b, n_g1_z, n_g1_k, n_g2_b;
+    uint64_t off_alpha1, off_g1_a, off_g1_b, off_g1_z, off_g1_k, off_beta2, off_g2_b, off_infinity_a, off_infinity_b;
+    uint64_t n_basis[MI_PK_RAW_MAX_COMMITMENTS], off_basis[MI_PK_RAW_MAX_COMMITMENTS], off_basis_exp_sigma[MI_PK_RAW_MAX_COMMITMENTS];
+} mi_pk_raw_info;
+int32_t mi_pk_raw_inspect(const uint8_t *buf, size_t len, mi_pk_raw_info *info);   /* host only: section offsets and counts */
+typedef struct mi_pedersen_pk mi_pedersen_pk;
+int32_t mi_pk_load_raw(mi_ctx *ctx, const uint8_t *buf, size_t len, uint32_t nb_public, const uint32_t *committed_wires,
+                       size_t n_committed, mi_pk **out, mi_pedersen_pk **ped_out, uint32_t *n_ped_out);
+
 /* ---- fft.Domain.FFT / FFTInverse over Fr, in place, n = 2^log_n (row a3/a4) ---- */
 int32_t mi_ntt(mi_ctx *ctx, mi_fr *inout, uint32_t log_n, uint32_t flags);
 int32_t mi_ntt_dev(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t flags);
@@ -263,7 +281,6 @@ size_t mi_proof_write(const mi_proof_out *proof, const mi_g1_affine *commitments
  *   Commit(values)          = sum_i values[i] * Basis[i]
  *   ProveKnowledge(values)  = sum_i values[i] * BasisExpSigma[i]
  *   Fold(points, challenge) = sum_i challenge^i * points[i]          (pedersen.Fold / FoldCommitments)            ---- */
-typedef struct mi_pedersen_pk mi_pedersen_pk;
 int32_t mi_pedersen_pk_load(mi_ctx *ctx, const mi_g1_affine *basis, const mi_g1_affine *basis_exp_sigma, size_t n,
                             mi_pedersen_pk **out);                       /* uploads once, device-resident */
 int32_t mi_pedersen_pk_free(mi_ctx *ctx, mi_pedersen_pk *pk);
