@@ -308,16 +308,20 @@ def main():
         per_launch_bytes = 96.0 * accum_pairs / max(accum_launches, 1)
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         g1_pairs_per_proof = na + nb + nk + (N - 1)
-        # HBM traffic of the dominant kernel: from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/r01_pmc_bench_traffic.json; FETCH_SIZE and WRITE_SIZE in separate passes, KB units).  The guide's x2
-        # FETCH_SIZE correction is for wide coalesced streams; this kernel gathers 64-B points, so the raw sum is reported.
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")))
-            kname = "void k_msm_accum_affine<Fe<FpParams> >"
-            traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
-        except Exception:
-            traffic = None
+        # HBM traffic per launch: NOT measured by this run -- read from the committed rocprofv3 --pmc passes of this same
+        # workload (profiles/r02_pmc_bench_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, KB units), and only
+        # reported when this run has the profiled shape (N = 2^23, WHIR mix, automatic plans).  The accumulate kernel gathers 64-B
+        # points, so its FETCH_SIZE is taken raw; the NTT passes stream 16 B per lane, so theirs gets the guide's x2 correction.
+        traffic = traffic_ntt = None
+        if log_n == 23 and args.dist == "whir" and not (args.msm_plan or args.fixed_base or args.ntt_plan or args.msm_group_bits or args.msm_chunk):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")))
+                kname = "void k_msm_accum_affine<Fe<FpParams> >"
+                traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
+                kn = "k_ntt_pass_wave"   # per pass launch; one transform = pass_launches / 7 launches
+                traffic_ntt = (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0 * ntt_solo["pass_launches"] / 7.0
+            except Exception:
+                traffic = traffic_ntt = None
         line = {
             "metric": "Groth16 proofs/sec for WHIR-verifier circuit (2^20 poly); G1 MSM pts/sec",
             "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -343,12 +347,14 @@ def main():
             "phase_ms": {k: last[k] for k in ("compute_h_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "msm_k_ms", "msm_z_ms", "assemble_ms", "total_ms")},
             "roofline": {"kernel": "k_msm_accum_affine<Fp> (G1 level-1 bucket accumulate)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": "profiles/r02_pmc_bench_traffic.json (committed PMC passes of this workload, not this run)",
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
             # time = computeH alone on the GPU / 7 transforms (the pointwise kernel, 0.1 ms, is inside: counted as fused)
-            "roofline_ntt": {"kernel": "k_ntt_pass (all passes of one size-N transform)", "bound": "hbm",
+            "roofline_ntt": {"kernel": "k_ntt_pass_wave (all passes of one size-N transform)", "bound": "hbm",
                              "achieved": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                             "frac": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                             "frac": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9 / 8000.0, "traffic": traffic_ntt,
+                             "traffic_source": "profiles/r02_pmc_bench_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) per pass launch x passes per transform",
                              "compute_h_solo_ms": ntt_solo["compute_h_ms"], "pass_launches_per_compute_h": ntt_solo["pass_launches"],
                              "algorithmic_bytes_per_transform": 64.0 * N},
             # why the HBM fraction is small: the kernel is bound by 256-bit modular products on the VALU (no MFMA form exists)
