@@ -21,6 +21,7 @@
 
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
+    u32 one_pass_sort = 0;                      // 1: large generic MSMs keep the one-pass counting sort (tests compare both)
     u32 chunk = 0;                              // fixed-base sort: entries per pass-2 chunk (tests shrink it)
     u32 gbits = 0;                              // fixed-base sort: log2 buckets per pass-1 group (0 = automatic)
 };
@@ -389,10 +390,17 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
 }
 
 // sort stage on slot sl: digits + counting sort of (key -> point index | sign).  Records sl.ev[0].
+static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c, bool wkeys = false);
 static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 generic_c) {
     MsmKnobs *kn = knobs_of(ctx);
     sl.n = n;
     sl.c = kn->c ? kn->c : (generic_c >= 2 && generic_c <= 16 ? generic_c : auto_c(n));
+    // Large generic MSMs (c = 16: 16 windows x 2^15 buckets = 2^19 keys, as many as a fixed-base c = 20 sort) borrow the
+    // fixed-base path's two-pass sort with the window folded into the key.  The one-pass scatter below writes every 4-byte
+    // entry as a partial line of its own (PMC round 1: 4.1 GB written for 0.5 GB of entries at 2^23 pairs); the two-pass
+    // sort stages runs through LDS and walks its chunks XCD by XCD (1.5x).  Same entries, same order inside a key up to the
+    // order of LDS atomics -- which the sums do not depend on.
+    if (sl.c == 16 && !kn->one_pass_sort && n >= (1u << 18) && (u64)n * 16 < ((u64)1 << 31)) return msm2_sort_enqueue(ctx, sl, scalars, n, flags, 16, true);
     sl.G = kn->G ? kn->G : (n / 8192 > 64 ? 64 : (n / 8192 ? n / 8192 : 1));
     const MsmShape s = slot_shape(sl);
     sl.nwin_keys = sl.nwin_digits = s.nwin;
@@ -419,16 +427,17 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
 }
 
 // fixed-base sort stage: entries of ALL windows keyed by one bucket set of 2^(c-1), two-pass sort.  Records sl.ev[0].
-static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c) {
+static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c, bool wkeys) {
     MsmKnobs *kn = knobs_of(ctx);
-    if (c < 17 || c > 22) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: window bits must be 17..22");
+    if (!wkeys && (c < 17 || c > 22)) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: window bits must be 17..22");
     const u32 G = n ? (n + MSM2_SLICE - 1) / MSM2_SLICE : 1;   // pass-1 slices
     const u32 chunk = kn->chunk ? kn->chunk : 8192;    // (gbits, chunk) sweep at 2^23 pairs, c = 20: tools/fixed_probe.py
     u32 gbits = kn->gbits ? kn->gbits : 11;
     if (gbits > 15) gbits = 15;
-    while (((1u << (c - 1)) >> gbits) > MSM2_MAX_GROUPS) gbits++;
-    const Msm2Shape s = msm2_shape(n, c, G, chunk, gbits);
-    sl.n = n; sl.c = c; sl.G = G; sl.nwin_keys = 1; sl.nwin_digits = s.nwin;
+    const u32 keys_total = (wkeys ? (256 + c - 1) / c : 1u) << (c - 1);
+    while ((keys_total >> gbits) > MSM2_MAX_GROUPS) gbits++;
+    const Msm2Shape s = msm2_shape(n, c, G, chunk, gbits, wkeys ? 1u : 0u);
+    sl.n = n; sl.c = c; sl.G = G; sl.nwin_keys = wkeys ? s.nwin : 1; sl.nwin_digits = s.nwin;
     const u64 T_bound = (u64)s.nwin * n;
     if (T_bound >= ((u64)1 << 31)) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: windows * n must stay below 2^31");
     const u32 chunks_bound = (u32)(T_bound / chunk) + s.ngroups + 1;
@@ -667,6 +676,11 @@ int32_t mi_msm_g1_fixed_dev(mi_ctx *ctx, const mi_g1_affine *pre_dev, const mi_f
 int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c, uint32_t flags, mi_g2_jac *out) {
     if (!ctx || !out || ((!pre_dev || !scalars_dev) && n) || (flags & ~1u)) return MI_EINVAL;
     return msm_fixed_dev_entry<Fp2>(ctx, 2, pre_dev, scalars_dev, n, c, flags, out);
+}
+int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on) {
+    if (!ctx || on > 1) return MI_EINVAL;
+    knobs_of(ctx)->one_pass_sort = on;
+    return MI_OK;
 }
 int32_t mi_debug_set_msm_chunk(mi_ctx *ctx, uint32_t chunk) {
     if (!ctx) return MI_EINVAL;

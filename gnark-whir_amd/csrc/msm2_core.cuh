@@ -20,7 +20,10 @@
 struct Msm2Shape {
     u32 c;          // window bits (17..22)
     u32 nwin;       // ceil(256 / c)
-    u32 nkeys;      // 2^(c-1) buckets, one set for all windows
+    u32 nkeys;      // keys of the sort: 2^(c-1) buckets, one set for all windows (fixed-base); nwin * 2^(c-1) when wkeys
+    u32 half;       // 2^(c-1): buckets of one window
+    u32 wkeys;      // 1: the GENERIC MSM on arbitrary bases borrows this sort (msm.hip): key = (w << (c-1)) | bucket, value =
+                    //    point index | sign -- no window copies exist, every window keeps its own bucket set
     u32 gbits;      // log2 of the buckets per group (<= 15: the group-local bucket travels as u16)
     u32 gsize;      // 1 << gbits
     u32 ngroups;    // nkeys >> gbits
@@ -28,9 +31,10 @@ struct Msm2Shape {
     u32 chunk;      // entries per pass-2 chunk
     u32 n;          // pairs
 };
-MI_HD Msm2Shape msm2_shape(u32 n, u32 c, u32 nslices, u32 chunk, u32 gbits = 15) {
+MI_HD Msm2Shape msm2_shape(u32 n, u32 c, u32 nslices, u32 chunk, u32 gbits = 15, u32 wkeys = 0) {
     Msm2Shape s;
-    s.c = c; s.nwin = (256 + c - 1) / c; s.nkeys = 1u << (c - 1); s.gbits = gbits; s.gsize = 1u << gbits; s.ngroups = s.nkeys >> gbits;
+    s.c = c; s.nwin = (256 + c - 1) / c; s.half = 1u << (c - 1); s.wkeys = wkeys; s.nkeys = wkeys ? s.nwin * s.half : s.half;
+    s.gbits = gbits; s.gsize = 1u << gbits; s.ngroups = s.nkeys >> gbits;
     s.nslices = nslices; s.chunk = chunk; s.n = n;
     return s;
 }
@@ -51,7 +55,7 @@ struct Msm2Digits {
         u64 lo = limb < 8 ? v.l[limb] : 0u, hi = limb + 1 < 8 ? v.l[limb + 1] : 0u;
         u32 raw = (u32)(((hi << 32) | lo) >> sh) & ((1u << s.c) - 1);
         int32_t d = (int32_t)(raw + carry);
-        if ((u32)d >= s.nkeys) { d -= (int32_t)(1u << s.c); carry = 1; } else carry = 0;
+        if ((u32)d >= s.half) { d -= (int32_t)(1u << s.c); carry = 1; } else carry = 0;
         w++;
         return d;
     }
@@ -62,7 +66,7 @@ struct Msm2Digits {
 MI_HD void msm2_count_one(const Msm2Shape &s, Msm2Digits dg, u32 *lds) {
     for (u32 w = 0; w < s.nwin; w++) {
         int32_t d = dg.next(s);
-        if (d) MI_LDS_ATOMIC_ADD(&lds[((u32)(d < 0 ? -d : d) - 1) >> s.gbits], 1u);
+        if (d) MI_LDS_ATOMIC_ADD(&lds[(((u32)(d < 0 ? -d : d) - 1) + (s.wkeys ? w * s.half : 0u)) >> s.gbits], 1u);
     }
 }
 MI_HD void msm2_count_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *lds, u32 tid, u32 nthr) {
@@ -84,10 +88,10 @@ MI_HD void msm2_place_one(const Msm2Shape &s, Msm2Digits dg, u32 i, u32 *cursor,
     for (u32 w = 0; w < s.nwin; w++) {
         int32_t d = dg.next(s);
         if (!d) continue;
-        u32 key = (u32)(d < 0 ? -d : d) - 1;
+        u32 key = (u32)(d < 0 ? -d : d) - 1 + (s.wkeys ? w * s.half : 0u);
         u32 pos = MI_LDS_ATOMIC_ADD(&cursor[key >> s.gbits], 1u);
         stage_lo[pos] = (uint16_t)(key & (s.gsize - 1));
-        stage_val[pos] = (w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
+        stage_val[pos] = (s.wkeys ? i : w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
     }
 }
 MI_HD void msm2_stage_place_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *cursor, uint16_t *stage_lo, u32 *stage_val,

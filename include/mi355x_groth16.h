@@ -341,6 +341,8 @@ int32_t mi_debug_set_msm_group_bits(mi_ctx *ctx, uint32_t gbits);   /* fixed-bas
  * 0 = automatic (tables when the MSM has >= 2^20 points and they fit in a third of the free device memory),
  * 1 = never, 17..22 = that width whatever the size */
 int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, uint32_t c_z);
+/* 1: generic MSMs of >= 2^18 pairs keep the one-pass counting sort instead of the LDS-staged two-pass one (parity tests run both) */
+int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on);
 /* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
  * running; 0 disarms.  Used to prove that init / load / prove unwind without leaks or crashes. */
 int32_t mi_debug_inject_hip_failure(int32_t nth);

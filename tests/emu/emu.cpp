@@ -215,12 +215,13 @@ extern "C" int emu_msm_g2(void *out, const void *pts, const void *sc, uint32_t n
 // ---------------------------------------------------------------- fixed-base MSM (msm2_core.cuh on the host)
 #include "../../gnark-whir_amd/csrc/msm2_core.cuh"
 extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uint32_t n, int mont, uint32_t c, uint32_t G, uint32_t chunk, uint32_t L,
-                           uint32_t seg, uint32_t nthr, uint32_t gbits) {
+                           uint32_t seg, uint32_t nthr, uint32_t gbits, uint32_t wkeys) {
     typedef Fp F;
-    Msm2Shape s = msm2_shape(n, c, G, chunk, gbits);
-    // pk_load: window copies
-    std::vector<Affine<F>> pre((size_t)s.nwin * n);
-    for (u32 i = 0; i < n; i++) msm2_precompute_body<F>((const Affine<F> *)pts_v, pre.data(), n, c, s.nwin, i);
+    Msm2Shape s = msm2_shape(n, c, G, chunk, gbits, wkeys);
+    // pk_load: window copies (fixed-base).  wkeys: the generic MSM borrows the sort, points stay as they are
+    std::vector<Affine<F>> pre((size_t)(wkeys ? 1 : s.nwin) * n);
+    if (wkeys) memcpy(pre.data(), pts_v, sizeof(Affine<F>) * n);
+    else for (u32 i = 0; i < n; i++) msm2_precompute_body<F>((const Affine<F> *)pts_v, pre.data(), n, c, s.nwin, i);
     // pass 1
     std::vector<u32> C1((size_t)s.ngroups * G), lds(s.gsize > s.ngroups ? s.gsize : s.ngroups);
     for (u32 g = 0; g < G; g++) {
@@ -271,17 +272,20 @@ extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uin
     }
     // items / levels over nkeys keys (one window), then bucket reduce with nwin = 1
     MsmShape ks;
-    ks.c = c; ks.nwin = 1; ks.nbuckets = s.nkeys; ks.nkeys = s.nkeys; ks.nslices = G; ks.n = n;
+    ks.c = c; ks.nwin = wkeys ? s.nwin : 1; ks.nbuckets = s.half; ks.nkeys = s.nkeys; ks.nslices = G; ks.n = n;
     std::vector<u32> start(s.nkeys), cnt(s.nkeys), items(s.nkeys);
     for (u32 k = 0; k < s.nkeys; k++) msm_prep_level1(ks, keystart.data(), L, start.data(), cnt.data(), items.data(), k);
     std::vector<XYZZ<F>> bucket(s.nkeys);
     memset(bucket.data(), 0, sizeof(XYZZ<F>) * s.nkeys);
     run_levels<F>(s.nkeys, start, cnt, items, L, pre.data(), sorted.data(), std::vector<XYZZ<F>>(), bucket, nthr);
-    u32 tb = (s.nkeys + seg - 1) / seg;
-    std::vector<XYZZ<F>> Pp(tb);
-    for (u32 t = 0; t < tb; t++) msm_bucket_reduce_body<F>(bucket.data(), s.nkeys, seg, Pp.data(), 0, t);
-    XYZZ<F> tot = XYZZ<F>::inf();
-    for (u32 t = 0; t < tb; t++) xyzz_add(tot, Pp[t]);
+    u32 tb = (s.half + seg - 1) / seg;
+    std::vector<XYZZ<F>> Pp((size_t)ks.nwin * tb), wsum(ks.nwin);
+    for (u32 w = 0; w < ks.nwin; w++) {
+        for (u32 t = 0; t < tb; t++) msm_bucket_reduce_body<F>(bucket.data(), s.half, seg, Pp.data(), w, t);
+        wsum[w] = XYZZ<F>::inf();
+        for (u32 t = 0; t < tb; t++) xyzz_add(wsum[w], Pp[(size_t)w * tb + t]);
+    }
+    XYZZ<F> tot = msm_combine_windows<F>(wsum.data(), ks.nwin, wkeys ? c : 0);   // one window: no doublings
     *(Affine<F> *)out_v = xyzz_to_affine(tot);
     return (int)nchunks;
 }

@@ -176,6 +176,19 @@ def test_fixed_base_msm_pipeline_matches_oracle(emu, n, dist, c, G, chunk, L, gb
     if n > 30:
         pts[3] = 0; sc[1] = fr_arr([P.R_MOD - 1])[0]; sc[2] = 0; pts[6] = pts[5]; sc[6] = sc[5]
     out = np.zeros(8, np.uint64)
-    nchunks = emu.emu_msm2_g1(_p(out), _p(pts), _p(sc), n, 1, c, G, chunk, L, 64, 5, gbits)
+    nchunks = emu.emu_msm2_g1(_p(out), _p(pts), _p(sc), n, 1, c, G, chunk, L, 64, 5, gbits, 0)
+    want = cref.msm_g1(pts, sc)
+    assert nchunks >= 1 and (np.array_equal(out, want[:8]) or (not want[8:].any() and not out.any()))
+
+
+@pytest.mark.parametrize("n,dist,c,G,chunk,L,gbits", [(1, 0, 4, 1, 8, 4, 3), (70, 1, 5, 3, 16, 3, 4), (300, 0, 8, 2, 50, 8, 6), (257, 1, 6, 4, 7, 4, 5)])
+def test_generic_msm_through_two_pass_sort_matches_oracle(emu, n, dist, c, G, chunk, L, gbits):
+    """msm2_core.cuh with the window folded into the key (wkeys): what large generic MSMs (c = 16) use instead of the one-pass
+    scatter -- key = (w << (c-1)) | bucket, value = point index | sign, per-window bucket sets, window combine"""
+    pts = cref.gen_g1(n, 950 + n); sc = cref.gen_scalars(n, 951 + n, dist)
+    if n > 30:
+        pts[3] = 0; sc[1] = fr_arr([P.R_MOD - 1])[0]; sc[2] = 0; pts[6] = pts[5]; sc[6] = sc[5]
+    out = np.zeros(8, np.uint64)
+    nchunks = emu.emu_msm2_g1(_p(out), _p(pts), _p(sc), n, 1, c, G, chunk, L, 4, 5, gbits, 1)
     want = cref.msm_g1(pts, sc)
     assert nchunks >= 1 and (np.array_equal(out, want[:8]) or (not want[8:].any() and not out.any()))

@@ -377,3 +377,24 @@ def test_fixed_base_equals_generic_at_baseline_size(ctx):
     assert np.array_equal(got, want)
     for d in (pts, sc, pre):
         d.free()
+
+
+@pytest.mark.parametrize("n,dist", [(1 << 20, 1), ((1 << 21) + 12345, 0)])
+def test_generic_msm_two_pass_and_one_pass_sorts_agree_with_oracle(ctx, n, dist):
+    """generic MSMs with c = 16 (n >= 2^20) sort through the LDS-staged two-pass sort with the window folded into the key;
+    the one-pass counting sort stays behind a knob: both against the oracle, G1 and G2"""
+    pts = cref.gen_g1(n, 2100 + dist); sc = cref.gen_scalars(n, 2200 + dist, dist)
+    pts[3] = 0; sc[1] = fr_arr([P.R_MOD - 1])[0]; sc[2] = 0; pts[6] = pts[5]; sc[6] = sc[5]
+    want = cref.msm_g1(pts, sc)
+    dp, ds = ctx.to_dev(pts), ctx.to_dev(sc)
+    n2 = 1 << 20
+    p2 = ctx.gen_g2(n2, 77); want2 = cref.msm_g2(p2.download((n2, 16)), sc[:n2])
+    try:
+        for one_pass in (0, 1):
+            assert ctx.lib.mi_debug_set_msm_one_pass_sort(ctx.h, one_pass) == 0
+            assert np.array_equal(ctx.msm_g1_dev(dp.ptr, ds.ptr, n), want), one_pass
+            assert np.array_equal(ctx.msm_g2_dev(p2.ptr, ds.ptr, n2), want2), one_pass
+    finally:
+        assert ctx.lib.mi_debug_set_msm_one_pass_sort(ctx.h, 0) == 0
+    for d in (dp, ds, p2):
+        d.free()
