@@ -31,8 +31,14 @@ struct NttState {
     // defaults from the tools/tune.py sweep at N = 2^23: 2^9-element tiles (16 KiB of LDS, 8 workgroups of 256
     // threads per CU), radices 2^7 * 2^7 * 2^9: 1.46 ms per transform vs 1.99 ms for 2^11 tiles
     u32 log_e = 9, max_contig = 9, max_strided = 7, threads = 256;
+    u32 plan_set = 0;      // the knobs above were set by the caller: no per-size defaults
     u32 wave_stages = 1;   // passes of radix >= 2^7 run their last / first seven stages in registers (k_ntt_pass_wave); 0 = all through LDS
 };
+// Tile / radix knobs for a transform of 2^log_n: the caller's (mi_debug_set_ntt_plan) or, untouched, the measured best per size
+// (tools/ntt_probe.py sweep, profiles/r02_tune_ntt_sweep.json): 2^9 tiles and radices 2^7 2^7 2^9 up to 2^23; 2^10 tiles and
+// 2^8 2^8 2^8 at 2^24 (16.2 vs 17.4 ms per computeH); 2^10 tiles and 2^8 2^8(2^7) 2^10 from 2^25 on (71.9 vs 74.0 ms at 2^26).
+struct NttKnobs { u32 log_e, max_contig, max_strided; };
+static NttKnobs knobs_for(const struct NttState *st, u32 log_n);
 static NttState *state_of(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= 384, "NttState lives in ctx->ntt_state");
     return reinterpret_cast<NttState *>(ctx->ntt_state);
@@ -51,6 +57,13 @@ void mi_ntt_state_free(mi_ctx *ctx) {
     Fr **all[] = {&st->small_f, &st->small_i, &st->tw64k_f, &st->tw64k_i, &st->g_hi_n, &st->gi_hi_nd, &st->tw_lo_f, &st->tw_hi_f, &st->tw_lo_i, &st->tw_hi_i,
                   &st->g_lo, &st->g_hi, &st->gi_lo, &st->gi_hi, &st->ninv, &st->d_tw_inv, &st->d_tw_fwd, &st->d_sc_fwd, &st->d_sc_inv};
     for (Fr **p : all) if (*p) { (void)hipFree(*p); *p = nullptr; }
+}
+
+static NttKnobs knobs_for(const NttState *st, u32 log_n) {
+    if (st->plan_set) return NttKnobs{st->log_e, st->max_contig, st->max_strided};
+    if (log_n == 24) return NttKnobs{10, 8, 8};
+    if (log_n >= 25) return NttKnobs{10, 10, 8};
+    return NttKnobs{st->log_e, st->max_contig, st->max_strided};
 }
 
 // out[j] = c * base^(j << shift)
@@ -202,7 +215,8 @@ static int32_t ensure_tables(mi_ctx *ctx, u32 log_n) {
 // computeH's direct tables for (log_n, current plan); a failure to allocate them only means the composed-table path runs
 static int32_t ensure_direct(mi_ctx *ctx, u32 log_n) {
     NttState *st = state_of(ctx);
-    const NttPlan pl = ntt_make_plan(log_n, st->max_contig, st->max_strided);
+    const NttKnobs kn = knobs_for(st, log_n);
+    const NttPlan pl = ntt_make_plan(log_n, kn.max_contig, kn.max_strided);
     if (st->d_log_n == log_n && st->d_log_r0 == pl.log_r[0] && st->d_npass == pl.n_pass) return MI_OK;
     Fr **four[] = {&st->d_tw_inv, &st->d_tw_fwd, &st->d_sc_fwd, &st->d_sc_inv};
     for (Fr **p : four) if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -253,7 +267,8 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
     else if (coset && inverse) { t.sc_lo = st->gi_lo; t.sc_hi = variant == 3 ? st->gi_hi_nd : st->gi_hi; store_scale = dit ? 4 : 3; }
     else if (inverse && variant != 1) { t.sc_lo = st->ninv; t.sc_hi = st->ninv; store_scale = 5; }
 
-    NttPlan pl = ntt_make_plan(log_n, st->max_contig, st->max_strided);
+    const NttKnobs kn = knobs_for(st, log_n);
+    NttPlan pl = ntt_make_plan(log_n, kn.max_contig, kn.max_strided);
     // log_s of pass i (DIF order): product of later radices
     u32 log_s[8];
     for (u32 i = 0, acc = log_n; i < pl.n_pass; i++) { acc -= pl.log_r[i]; log_s[i] = acc; }
@@ -262,7 +277,7 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
         u32 i = dit ? pl.n_pass - 1 - step : step;
         NttPass p{};
         p.log_n = log_n; p.log_r = pl.log_r[i]; p.log_s = log_s[i];
-        u32 room = st->log_e > p.log_r ? st->log_e - p.log_r : 0;
+        u32 room = kn.log_e > p.log_r ? kn.log_e - p.log_r : 0;
         u32 avail = p.log_s == 0 ? log_n - p.log_r : p.log_s;
         p.log_c = room < avail ? room : avail;
         p.dit = dit ? 1 : 0;
@@ -332,7 +347,7 @@ int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, 
     if (!ctx || log_e < 1 || log_e > 12 || max_contig < 1 || max_contig > 12 || max_contig > log_e || max_strided < 1 || max_strided > 12 || max_strided > log_e)
         return MI_EINVAL;
     NttState *st = state_of(ctx);
-    st->log_e = log_e; st->max_contig = max_contig; st->max_strided = max_strided;
+    st->log_e = log_e; st->max_contig = max_contig; st->max_strided = max_strided; st->plan_set = 1;
     return MI_OK;
 }
 int32_t mi_debug_set_ntt_wave_stages(mi_ctx *ctx, uint32_t on, uint32_t direct_min_log_n) {

@@ -31,7 +31,9 @@ print(f"computeH N=2^{log_n}: best of {reps}: {run():.3f} ms", flush=True)
 if sweep:
     out = []
     ref = h.download((N, 4)).copy()
-    for (log_e, mc, ms_, thr, wave) in [(9, 9, 7, 256, 1), (9, 9, 7, 256, 0), (9, 9, 7, 128, 1), (10, 9, 7, 256, 1), (10, 9, 7, 512, 1), (10, 10, 7, 256, 1),
+    cfgs26 = [(9, 9, 7, 256, 1), (10, 9, 9, 256, 1), (11, 9, 9, 256, 1), (10, 10, 8, 256, 1), (11, 11, 8, 256, 1), (10, 8, 9, 256, 1), (11, 8, 9, 256, 1),
+              (10, 9, 8, 256, 1), (11, 9, 8, 256, 1), (11, 10, 8, 256, 1), (9, 9, 9, 256, 1), (9, 8, 9, 256, 1), (9, 9, 8, 256, 1)]
+    for (log_e, mc, ms_, thr, wave) in cfgs26 if log_n >= 25 else [(9, 9, 7, 256, 1), (9, 9, 7, 256, 0), (9, 9, 7, 128, 1), (10, 9, 7, 256, 1), (10, 9, 7, 512, 1), (10, 10, 7, 256, 1),
                                         (9, 7, 8, 256, 1), (10, 7, 8, 256, 1), (10, 8, 8, 256, 1), (11, 9, 7, 256, 1), (11, 11, 7, 256, 1), (8, 8, 8, 128, 1),
                                         (9, 8, 8, 256, 1), (8, 7, 8, 128, 1), (8, 8, 8, 256, 1)]:
         assert ctx.lib.mi_debug_set_ntt_plan(ctx.h, log_e, mc, ms_) == 0 and ctx.lib.mi_debug_set_ntt_threads(ctx.h, thr) == 0
