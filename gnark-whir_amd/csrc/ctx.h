@@ -18,6 +18,7 @@ struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, 
     DevBuf buf[14];
     void *host_wsum = nullptr;
     uint32_t n = 0, c = 0, G = 0;
+    uint64_t entries_cap = 0;   // entries the sort of this slot is sized for: windows * n, or the counted number (MI_MSM_EXACT_SIZE)
     uint64_t stat_pairs = 0;    // (point, scalar) pairs this MSM really has (A and K run over per-wire expanded arrays with holes)
     uint32_t nwin_keys = 0;     // windows in the key space: ceil(256/c) for the generic MSM, 1 for the fixed-base one
     uint32_t nwin_digits = 0;   // digits per scalar = ceil(256/c)
@@ -111,6 +112,9 @@ int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host);
 // Internal flag of mi_msm_enqueue (next to MI_MSM_SCALARS_CANONICAL): stop at the bucket sums.  mi_msm_bucket_view then
 // exposes them, mi_msm_reduce_enqueue runs the rest (bucket reduce, window sums, copy to the host) and mi_msm_finish collects.
 #define MI_MSM_DEFER_REDUCE 0x100u
+// Internal flag: size the entry-indexed workspaces by the COUNTED number of non-zero digits (one synchronisation of the slot's
+// stream after the count pass) instead of windows * n.  For scalars that are available when the MSM is enqueued (wire values).
+#define MI_MSM_EXACT_SIZE 0x200u
 struct MsmBucketView {
     void *bucket = nullptr;     // XYZZ[nkeys] on the slot's device; null for an empty MSM
     size_t nkeys = 0, xyzz_bytes = 0;

@@ -390,8 +390,8 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
 }
 
 // sort stage on slot sl: digits + counting sort of (key -> point index | sign).  Records sl.ev[0].
-static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c, bool wkeys = false);
-static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 generic_c) {
+static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c, bool wkeys = false, bool exact = false);
+static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 generic_c, bool exact) {
     MsmKnobs *kn = knobs_of(ctx);
     sl.n = n;
     sl.c = kn->c ? kn->c : (generic_c >= 2 && generic_c <= 16 ? generic_c : auto_c(n));
@@ -400,11 +400,12 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
     // entry as a partial line of its own (PMC round 1: 4.1 GB written for 0.5 GB of entries at 2^23 pairs); the two-pass
     // sort stages runs through LDS and walks its chunks XCD by XCD (1.5x).  Same entries, same order inside a key up to the
     // order of LDS atomics -- which the sums do not depend on.
-    if (sl.c == 16 && !kn->one_pass_sort && n >= (1u << 18) && (u64)n * 16 < ((u64)1 << 31)) return msm2_sort_enqueue(ctx, sl, scalars, n, flags, 16, true);
+    if (sl.c == 16 && !kn->one_pass_sort && n >= (1u << 18) && (u64)n * 16 < ((u64)1 << 31)) return msm2_sort_enqueue(ctx, sl, scalars, n, flags, 16, true, exact);
     sl.G = kn->G ? kn->G : (n / 8192 > 64 ? 64 : (n / 8192 ? n / 8192 : 1));
     const MsmShape s = slot_shape(sl);
     sl.nwin_keys = sl.nwin_digits = s.nwin;
     const u64 T_bound = (u64)s.nwin * n;
+    sl.entries_cap = T_bound;
     if (s.nwin > 128) MI_FAIL(ctx, MI_EINVAL, "msm: too many windows");
     MI_TRY(mi_reserve(ctx, sl.buf[B_DIGITS], T_bound * 2 + 64));
     MI_TRY(mi_reserve(ctx, sl.buf[B_H], ((size_t)s.nkeys * s.nslices + 1) * 4));
@@ -427,7 +428,7 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
 }
 
 // fixed-base sort stage: entries of ALL windows keyed by one bucket set of 2^(c-1), two-pass sort.  Records sl.ev[0].
-static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c, bool wkeys) {
+static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32 n, u32 flags, u32 c, bool wkeys, bool exact) {
     MsmKnobs *kn = knobs_of(ctx);
     if (!wkeys && (c < 17 || c > 22)) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: window bits must be 17..22");
     const u32 G = n ? (n + MSM2_SLICE - 1) / MSM2_SLICE : 1;   // pass-1 slices
@@ -440,18 +441,10 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     sl.n = n; sl.c = c; sl.G = G; sl.nwin_keys = wkeys ? s.nwin : 1; sl.nwin_digits = s.nwin;
     const u64 T_bound = (u64)s.nwin * n;
     if (T_bound >= ((u64)1 << 31)) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: windows * n must stay below 2^31");
-    const u32 chunks_bound = (u32)(T_bound / chunk) + s.ngroups + 1;
     MI_TRY(mi_reserve(ctx, sl.buf[B_C1], ((size_t)s.ngroups * G + 1) * 4 * 2));
-    MI_TRY(mi_reserve(ctx, sl.buf[B_DIGITS], T_bound * 2 + 64));                  // part_lo (u16)
-    MI_TRY(mi_reserve(ctx, sl.buf[B_PVAL], (T_bound + 1) * 4));                   // part_val
     MI_TRY(mi_reserve(ctx, sl.buf[B_CHUNKS], ((size_t)s.ngroups + 1) * 4 * 3));
-    MI_TRY(mi_reserve(ctx, sl.buf[B_H], (size_t)chunks_bound * s.gsize * 4));
     MI_TRY(mi_reserve(ctx, sl.buf[B_S], ((size_t)s.nkeys * 2 + 2) * 4));
-    MI_TRY(mi_reserve(ctx, sl.buf[B_SORTED], (T_bound + 1) * 4));
     u32 *C1 = (u32 *)sl.buf[B_C1].p, *S1 = C1 + (size_t)s.ngroups * G + 1;
-    uint16_t *part_lo = (uint16_t *)sl.buf[B_DIGITS].p;
-    u32 *part_val = (u32 *)sl.buf[B_PVAL].p, *gstart = (u32 *)sl.buf[B_CHUNKS].p, *cstart = gstart + s.ngroups + 1, *nchunks = cstart + s.ngroups + 1;
-    u32 *H2 = (u32 *)sl.buf[B_H].p, *keystart = (u32 *)sl.buf[B_S].p, *total = keystart + s.nkeys + 1, *sorted = (u32 *)sl.buf[B_SORTED].p;
     const int mont = (flags & MI_MSM_SCALARS_CANONICAL) ? 0 : 1;
     hipStream_t st = sl.stream;
     u32 per = 8;   // slices per counting workgroup
@@ -459,6 +452,28 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     hipLaunchKernelGGL(k_msm2_count, dim3((G + per - 1) / per), dim3(512), 0, st, s, scalars, mont, per, C1);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, C1, (size_t)s.ngroups * G, S1, sl.buf[B_SCAN]));
+    // Entry-indexed workspaces (two partition arrays, chunk histograms, sorted entries; later the per-item partial sums) take
+    // ~19 B per entry.  The bound nwin * n is tight for uniform scalars (the h coefficients of the Z MSM) but 3x too large
+    // for wire values (45 % of them in {0, 1}, 25 % bytes: 4..5 non-zero digits of 14).  `exact`: the count pass
+    // above has the true number -- fetch it (one stream synchronisation of THIS slot's stream: everything else the caller
+    // enqueued keeps the GPU busy meanwhile) and size by it.  N = 2^26: 80 -> 35 GB of workspaces per context.
+    u64 T = T_bound;
+    if (exact) {
+        u32 *host_total = (u32 *)((char *)sl.host_wsum + 128 * 256 + 16);
+        MI_CHECK_HIP(ctx, hipMemcpyAsync(host_total, S1 + (size_t)s.ngroups * G, 4, hipMemcpyDeviceToHost, st));
+        MI_CHECK_HIP(ctx, hipStreamSynchronize(st));
+        T = *host_total;
+        if (T > T_bound) MI_FAIL(ctx, MI_EHIP, "msm: counted more entries than windows * n");
+    }
+    sl.entries_cap = T;
+    const u32 chunks_bound = (u32)(T / chunk) + s.ngroups + 1;
+    MI_TRY(mi_reserve(ctx, sl.buf[B_DIGITS], T * 2 + 64));                  // part_lo (u16)
+    MI_TRY(mi_reserve(ctx, sl.buf[B_PVAL], (T + 1) * 4));                   // part_val
+    MI_TRY(mi_reserve(ctx, sl.buf[B_H], (size_t)chunks_bound * s.gsize * 4));
+    MI_TRY(mi_reserve(ctx, sl.buf[B_SORTED], (T + 1) * 4));
+    uint16_t *part_lo = (uint16_t *)sl.buf[B_DIGITS].p;
+    u32 *part_val = (u32 *)sl.buf[B_PVAL].p, *gstart = (u32 *)sl.buf[B_CHUNKS].p, *cstart = gstart + s.ngroups + 1, *nchunks = cstart + s.ngroups + 1;
+    u32 *H2 = (u32 *)sl.buf[B_H].p, *keystart = (u32 *)sl.buf[B_S].p, *total = keystart + s.nkeys + 1, *sorted = (u32 *)sl.buf[B_SORTED].p;
     const u32 cap = ((n + G - 1) / G) * s.nwin;   // entries of one slice at most
     const size_t part_lds = ((size_t)3 * s.ngroups + 1 + 256 + cap) * 4 + (size_t)cap * 2;
     if (part_lds > 160 * 1024) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: pass-1 slice does not fit in LDS");
@@ -485,7 +500,7 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     const u32 n = s.n;
     const u32 L1 = kn->L1 ? kn->L1 : 16, L2 = kn->L2 ? kn->L2 : 8;   // tools/tune.py sweep, N = 2^23
     const u32 seg = kn->seg ? kn->seg : (s.nbuckets >= 256 ? 8 : 2);
-    const u64 T_bound = (u64)srt.nwin_digits * n;
+    const u64 T_bound = srt.entries_cap;   // nwin * n, or the counted number of entries (msm2_sort_enqueue, exact)
     hipStream_t st = acc.stream;
     if (&srt != &acc) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, srt.ev[0], 0));
     MI_TRY(mi_reserve(ctx, acc.buf[B_LEVELS], ((size_t)s.nkeys + 1) * 4 * 8));
@@ -578,14 +593,14 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     sl.active = false;
     sl.deferred = false;
     sl.stat_pairs = stat_pairs ? stat_pairs : n;
-    const bool defer = (flags & MI_MSM_DEFER_REDUCE) != 0;
-    flags &= ~MI_MSM_DEFER_REDUCE;
+    const bool defer = (flags & MI_MSM_DEFER_REDUCE) != 0, exact = (flags & MI_MSM_EXACT_SIZE) != 0;
+    flags &= ~(MI_MSM_DEFER_REDUCE | MI_MSM_EXACT_SIZE);
     if (n == 0) return MI_OK;
     if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
     MsmSlot &srt = sort_slot >= 0 ? ctx->msm[sort_slot] : sl;
-    if (sort_slot < 0 && precomp_c) MI_TRY(msm2_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, precomp_c));
-    else if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, generic_c));
+    if (sort_slot < 0 && precomp_c) MI_TRY(msm2_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, precomp_c, false, exact));
+    else if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, generic_c, exact));
     else if (srt.n != n) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
     return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed, defer);
 }
@@ -625,7 +640,7 @@ template <class F, class JacT>
 static int32_t msm_dev_entry(mi_ctx *ctx, int curve, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, JacT *out) {
     std::memset(&ctx->stats, 0, sizeof(ctx->stats));
     MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pts_dev, scalars_dev, n, flags, ctx->ev[0], curve == 1));
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pts_dev, scalars_dev, n, flags | MI_MSM_EXACT_SIZE, ctx->ev[0], curve == 1));
     if (n) MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->msm[0].stream));
     XYZZ<F> r;
     MI_TRY(mi_msm_finish(ctx, 0, curve, &r));
@@ -649,7 +664,7 @@ template <class F, class JacT>
 static int32_t msm_fixed_dev_entry(mi_ctx *ctx, int curve, const void *pre_dev, const void *scalars_dev, size_t n, uint32_t c, uint32_t flags, JacT *out) {
     std::memset(&ctx->stats, 0, sizeof(ctx->stats));
     MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pre_dev, scalars_dev, n, flags, ctx->ev[0], curve == 1, c));
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pre_dev, scalars_dev, n, flags | MI_MSM_EXACT_SIZE, ctx->ev[0], curve == 1, c));
     if (n) MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->msm[0].stream));
     XYZZ<F> r;
     MI_TRY(mi_msm_finish(ctx, 0, curve, &r));

@@ -245,7 +245,8 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
 // ---------------------------------------------------------------- the pieces of a proof (shared with group.hip)
 // step 5 + the wire MSMs: they depend on W only (ev_w = "W is on the device")
 int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
-    const uint32_t df = defer ? MI_MSM_DEFER_REDUCE : 0;
+    // wire values are skewed (45 % of them 0 or 1): their sorts are sized by the counted entries, not by windows * n (msm.hip)
+    const uint32_t df = (defer ? MI_MSM_DEFER_REDUCE : 0) | MI_MSM_EXACT_SIZE;
     // wireValuesB by the static gather indices, on its MSM's stream; B2 (G2) shares B1's sort (same scalars)
     MI_TRY(mi_reserve(ctx, ctx->ws[17], (pk->n_b + 1) * sizeof(Fr)));
     hipStream_t st = ctx->msm[1].stream;
