@@ -115,6 +115,8 @@ int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host);
 // Internal flag: size the entry-indexed workspaces by the COUNTED number of non-zero digits (one synchronisation of the slot's
 // stream after the count pass) instead of windows * n.  For scalars that are available when the MSM is enqueued (wire values).
 #define MI_MSM_EXACT_SIZE 0x200u
+// Internal flag: the points are in the R' = 2^261 packed form (msm_curve_ops.h to_rprime): G1 level 1 runs the 9 x 29-bit kernel.
+#define MI_MSM_PTS_RPRIME 0x400u
 struct MsmBucketView {
     void *bucket = nullptr;     // XYZZ[nkeys] on the slot's device; null for an empty MSM
     size_t nkeys = 0, xyzz_bytes = 0;
@@ -124,6 +126,7 @@ struct MsmBucketView {
 };
 int32_t mi_msm_bucket_view(mi_ctx *ctx, int slot, int curve, MsmBucketView *v);
 int32_t mi_msm_reduce_enqueue(mi_ctx *ctx, int slot, int curve);
+bool mi_msm_limb29_enabled(mi_ctx *ctx);   // the G1 level-1 kernel in 9 x 29-bit limbs is in use (mi_debug_set_msm_limb29)
 uint32_t mi_msm_auto_c(size_t n);   // the generic path's window bits for n pairs
 const struct MsmCurveOps &mi_msm_ops(int curve);
 

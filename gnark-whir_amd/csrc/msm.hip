@@ -21,6 +21,7 @@
 
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
+    u32 no_rprime = 0;                          // 1: G1 level 1 stays on the 8 x 32-bit kernel everywhere (tests compare both)
     u32 one_pass_sort = 0;                      // 1: large generic MSMs keep the one-pass counting sort (tests compare both)
     u32 chunk = 0;                              // fixed-base sort: entries per pass-2 chunk (tests shrink it)
     u32 gbits = 0;                              // fixed-base sort: log2 buckets per pass-1 group (0 = automatic)
@@ -340,7 +341,7 @@ enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCA
 // already in cur.  Level 0 reads (pts, sorted) when pts != null, else partial_first.
 static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 nkeys, LevelArrays cur, LevelArrays nxt, u64 first_items_bound,
                           u64 max_count, u32 L_first, u32 L_next, const void *pts, const u32 *sorted, const void *partial_first,
-                          void *final_out, bool time_first) {
+                          void *final_out, bool time_first, bool rprime = false) {
     hipStream_t st = sl.stream;
     const void *pin = partial_first;
     u64 items_bound = first_items_bound;
@@ -361,7 +362,7 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         if (grid > grid_cap) grid = grid_cap;
         if (grid == 0) grid = 1;
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
-        if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+        if (level == 0 && pts) (rprime && ops.accum_affine_rp ? ops.accum_affine_rp : ops.accum_affine)(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         MI_CHECK_HIP(ctx, hipGetLastError());
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], st));
@@ -493,7 +494,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
 
 // accumulate stage on slot acc, reading the sort of slot srt (may be the same slot)
 static int32_t msm_tail_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &acc);
-static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &srt, MsmSlot &acc, const void *pts, bool timed, bool defer_reduce) {
+static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &srt, MsmSlot &acc, const void *pts, bool timed, bool defer_reduce, bool rprime) {
     MsmKnobs *kn = knobs_of(ctx);
     acc.n = srt.n; acc.c = srt.c; acc.G = srt.G; acc.nwin_keys = srt.nwin_keys; acc.nwin_digits = srt.nwin_digits;
     const MsmShape s = key_shape(srt);
@@ -515,7 +516,7 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     MI_CHECK_HIP(ctx, hipGetLastError());
     // largest possible bucket: one entry per scalar and window of the key space it collects
     const u64 max_count = (u64)(srt.nwin_digits / srt.nwin_keys) * n;
-    MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed));
+    MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed, rprime));
     // everything below reads the bucket sums only: a point-sharded MSM (group.hip, SURVEY 8e option ii) stops here, exchanges
     // bucket slices between the devices and calls mi_msm_reduce_enqueue afterwards
     acc.tail_seg = seg;
@@ -593,8 +594,8 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     sl.active = false;
     sl.deferred = false;
     sl.stat_pairs = stat_pairs ? stat_pairs : n;
-    const bool defer = (flags & MI_MSM_DEFER_REDUCE) != 0, exact = (flags & MI_MSM_EXACT_SIZE) != 0;
-    flags &= ~(MI_MSM_DEFER_REDUCE | MI_MSM_EXACT_SIZE);
+    const bool defer = (flags & MI_MSM_DEFER_REDUCE) != 0, exact = (flags & MI_MSM_EXACT_SIZE) != 0, rprime = (flags & MI_MSM_PTS_RPRIME) != 0;
+    flags &= ~(MI_MSM_DEFER_REDUCE | MI_MSM_EXACT_SIZE | MI_MSM_PTS_RPRIME);
     if (n == 0) return MI_OK;
     if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
@@ -602,8 +603,9 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     if (sort_slot < 0 && precomp_c) MI_TRY(msm2_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, precomp_c, false, exact));
     else if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, generic_c, exact));
     else if (srt.n != n) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
-    return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed, defer);
+    return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed, defer, rprime && curve == 1);
 }
+bool mi_msm_limb29_enabled(mi_ctx *ctx) { return !knobs_of(ctx)->no_rprime; }
 uint32_t mi_msm_auto_c(size_t n) { return auto_c(n ? (u32)n : 1u); }
 const MsmCurveOps &mi_msm_ops(int curve) { return curve == 1 ? msm_g1_ops() : msm_g2_ops(); }
 int32_t mi_msm_reduce_enqueue(mi_ctx *ctx, int slot, int curve) {
@@ -639,8 +641,18 @@ static void xyzz_to_jac_out(const XYZZ<F> &r, JacT *out) {
 template <class F, class JacT>
 static int32_t msm_dev_entry(mi_ctx *ctx, int curve, const void *pts_dev, const void *scalars_dev, size_t n, uint32_t flags, JacT *out) {
     std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    // G1 with enough pairs to repay one pass over the bases: copy them into the R' packed form the 9 x 29-bit level-1 kernel
+    // reads (64 B in, 64 B out per point: 0.2 ms per 2^23 points against ~15 ms of MSM)
+    uint32_t rp = 0;
+    if (curve == 1 && n >= ((size_t)1 << 16) && !knobs_of(ctx)->no_rprime) {
+        MI_TRY(mi_reserve(ctx, ctx->ws[23], n * 64 + 64));
+        msm_g1_ops().to_rprime(ctx->stream, ctx->ws[23].p, pts_dev, n);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+        pts_dev = ctx->ws[23].p;
+        rp = MI_MSM_PTS_RPRIME;
+    }
     MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pts_dev, scalars_dev, n, flags | MI_MSM_EXACT_SIZE, ctx->ev[0], curve == 1));
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pts_dev, scalars_dev, n, flags | MI_MSM_EXACT_SIZE | rp, ctx->ev[0], curve == 1));
     if (n) MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->msm[0].stream));
     XYZZ<F> r;
     MI_TRY(mi_msm_finish(ctx, 0, curve, &r));
@@ -691,6 +703,11 @@ int32_t mi_msm_g1_fixed_dev(mi_ctx *ctx, const mi_g1_affine *pre_dev, const mi_f
 int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c, uint32_t flags, mi_g2_jac *out) {
     if (!ctx || !out || ((!pre_dev || !scalars_dev) && n) || (flags & ~1u)) return MI_EINVAL;
     return msm_fixed_dev_entry<Fp2>(ctx, 2, pre_dev, scalars_dev, n, c, flags, out);
+}
+int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on) {
+    if (!ctx || on > 1) return MI_EINVAL;
+    knobs_of(ctx)->no_rprime = on ? 0 : 1;
+    return MI_OK;
 }
 int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on) {
     if (!ctx || on > 1) return MI_EINVAL;

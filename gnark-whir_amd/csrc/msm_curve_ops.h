@@ -21,6 +21,12 @@ struct MsmCurveOps {
     void (*combine_windows)(const void *host_wsum, uint32_t nwin, uint32_t c, void *out_xyzz);
     // own[i] += sum_p recv[p * own_len + i]  (XYZZ; bucket slices received from the other devices of a sharded MSM)
     void (*sum_slices)(hipStream_t st, void *own, const void *recv, uint32_t n_peers, uint32_t own_len);
+    // Level-1 accumulation over points kept in the R' = 2^261 packed form (curve29.cuh: nine 29-bit limbs, lazy arithmetic);
+    // same arguments and results as accum_affine.  Null where no such kernel exists (G2).
+    void (*accum_affine_rp)(hipStream_t st, unsigned grid, const void *pts_rp, const uint32_t *sorted, const uint32_t *start, const uint32_t *cnt,
+                            const uint32_t *items, const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out);
+    // dst[i] = src[i] with both coordinates multiplied by 2^5 mod p: standard Montgomery form -> the R' packed form (dst may be src)
+    void (*to_rprime)(hipStream_t st, void *dst, const void *src, size_t n);
 };
 const MsmCurveOps &msm_g1_ops();   // msm_g1.hip
 const MsmCurveOps &msm_g2_ops();   // msm_g2.hip

@@ -70,6 +70,6 @@ static void launch_accum_affine_g2(hipStream_t st, unsigned grid, const void *pt
                        (G2X *)bucket, (G2X *)pout);
 }
 const MsmCurveOps &msm_g2_ops() {
-    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, host_combine_windows<Fp2>, launch_sum_slices<Fp2>};
+    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, host_combine_windows<Fp2>, launch_sum_slices<Fp2>, nullptr, nullptr};
     return ops;
 }

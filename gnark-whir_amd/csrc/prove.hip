@@ -143,6 +143,30 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
     if (pk->c_ak) { (void)hipFree(pk->a_full); (void)hipFree(pk->k_full); pk->a_full = pk->k_full = nullptr; }
     if (pk->owns_points && pk->c_b) { (void)hipFree(pk->g1_b); (void)hipFree(pk->g2_b); pk->g1_b = pk->g2_b = nullptr; }
     if (pk->owns_points && pk->c_z) { (void)hipFree(pk->g1_z); pk->g1_z = nullptr; }
+    // the G1 arrays of the level-1 accumulation go into the R' packed form, in place where the key owns them
+    if (mi_msm_limb29_enabled(ctx)) {
+        const MsmCurveOps &g1 = mi_msm_ops(1);
+        auto nwin_of = [](u32 c) { return (size_t)((256 + c - 1) / c); };
+        auto in_place = [&](void *arr, size_t n) { if (arr && n) g1.to_rprime(ctx->stream, arr, arr, n); };
+        auto own_or_copy = [&](void **arr, void **copy, size_t n) -> int32_t {
+            if (!*arr || !n) return MI_OK;
+            if (pk->owns_points) { g1.to_rprime(ctx->stream, *arr, *arr, n); return MI_OK; }
+            MI_CHECK_HIP(ctx, hipMalloc(copy, n * sizeof(G1Aff)));
+            g1.to_rprime(ctx->stream, *copy, *arr, n);
+            *arr = *copy;
+            return MI_OK;
+        };
+        int32_t r = MI_OK;
+        if (pk->c_ak) { in_place(pk->pre_a, nwin_of(pk->c_ak) * pk->nb_wires); in_place(pk->pre_k, nwin_of(pk->c_ak) * pk->nb_wires); }
+        else { in_place(pk->a_full, pk->nb_wires); in_place(pk->k_full, pk->nb_wires); }
+        if (pk->c_b) in_place(pk->pre_b1, nwin_of(pk->c_b) * pk->n_b);
+        else r = own_or_copy(&pk->g1_b, &pk->b1_copy, pk->n_b);
+        if (pk->c_z) in_place(pk->pre_z, nwin_of(pk->c_z) * pk->n_z_msm);
+        else if (r == MI_OK) r = own_or_copy(&pk->g1_z, &pk->z_copy, pk->n_z_msm);
+        if (r == MI_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) { ctx->err = "pk: conversion of the G1 arrays failed"; r = MI_EHIP; }
+        if (r != MI_OK) { if (device_points && !adopt) pk->owns_points = false; mi_pk_free(ctx, pk); return r; }
+        pk->rprime = true;
+    }
     *out = pk;
     return MI_OK;
 }
@@ -235,7 +259,7 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
     (void)hipStreamSynchronize(ctx->stream);
     if (pk->owns_points) for (void *p : {pk->g1_a, pk->g1_b, pk->g1_k, pk->g1_z, pk->g2_b}) if (p) (void)hipFree(p);
     for (void *p : {(void *)pk->idx_a, (void *)pk->idx_b, (void *)pk->idx_k, (void *)pk->a_full, (void *)pk->k_full}) if (p) (void)hipFree(p);
-    for (void *p : {pk->pre_a, pk->pre_k, pk->pre_b1, pk->pre_b2, pk->pre_z}) if (p) (void)hipFree(p);
+    for (void *p : {pk->pre_a, pk->pre_k, pk->pre_b1, pk->pre_b2, pk->pre_z, pk->b1_copy, pk->z_copy}) if (p) (void)hipFree(p);
     delete pk;
     return MI_OK;
 }
@@ -247,6 +271,7 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
 int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
     // wire values are skewed (45 % of them 0 or 1): their sorts are sized by the counted entries, not by windows * n (msm.hip)
     const uint32_t df = (defer ? MI_MSM_DEFER_REDUCE : 0) | MI_MSM_EXACT_SIZE;
+    const uint32_t rp = pk->rprime ? MI_MSM_PTS_RPRIME : 0;   // G1 slots only: the G2 arrays stay in the standard form
     // wireValuesB by the static gather indices, on its MSM's stream; B2 (G2) shares B1's sort (same scalars)
     MI_TRY(mi_reserve(ctx, ctx->ws[17], (pk->n_b + 1) * sizeof(Fr)));
     hipStream_t st = ctx->msm[1].stream;
@@ -254,24 +279,24 @@ int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEv
     if (pk->n_b) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((pk->n_b + 255) / 256)), dim3(256), 0, st, (Fr *)ctx->ws[17].p, (const Fr *)W, pk->idx_b, pk->n_b);
     MI_CHECK_HIP(ctx, hipGetLastError());
     if (pk->pre_b1) {
-        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, df, nullptr, true, pk->c_b));
+        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, pk->c_b));
         MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, df, nullptr, false, pk->c_b));
     } else {
-        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df, nullptr, true, 0, 0, pk->gen_c_b));
+        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, 0, 0, pk->gen_c_b));
         MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, df, nullptr, false));
     }
     // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
     // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
     if (pk->pre_a) {
-        MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->pre_a, W, pk->nb_wires, df, ev_w, true, pk->c_ak, pk->n_a));
-        return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, df, nullptr, true, pk->c_ak, pk->n_k);
+        MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->pre_a, W, pk->nb_wires, df | rp, ev_w, true, pk->c_ak, pk->n_a));
+        return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, df | rp, nullptr, true, pk->c_ak, pk->n_k);
     }
-    MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, df, ev_w, true, 0, pk->n_a, pk->gen_c_ak));
-    return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, df, nullptr, true, 0, pk->n_k);
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, df | rp, ev_w, true, 0, pk->n_a, pk->gen_c_ak));
+    return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, df | rp, nullptr, true, 0, pk->n_k);
 }
 // the Z MSM over this key's h coefficients against the bit-reversed pk.G1.Z (ev_h = "h is ready")
 int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h, hipEvent_t ev_h, bool defer) {
-    const uint32_t df = defer ? MI_MSM_DEFER_REDUCE : 0;
+    const uint32_t df = (defer ? MI_MSM_DEFER_REDUCE : 0) | (pk->rprime ? MI_MSM_PTS_RPRIME : 0);
     if (pk->pre_z) return mi_msm_enqueue(ctx, 4, -1, 1, pk->pre_z, h, pk->n_z_msm, df, ev_h, true, pk->c_z);
     return mi_msm_enqueue(ctx, 4, -1, 1, pk->g1_z, h, pk->n_z_msm, df, ev_h, true, 0, 0, pk->gen_c_z);
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include "ctx.h"
 #include "curve.cuh"
+#include "msm_curve_ops.h"
 #include <future>
 
 struct mi_pk {
@@ -24,7 +25,12 @@ struct mi_pk {
     // A part of a point-sharded key (group.hip) covers wires [wire_lo, wire_lo + nb_wires) and the Z pairs
     // [z_lo, z_lo + n_z_msm) of the 2^log_n - 1; a whole key has wire_lo = z_lo = 0 and n_z_msm = 2^log_n - 1.
     u64 wire_lo = 0, z_lo = 0, n_z_msm = 0;
-    u32 gen_c_ak = 0, gen_c_b = 0, gen_c_z = 0;   // generic-path window bits the parts of a sharded key agree on (0 = from n)
+    u32 gen_c_ak = 0, gen_c_b = 0, gen_c_z = 0;
+    // The G1 arrays the level-1 accumulation gathers from (tables, or the plain bases of a group without tables) hold both
+    // coordinates times 2^5: the R' = 2^261 packed form of the 9 x 29-bit kernel (msm_curve_ops.h).  Arrays of the caller
+    // (mi_pk_load_dev) are never rewritten: b1_copy / z_copy are the key's own converted copies of pk.G1.B / pk.G1.Z then.
+    bool rprime = false;
+    void *b1_copy = nullptr, *z_copy = nullptr;   // generic-path window bits the parts of a sharded key agree on (0 = from n)
 };
 
 

@@ -50,6 +50,38 @@ int emu_g1_mul_u32(void *out, const void *a, uint32_t k) { G1X r = xyzz_mul_u32(
 void emu_g2_b(void *out) { Fp2 b = curve_b((const Fp2 *)0); memcpy(out, &b, sizeof(b)); }
 }
 
+// ---------------------------------------------------------------- 9 x 29-bit level-1 accumulation (curve29.cuh on the host; traps on any
+// violated limb / carry assumption because this file is built with -DMI_CHECK_NOWRAP)
+#include "../../gnark-whir_amd/csrc/curve29.cuh"
+extern "C" int emu_g1_madd29_chain(void *out_aff, const void *pts_std, const unsigned char *neg, size_t n) {
+    const G1Aff *p = (const G1Aff *)pts_std;
+    G1X29 acc = g1x29_inf();
+    for (size_t i = 0; i < n; i++) {
+        G1Aff rp{fe_to_rprime_packed(p[i].x), fe_to_rprime_packed(p[i].y)};
+        u32 w[16];
+        memcpy(w, &rp, 64);
+        g1x29_madd(acc, w, neg[i] != 0);
+    }
+    *(G1Aff *)out_aff = xyzz_to_affine(g1x29_to_std(acc));
+    return 0;
+}
+extern "C" int emu_f29_roundtrip(void *out_std, const void *in_std, size_t n, int field) {   // std -> R' limbs -> std, and a product in both
+    for (size_t i = 0; i < n; i++) {
+        if (field == 1) {
+            const Fp x = ((const Fp *)in_std)[2 * i], y = ((const Fp *)in_std)[2 * i + 1];
+            F29 a = f29_from_std<FpParams>(x), b = f29_from_std<FpParams>(y);
+            ((Fp *)out_std)[2 * i] = f29_to_std<FpParams>(a);
+            ((Fp *)out_std)[2 * i + 1] = f29_to_std<FpParams>(f29_mul<FpParams>(a, b));
+        } else {
+            const Fr x = ((const Fr *)in_std)[2 * i], y = ((const Fr *)in_std)[2 * i + 1];
+            F29 a = f29_from_std<FrParams>(x), b = f29_from_std<FrParams>(y);
+            ((Fr *)out_std)[2 * i] = f29_to_std<FrParams>(a);
+            ((Fr *)out_std)[2 * i + 1] = f29_to_std<FrParams>(f29_mul<FrParams>(a, b));
+        }
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------- NTT pass emulation (ntt_tile.cuh on the host)
 #include <vector>
 #include "../../gnark-whir_amd/csrc/ntt_tile.cuh"

@@ -86,6 +86,48 @@ def test_montgomery_product_carry_edge_limbs(emu):
         assert np.array_equal(cref.field_op(field, 2, X, Y), raw_arr(want[2]))
 
 
+def test_limb29_field_roundtrip_and_product(emu):
+    """field29.cuh: standard Montgomery form -> nine 29-bit limbs (R' = 2^261) -> back, and the carry-free product, for Fp and Fr;
+    random and edge values (0, 1, p - 1, all-ones low limbs)"""
+    rng = P.SplitMix64(91)
+    for field, mod, arr, op_field in ((1, P.Q_MOD, fp_arr, 1), (0, P.R_MOD, fr_arr, 0)):
+        vals = [rng.fr() % mod for _ in range(200)] + [0, 1, mod - 1, mod - 2, (1 << 253) - 1, (1 << 224) - 1, 2, mod - 1]
+        X = arr(vals); Y = arr(vals[::-1])
+        inp = np.empty((2 * len(vals), 4), np.uint64); inp[0::2] = X; inp[1::2] = Y
+        out = np.zeros_like(inp)
+        emu.emu_f29_roundtrip(_p(out), _p(inp), C.c_size_t(len(vals)), field)
+        assert np.array_equal(out[0::2], X)
+        assert np.array_equal(out[1::2], cref.field_op(op_field, 2, X, Y))
+
+
+def test_limb29_mixed_addition_chain_matches_oracle(emu):
+    """curve29.cuh: chains of mixed additions in 29-bit limbs (lazy bounds hand-tracked; the host build traps on any limb
+    underflow or 64-bit column overflow) against the oracle's group law -- random chains with sign flips, the same point twice
+    (doubling through the standard-arithmetic slow path), a point and its opposite (cancellation to infinity and restart),
+    infinity entries, and a long chain"""
+    g = cref.gen_g1(400, 11)
+    def run(pts, neg):
+        out = np.zeros(8, np.uint64)
+        pts = np.ascontiguousarray(pts); neg = np.ascontiguousarray(neg, dtype=np.uint8)
+        emu.emu_g1_madd29_chain(_p(out), _p(pts), neg.ctypes.data_as(C.c_char_p), C.c_size_t(pts.shape[0]))
+        return out
+    def want(pts, neg):
+        acc = None
+        for p_, n_ in zip(g1_pts(pts), neg):
+            q = P.g1_neg(p_) if (n_ and p_ is not None) else p_
+            acc = q if acc is None else P.g1_add(acc, q)
+        return g1_arr([acc])[0]
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 3, 16, 64, 400):
+        neg = rng.integers(0, 2, n)
+        assert np.array_equal(run(g[:n], neg), want(g[:n], neg)), n
+    dbl = np.stack([g[0], g[0], g[1], g[1], g[1]]); z = np.zeros(5, np.uint8)
+    assert np.array_equal(run(dbl, z), want(dbl, z))
+    canc = np.stack([g[2], g[2], g[3], np.zeros(8, np.uint64), g[4]]); ng = np.array([0, 1, 0, 0, 1], np.uint8)
+    assert np.array_equal(run(canc, ng), want(canc, ng))
+    allc = np.stack([g[5], g[5]]); assert not run(allc, np.array([0, 1], np.uint8)).any()
+
+
 def test_curve_ops_bit_exact(emu):
     g1 = cref.gen_g1(64, 5)
     a = np.concatenate([g1[:32], g1[:4], g1[4:8], np.zeros((2, 8), np.uint64), g1[8:9]])

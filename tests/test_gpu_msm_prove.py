@@ -398,3 +398,31 @@ def test_generic_msm_two_pass_and_one_pass_sorts_agree_with_oracle(ctx, n, dist)
         assert ctx.lib.mi_debug_set_msm_one_pass_sort(ctx.h, 0) == 0
     for d in (dp, ds, p2):
         d.free()
+
+
+def test_limb29_level1_kernel_on_and_off_agree_with_oracle(ctx):
+    """the G1 level-1 accumulation in nine 29-bit limbs (default) and in 8 x 32-bit limbs (knob), generic and fixed-base keys:
+    proof bytes and a generic MSM with repeated / opposite / infinity points against the oracle"""
+    B = load_binding()
+    log_n = 15
+    N = 1 << log_n
+    pk = synthetic_pk(log_n, N - 50, 300, 5151, n_committed=9)
+    W = cref.gen_scalars(N - 50, 1, 1); a = cref.gen_scalars(N - 10, 2, 1); b = cref.gen_scalars(N - 10, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    n = 1 << 17
+    pts = cref.gen_g1(n, 88); sc = cref.gen_scalars(n, 89, 1)
+    pts[3] = 0; pts[6] = pts[5]; sc[6] = sc[5]; pts[8] = g1_arr([P.g1_neg(g1_pts(pts[7:8])[0])])[0]; sc[8] = sc[7]; pts[100:200] = pts[99]
+    want_msm = cref.msm_g1(pts, sc)
+    try:
+        for on in (1, 0):
+            assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, on) == 0
+            for knob in ((0, 0, 0), (17, 18, 17)):
+                assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0
+                pkh = ctx.pk_load(pk)
+                got, _ = ctx.prove(pkh, W, a, b, c, r, s)
+                ctx.pk_free(pkh)
+                assert B.proof_write(got["raw"]) == want, (on, knob)
+            assert np.array_equal(ctx.msm_g1(pts, sc), want_msm), on
+    finally:
+        assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
