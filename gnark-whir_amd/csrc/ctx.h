@@ -15,7 +15,7 @@ struct DevBuf {             // growable device scratch owned by the ctx (no hipM
 struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, workspaces, pinned result
     hipStream_t stream = nullptr;
     hipEvent_t ev[6]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job, 5: bucket sums ready (deferred reduce)
-    DevBuf buf[14];
+    DevBuf buf[15];
     void *host_wsum = nullptr;
     uint32_t n = 0, c = 0, G = 0;
     uint64_t entries_cap = 0;   // entries the sort of this slot is sized for: windows * n, or the counted number (MI_MSM_EXACT_SIZE)

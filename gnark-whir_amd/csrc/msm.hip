@@ -335,7 +335,7 @@ void mi_msm_state_free(mi_ctx *ctx) {
 }
 
 // slot buffers
-enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_PVAL, B_C1, B_CHUNKS, B_COUNT_ };
+enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_PVAL, B_C1, B_CHUNKS, B_ITEMTAB, B_COUNT_ };
 
 // Runs levels of the item machinery over `nkeys` keys whose level-0 decomposition (start/cnt/items) is
 // already in cur.  Level 0 reads (pts, sorted) when pts != null, else partial_first.
@@ -362,7 +362,10 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         if (grid > grid_cap) grid = grid_cap;
         if (grid == 0) grid = 1;
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
-        if (level == 0 && pts) (rprime && ops.accum_affine_rp ? ops.accum_affine_rp : ops.accum_affine)(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+        if (level == 0 && pts && rprime && ops.accum_affine_rp) {
+            MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
+            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p);
+        } else if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         MI_CHECK_HIP(ctx, hipGetLastError());
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], st));

@@ -24,7 +24,8 @@ struct MsmCurveOps {
     // Level-1 accumulation over points kept in the R' = 2^261 packed form (curve29.cuh: nine 29-bit limbs, lazy arithmetic);
     // same arguments and results as accum_affine.  Null where no such kernel exists (G2).
     void (*accum_affine_rp)(hipStream_t st, unsigned grid, const void *pts_rp, const uint32_t *sorted, const uint32_t *start, const uint32_t *cnt,
-                            const uint32_t *items, const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out);
+                            const uint32_t *items, const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out,
+                            void *item_table /* 16 B per item of scratch */);
     // dst[i] = src[i] with both coordinates multiplied by 2^5 mod p: standard Montgomery form -> the R' packed form (dst may be src)
     void (*to_rprime)(hipStream_t st, void *dst, const void *src, size_t n);
 };

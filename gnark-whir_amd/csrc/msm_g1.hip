@@ -7,27 +7,47 @@
 // additions of an item in nine 29-bit limbs (162 multiplications and no carry instruction per product instead of 136 + 120;
 // lazy additions), the item's sum converted back to the standard XYZZ once at its end.  +13..16 % mixed additions per second
 // (tools/bench_limb29/madd29.hip: 13.1 against 11.3 G/s on L2-resident points, conversions included).
-__global__ void __launch_bounds__(64) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
-                                                           const u32 *item_start, u32 nkeys, u32 L, G1X *bucket, G1X *partial_out) {
+// item -> (key, first entry, end entry, "this item is its key's only one"): the 19-step binary search over item_start and the four
+// dependent loads behind it, done once by a cheap, fully occupied kernel instead of at the head of every item of the heavy one
+// (which runs 2 waves per SIMD and cannot hide that chain).  16 B per item, read back as one coalesced load.
+__global__ void __launch_bounds__(256) k_msm_item_table(const u32 *start, const u32 *cnt, const u32 *items, const u32 *item_start, u32 nkeys, uint4 *tab) {
     const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
     for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
         u32 key = msm_item_key(item_start, nkeys, item), b, e;
         msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
+        tab[item] = make_uint4(key, b, e, items[key] == 1 ? 1u : 0u);
+    }
+}
+__global__ void __launch_bounds__(64) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+                                                           G1X *bucket, G1X *partial_out) {
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+        const uint4 rec = tab[item];
+        const u32 key = rec.x, b = rec.y, e = rec.z;
         G1X29 acc = g1x29_inf();
+        // software pipelining: the gather of entry k + 1 is in flight while entry k is added (the kernel runs 2 waves per SIMD --
+        // 177 VGPRs -- so the ~2 us of a random 64-B HBM read are not hidden by other waves alone)
+        u32 v = sorted[b];
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(pts + (v & 0x7fffffffu));
+        uint4 q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];   // 64 B: x | y
         for (u32 k = b; k < e; k++) {
-            const u32 v = sorted[k];
-            const uint4 *q4 = reinterpret_cast<const uint4 *>(pts + (v & 0x7fffffffu));
-            const uint4 q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];   // 64 B: x | y
             const u32 w[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-            g1x29_madd(acc, w, (v >> 31) != 0);
+            const bool neg = (v >> 31) != 0;
+            if (k + 1 < e) {
+                v = sorted[k + 1];
+                q4 = reinterpret_cast<const uint4 *>(pts + (v & 0x7fffffffu));
+                q0 = q4[0]; q1 = q4[1]; q2 = q4[2]; q3 = q4[3];
+            }
+            g1x29_madd(acc, w, neg);
         }
         const G1X out = g1x29_to_std(acc);
-        if (items[key] == 1) bucket[key] = out; else partial_out[item] = out;
+        if (rec.w) bucket[key] = out; else partial_out[item] = out;
     }
 }
 static void launch_accum_affine29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
-                                  const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout) {
-    hipLaunchKernelGGL(k_msm_accum_affine29, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, start, cnt, items, item_start, nkeys, L,
+                                  const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab) {
+    hipLaunchKernelGGL(k_msm_item_table, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
+    hipLaunchKernelGGL(k_msm_accum_affine29, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
                        (G1X *)bucket, (G1X *)pout);
 }
 __global__ void k_g1_to_rprime(G1Aff *dst, const G1Aff *src, size_t n) {

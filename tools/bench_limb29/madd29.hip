@@ -3,6 +3,7 @@
 // hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../gnark-whir_amd/csrc madd29.hip -o madd29 && ./madd29
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "curve29.cuh"
 
@@ -27,7 +28,7 @@ __global__ void __launch_bounds__(64) k32(const G1Aff *pts, u32 mask, u32 iters,
     u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
     G1X acc = G1X::inf();
     for (u32 it = 0; it < iters; it++) {
-        u32 idx = (tid * 7u + it * 13u) & mask;
+        u32 idx = ((tid * 2654435761u) ^ (it * 40503u + (tid >> 3) * 2246822519u)) & mask;
         xyzz_madd(acc, pts[idx], (it & 3) == 3);
     }
     out[tid] = acc;
@@ -37,7 +38,7 @@ __global__ void __launch_bounds__(64, W) k29(const G1Aff *pts29, u32 mask, u32 i
     u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
     G1X29 acc = g1x29_inf();
     for (u32 it = 0; it < iters; it++) {
-        u32 idx = (tid * 7u + it * 13u) & mask;
+        u32 idx = ((tid * 2654435761u) ^ (it * 40503u + (tid >> 3) * 2246822519u)) & mask;
         const u32 *q = (const u32 *)&pts29[idx];
         u32 w[16];
 #pragma unroll
@@ -47,12 +48,15 @@ __global__ void __launch_bounds__(64, W) k29(const G1Aff *pts29, u32 mask, u32 i
     out[tid] = g1x29_to_std(acc);
 }
 int main() {
-    const u32 npts = 4096, threads = 256 * 64 * 8, iters = 64;
+    const u32 npts = getenv("NPTS_LOG") ? 1u << atoi(getenv("NPTS_LOG")) : 4096, threads = 256 * 64 * 8, iters = getenv("ITERS") ? atoi(getenv("ITERS")) : 64;
     G1Aff *pts, *pts29;
     G1X *o32, *o29;
     hipMalloc(&pts, npts * sizeof(G1Aff)); hipMalloc(&pts29, npts * sizeof(G1Aff));
     hipMalloc(&o32, threads * sizeof(G1X)); hipMalloc(&o29, threads * sizeof(G1X));
-    hipLaunchKernelGGL(k_gen, dim3(npts / 64), dim3(64), 0, 0, pts, pts29, npts);
+    // a big table repeats 65536 distinct points (the generator is slow); what matters is WHERE the 64 bytes come from
+    hipLaunchKernelGGL(k_gen, dim3((npts < 65536 ? npts : 65536) / 64), dim3(64), 0, 0, pts, pts29, npts < 65536 ? npts : 65536);
+    hipDeviceSynchronize();
+    for (size_t off = 65536; off < npts; off += 65536) { hipMemcpy(pts + off, pts, 65536 * sizeof(G1Aff), hipMemcpyDeviceToDevice); hipMemcpy(pts29 + off, pts29, 65536 * sizeof(G1Aff), hipMemcpyDeviceToDevice); }
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
