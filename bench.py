@@ -301,6 +301,13 @@ def main():
         ntt_solo = {"compute_h_ms": ms_h, "transforms": 7, "pass_launches": launches, "ms_per_transform": ms_h / 7.0}
     # VALU context for the roofline line: the chip's measured 256-bit Montgomery product rate (dependent chains, all CUs)
     modmul_ms = min(ctx.bench_modmul(1, 256 * 4096, 256) for _ in range(3)) if rank == 0 else 0.0
+    # ... and the memory system's ceiling for what that kernel asks of it: dependent random 64-byte gathers from a table far larger
+    # than the 256 MB Infinity Cache (8.6 GB of scratch: the Z MSM's window tables are 7 GB at N = 2^23, A+K's 15 GB)
+    gather_ms = 0.0
+    if rank == 0:
+        gtab = ctx.alloc(64 << 27)
+        gather_ms = min(ctx.bench_gather(gtab.ptr, 1 << 27, 256 * 4 * 64 * 4, 128) for _ in range(3))
+        gtab.free()
     if rank == 0:
         proofs = args.steps * world
         # dominant kernel: G1 level-1 bucket accumulate; algorithmic bytes = 96 B per (point, scalar) pair
@@ -359,6 +366,13 @@ def main():
                              "algorithmic_bytes_per_transform": 64.0 * N},
             # why the HBM fraction is small: the kernel is bound by 256-bit modular products on the VALU (no MFMA form exists)
             "g1_msm_solo": solo,
+            # the level-1 accumulate gathers one 64-B point per mixed addition from tables of 7..16 GB: measured ceiling of the memory
+            # system for that access pattern, the kernel's own gather rate alone on the GPU, and the job's aggregate rate
+            "random_gather": {"ceiling_gathers_per_s": 256 * 4 * 64 * 4 * 128 / (gather_ms * 1e-3), "ceiling_GBps_useful": 256 * 4 * 64 * 4 * 128 * 64 / (gather_ms * 1e-3) / 1e9,
+                              "kernel_alone_gathers_per_s": solo["mixed_adds_per_s"],
+                              "frac_alone": solo["mixed_adds_per_s"] / (256 * 4 * 64 * 4 * 128 / (gather_ms * 1e-3)),
+                              "job_g1_gathers_per_s": accum_entries / dt,
+                              "note": "ceiling: dependent random 64-B reads from an 8.6 GB table, 4 waves per SIMD on every CU; G2 gathers (128 B) not counted"},
             "valu": {"modmul_ceiling_per_s": 256 * 4096 * 256 * 2 / (modmul_ms * 1e-3),
                      "kernel_mixed_adds_per_s": accum_entries / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,
                      "kernel_modmul_per_s": 10.0 * accum_entries / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,

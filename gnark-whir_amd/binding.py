@@ -19,7 +19,7 @@ EXPORTS = [
     "mi_ntt", "mi_ntt_dev", "mi_compute_h", "mi_compute_h_dev", "mi_msm_g1", "mi_msm_g1_dev", "mi_msm_g2",
     "mi_msm_g2_dev", "mi_groth16_prove", "mi_groth16_prove_dev", "mi_get_stats", "mi_g1_compress",
     "mi_g2_compress", "mi_proof_write", "mi_g1_sum", "mi_g2_sum", "mi_gen_scalars_dev", "mi_gen_g1_dev",
-    "mi_gen_g2_dev", "mi_field_op_dev", "mi_g1_add_dev", "mi_g2_add_dev", "mi_bench_modmul_dev", "mi_bench_valu_dev",
+    "mi_gen_g2_dev", "mi_field_op_dev", "mi_g1_add_dev", "mi_g2_add_dev", "mi_bench_modmul_dev", "mi_bench_valu_dev", "mi_bench_gather_dev",
     "mi_dev_alloc", "mi_dev_free", "mi_dev_upload", "mi_dev_download", "mi_dev_sync",
     "mi_msm_precompute_g1_dev", "mi_msm_precompute_g2_dev", "mi_msm_g1_fixed_dev", "mi_msm_g2_fixed_dev",
     "mi_batch_scalar_mul_g1", "mi_batch_scalar_mul_g1_dev", "mi_batch_scalar_mul_g2", "mi_batch_scalar_mul_g2_dev",
@@ -202,6 +202,11 @@ class Context:
     def bench_modmul(self, field, n_threads, iters):
         s = self.alloc(1024 * 32); ms = C.c_float()
         self._ck(self.lib.mi_bench_modmul_dev(self.h, field, C.c_size_t(n_threads), C.c_uint32(iters), _p(s.ptr), C.byref(ms)))
+        s.free(); return ms.value
+
+    def bench_gather(self, table_ptr, n_entries, n_threads, iters):
+        s = self.alloc(1024); ms = C.c_float()
+        self._ck(self.lib.mi_bench_gather_dev(self.h, _p(table_ptr), C.c_size_t(n_entries), C.c_size_t(n_threads), C.c_uint32(iters), _p(s.ptr), C.byref(ms)))
         s.free(); return ms.value
 
     def bench_valu(self, kind, n_threads, iters):

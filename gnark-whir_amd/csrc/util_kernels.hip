@@ -129,6 +129,18 @@ __global__ void k_bench_modmul(Fe<P> *scratch, u32 iters) {
 }
 // raw VALU probes: kind 0 = 32x32+64 mad (v_mad_u64_u32), 1 = v_mul_lo+hi u32, 2 = fma f64,
 // 3 = 24-bit mad, 4 = add/addc chain
+__global__ void __launch_bounds__(64) k_bench_gather(const uint4 *tab, u64 mask, u32 iters, uint4 *out) {
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint4 acc = make_uint4(tid, 0, 0, 0);
+    u64 h = tid * 0x9E3779B97F4A7C15ull;
+    for (u32 it = 0; it < iters; it++) {
+        h = h * 6364136223846793005ull + 1442695040888963407ull + acc.x;   // the next address depends on this gather, as in a bucket's chain
+        const uint4 *q = tab + ((h >> 20) & mask) * 4;
+        const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+        acc.x ^= a.x ^ b.y ^ c.z ^ d.w; acc.y += a.y + d.x; acc.z ^= b.z; acc.w += c.w;
+    }
+    out[tid & 63] = acc;
+}
 __global__ void k_bench_valu(int kind, u32 iters, u64 *sink) {
     u32 t = threadIdx.x + blockIdx.x * blockDim.x;
     u64 a0 = t, a1 = t + 1, a2 = t + 2, a3 = t + 3, a4 = t + 4, a5 = t + 5, a6 = t + 6, a7 = t + 7;
@@ -214,6 +226,17 @@ int32_t mi_bench_modmul_dev(mi_ctx *ctx, int field, size_t n_threads, uint32_t i
     MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     if (field == 0) hipLaunchKernelGGL(k_bench_modmul<FrParams>, dim3((unsigned)(n_threads / 256)), dim3(256), 0, ctx->stream, (Fr *)scratch_dev, iters);
     else hipLaunchKernelGGL(k_bench_modmul<FpParams>, dim3((unsigned)(n_threads / 256)), dim3(256), 0, ctx->stream, (Fp *)scratch_dev, iters);
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    MI_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev[0], ctx->ev[1]));
+    return MI_OK;
+}
+// random 64-byte gathers from a table of n_entries 64-B entries (no arithmetic): the memory system's ceiling for the MSM's
+// level-1 accumulation, which gathers one 64-B point per mixed addition from tables far larger than the 256 MB Infinity Cache
+int32_t mi_bench_gather_dev(mi_ctx *ctx, const void *table_dev, size_t n_entries, size_t n_threads, uint32_t iters, void *scratch_dev, float *ms_out) {
+    if (!ctx || !table_dev || !scratch_dev || !ms_out || n_threads % 64 || n_entries < 2 || (n_entries & (n_entries - 1))) return MI_EINVAL;
+    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(k_bench_gather, dim3((unsigned)(n_threads / 64)), dim3(64), 0, ctx->stream, (const uint4 *)table_dev, (u64)(n_entries - 1), iters, (uint4 *)scratch_dev);
     MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     MI_CHECK_HIP(ctx, hipEventSynchronize(ctx->ev[1]));
     MI_CHECK_HIP(ctx, hipEventElapsedTime(ms_out, ctx->ev[0], ctx->ev[1]));

@@ -318,6 +318,10 @@ int32_t mi_g1_add_dev(mi_ctx *ctx, mi_g1_affine *out_dev, const mi_g1_affine *a_
                       const mi_g1_affine *b_dev, size_t n);
 int32_t mi_g2_add_dev(mi_ctx *ctx, mi_g2_affine *out_dev, const mi_g2_affine *a_dev,
                       const mi_g2_affine *b_dev, size_t n);
+/* random-gather throughput probe: n_threads lanes each chain `iters` dependent 64-byte gathers from a table of n_entries
+ * (a power of two) 64-byte entries; scratch: 1 KiB.  The ceiling the level-1 bucket accumulation's point gathers run against. */
+int32_t mi_bench_gather_dev(mi_ctx *ctx, const void *table_dev, size_t n_entries, size_t n_threads, uint32_t iters,
+                            void *scratch_dev, float *ms_out);
 /* modular-multiply throughput probe: chains `iters` dependent Fp products per thread */
 int32_t mi_bench_modmul_dev(mi_ctx *ctx, int field, size_t n_threads, uint32_t iters,
                             void *scratch_dev, float *ms_out);
