@@ -9,8 +9,10 @@ carries the latency of one proof alone).  N > 1 GPUs: one independent pool per G
 collective) -> weak scaling, value = proofs of all ranks / max-rank time.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant
-kernel (G1 level-1 bucket accumulate) and `cpu_baseline` (the oracle's C restatement on the host cores,
-rank 0, N = 1 only, on a bounded sample).
+kernel (G1 level-1 bucket accumulate), `roofline_ntt`, `random_gather` / `valu` (the two ceilings that kernel runs
+against), `value_host_inputs` (the same K steps with host-pointer inputs, the cgo path), `sharded_msm` (BASELINE
+configs[4] through the C-ABI's device group) and `cpu_baseline` (the oracle's C restatement on the host cores, rank 0,
+N = 1 only: one full prove of the benchmarked workload itself, proof bytes compared with the GPU's).
 """
 import argparse
 import importlib.util
@@ -323,7 +325,7 @@ def main():
         if log_n == 23 and args.dist == "whir" and not (args.msm_plan or args.fixed_base or args.ntt_plan or args.msm_group_bits or args.msm_chunk):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")))
-                kname = "void k_msm_accum_affine<Fe<FpParams> >"
+                kname = "k_msm_accum_affine29"
                 traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
                 kn = "k_ntt_pass_wave"   # per pass launch; one transform = pass_launches / 7 launches
                 traffic_ntt = (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0 * ntt_solo["pass_launches"] / 7.0
@@ -352,7 +354,7 @@ def main():
             # inside a proof the five MSMs overlap on five streams, so per-MSM spans there are not rates
             "g1_msm_pts_per_s": solo["msm_pts_per_s"], "g1_pairs_per_proof": g1_pairs_per_proof,
             "phase_ms": {k: last[k] for k in ("compute_h_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "msm_k_ms", "msm_z_ms", "assemble_ms", "total_ms")},
-            "roofline": {"kernel": "k_msm_accum_affine<Fp> (G1 level-1 bucket accumulate)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": "profiles/r02_pmc_bench_traffic.json (committed PMC passes of this workload, not this run)",
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
