@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) k_msm_item_table(const u32 *start, const 
         tab[item] = make_uint4(key, b, e, items[key] == 1 ? 1u : 0u);
     }
 }
-__global__ void __launch_bounds__(64) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+__global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
                                                            G1X *bucket, G1X *partial_out) {
     const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
     for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
