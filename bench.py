@@ -71,6 +71,7 @@ def sharded_msm_section(B, torch, dist, rank, local_rank, world, log_n_msm, step
     mode 1 = reduce-scatter of bucket sums (grouped ncclSend / ncclRecv) before the bucket reduce.  Strong scaling: total work
     fixed.  Fills `result` (a dict) in place so that a watchdog can give up on it."""
     import numpy as np
+    torch.cuda.set_device(local_rank)   # this runs on a thread of its own: the current device is per thread
     uid = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
         uid = torch.tensor(list(B.Group.unique_id()), dtype=torch.uint8)
