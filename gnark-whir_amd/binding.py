@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355x_groth16.so")
+LIB_PATH = os.environ.get("MI355X_GROTH16_LIB", os.path.join(_HERE, "libmi355x_groth16.so"))   # the override is for A/B runs of two builds
 _LIB = None
 
 EXPORTS = [
