@@ -1,5 +1,5 @@
-"""Soak: many proofs through the prover pool, every one compared with the proof a plain context computed alone.
-usage: python tools/soak_pool.py [log_n] [jobs] [in_flight]"""
+"""Soak: many proofs through the prover pool -- device-resident and HOST inputs mixed (the upload stage) -- every one compared
+with the proof a plain context computed alone.   usage: python tools/soak_pool.py [log_n] [jobs] [in_flight]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
@@ -27,6 +27,7 @@ for w in range(2):
     c = c0.alloc(32 * n_constraints); c0.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)
     wit.append((W, a, b, c))
 rs = c0.gen_scalars(8, 400, 0).download((8, 4))
+hwit = [tuple(x.download((n, 4)) for x, n in zip(wt, (nb_wires, n_constraints, n_constraints, n_constraints))) for wt in wit]   # host copies
 c0.sync()
 single = B.Context(0)
 combos = [(w, k) for w in range(2) for k in range(4)]
@@ -38,7 +39,10 @@ t0 = time.perf_counter(); bad = 0; done = 0
 window = []
 for j in range(jobs):
     w, k = combos[j % len(combos)]
-    window.append(((w, k), pool.submit(pkh, *(x.ptr for x in wit[w]), rs[2 * k], rs[2 * k + 1], device=True, n_wires=nb_wires, n_constraints=n_constraints)))
+    if j % 3 == 1:   # every third job hands over host pointers
+        window.append(((w, k), pool.submit(pkh, *hwit[w], rs[2 * k], rs[2 * k + 1])))
+    else:
+        window.append(((w, k), pool.submit(pkh, *(x.ptr for x in wit[w]), rs[2 * k], rs[2 * k + 1], device=True, n_wires=nb_wires, n_constraints=n_constraints)))
     if len(window) >= 4 * depth:
         key, t = window.pop(0)
         bad += not np.array_equal(pool.wait(t)[0]["raw"], ref[key]); done += 1
