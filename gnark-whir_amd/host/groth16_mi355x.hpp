@@ -128,6 +128,38 @@ class Prover {
     mi_prover *p_ = nullptr;
 };
 
+// One groth16.Prove spread over several GPUs of a node: contexts on `devices`, the key point-sharded at load,
+// mode 0 = per-device partial sums, 1 = reduce-scatter of bucket sums (RCCL; include/mi355x_groth16.h, device groups).
+class DeviceGroup {
+  public:
+    explicit DeviceGroup(const std::vector<int> &devices) {
+        int32_t rc = mi_group_create(devices.data(), (int)devices.size(), &g_);
+        if (rc != MI_OK) throw Error(rc, "mi_group_create failed (no gfx950 device? there is no CPU path)");
+    }
+    ~DeviceGroup() { if (spk_) mi_pk_sharded_free(g_, spk_); if (g_) mi_group_destroy(g_); }
+    DeviceGroup(const DeviceGroup &) = delete;
+    DeviceGroup &operator=(const DeviceGroup &) = delete;
+    void check(int32_t rc) const { if (rc != MI_OK) throw Error(rc, mi_group_last_error(g_)); }
+    void LoadKey(const mi_pk_desc &desc) { if (spk_) { mi_pk_sharded_free(g_, spk_); spk_ = nullptr; } check(mi_pk_load_sharded(g_, &desc, &spk_)); }
+    Proof Prove(const Solution &s, const mi_fr &r, const mi_fr &sBlind, uint32_t mode = 0) {
+        mi_proof_out out{};
+        check(mi_groth16_prove_sharded(g_, spk_, s.W, s.nWires, s.A, s.B, s.C, s.nConstraints, &r, &sBlind, mode, &out, nullptr));
+        Proof p;
+        p.Ar = out.ar; p.Bs = out.bs; p.Krs = out.krs;
+        return p;
+    }
+    mi_g1_jac MultiExpG1(const std::vector<mi_g1_affine> &points, const std::vector<mi_fr> &scalars, uint32_t mode = 0) {
+        if (points.size() != scalars.size()) throw Error(MI_EINVAL, "MultiExp: len(points) != len(scalars)");
+        mi_g1_jac out{};
+        check(mi_msm_g1_sharded(g_, points.data(), scalars.data(), points.size(), 0, mode, &out));
+        return out;
+    }
+
+  private:
+    mi_group *g_ = nullptr;
+    mi_pk_sharded *spk_ = nullptr;
+};
+
 // ecc/bn254 MultiExp
 inline mi_g1_jac MultiExpG1(const Context &ctx, const std::vector<mi_g1_affine> &points, const std::vector<mi_fr> &scalars) {
     if (points.size() != scalars.size()) throw Error(MI_EINVAL, "MultiExp: len(points) != len(scalars)");   // gnark: same error

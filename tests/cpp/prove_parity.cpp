@@ -80,6 +80,20 @@ int main() {
             catch (const groth16::Error &) { threw = true; }
             if (!threw) { std::puts("MISMATCH: pool size check"); return 1; }
         }
+        // the same proof over a device group: two ranks (both on device 0 here: one GPU), both exchange modes
+        {
+            groth16::DeviceGroup grp({0, 0});
+            grp.LoadKey(d);
+            for (uint32_t mode = 0; mode < 2; mode++) {
+                std::vector<uint8_t> pb;
+                grp.Prove(sol, rs[0], rs[1], mode).WriteTo(pb);
+                if (pb != wb) { std::printf("MISMATCH: sharded proof bytes differ (mode %u)\n", mode); return 1; }
+            }
+            std::vector<mi_g1_affine> p99(p100.begin(), p100.begin() + 99);   // sc lost one entry in the length check above
+            mi_g1_jac gs = grp.MultiExpG1(p99, sc, 1), ws{};
+            ref_msm_g1(p99.data(), sc.data(), 99, 0, &ws);
+            if (std::memcmp(&gs, &ws, sizeof(gs)) != 0) { std::puts("MISMATCH: sharded MultiExp"); return 1; }
+        }
         std::printf("OK %zu proof bytes identical\n", got.size());
         return 0;
     } catch (const groth16::Error &e) {
