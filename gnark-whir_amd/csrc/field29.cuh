@@ -141,6 +141,18 @@ MI_HD F29 f29_wnorm(const F29 &x) {
     z.l[8] = x.l[8] + (x.l[7] >> 29);
     return z;
 }
+// if x >= K p (decided on the top limb: x_8 > (K p)_8, so surely x > K p): x -= K p.  kp = K p normalised.  Input weak; the result has
+// limbs < 2^30 (one f29_wnorm later) and is < K p + 2^232 + (what the top-limb test cannot see) -- "almost < K p".
+MI_HD F29 f29_condsub(const F29 &x, const u32 (&kp)[9]) {
+    constexpr u32 B = 1u << 29;
+    const bool take = x.l[8] > kp[8];
+    F29 z;
+    z.l[0] = x.l[0] + (take ? B - kp[0] : 0u);
+#pragma unroll
+    for (int i = 1; i < 8; i++) z.l[i] = x.l[i] + (take ? B - 1 - kp[i] : 0u);
+    z.l[8] = x.l[8] - (take ? kp[8] + 1 : 0u);
+    return z;
+}
 // 32 bytes (8 x u32 little-endian, any value < 2^256) -> nine 29-bit limbs, normalised
 MI_HD F29 f29_unpack(const u32 *w) {
     constexpr u32 M = (1u << 29) - 1;

@@ -606,7 +606,7 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     if (sort_slot < 0 && precomp_c) MI_TRY(msm2_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, precomp_c, false, exact));
     else if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, generic_c, exact));
     else if (srt.n != n) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
-    return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed, defer, rprime && curve == 1);
+    return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed, defer, rprime);
 }
 bool mi_msm_limb29_enabled(mi_ctx *ctx) { return !knobs_of(ctx)->no_rprime; }
 uint32_t mi_msm_auto_c(size_t n) { return auto_c(n ? (u32)n : 1u); }
@@ -647,9 +647,10 @@ static int32_t msm_dev_entry(mi_ctx *ctx, int curve, const void *pts_dev, const 
     // G1 with enough pairs to repay one pass over the bases: copy them into the R' packed form the 9 x 29-bit level-1 kernel
     // reads (64 B in, 64 B out per point: 0.2 ms per 2^23 points against ~15 ms of MSM)
     uint32_t rp = 0;
-    if (curve == 1 && n >= ((size_t)1 << 16) && !knobs_of(ctx)->no_rprime) {
-        MI_TRY(mi_reserve(ctx, ctx->ws[23], n * 64 + 64));
-        msm_g1_ops().to_rprime(ctx->stream, ctx->ws[23].p, pts_dev, n);
+    if (n >= ((size_t)1 << (curve == 1 ? 16 : 14)) && !knobs_of(ctx)->no_rprime) {
+        const MsmCurveOps &o = curve == 1 ? msm_g1_ops() : msm_g2_ops();
+        MI_TRY(mi_reserve(ctx, ctx->ws[23], n * (curve == 1 ? 64 : 128) + 64));
+        o.to_rprime(ctx->stream, ctx->ws[23].p, pts_dev, n);
         MI_CHECK_HIP(ctx, hipGetLastError());
         pts_dev = ctx->ws[23].p;
         rp = MI_MSM_PTS_RPRIME;

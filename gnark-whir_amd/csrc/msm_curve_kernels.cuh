@@ -75,6 +75,18 @@ static void launch_sum_tree(hipStream_t st, unsigned nout, unsigned nwin, const 
     hipLaunchKernelGGL(k_msm_sum_tree<F>, dim3(nout, nwin), dim3(SumT<F>::value), SumT<F>::value * sizeof(XYZZ<F>), st, (const XYZZ<F> *)in, n, nout,
                        (XYZZ<F> *)out);
 }
+// item -> (key, first entry, end entry, "this item is its key's only one"): the 19-step binary search over item_start and the four
+// dependent loads behind it, done once by a cheap, fully occupied kernel instead of at the head of every item of the heavy one
+// (which runs 2 waves per SIMD and cannot hide that chain).  16 B per item, read back as one coalesced load.
+template <class F>   // F only keeps the two translation units' instances apart
+__global__ void __launch_bounds__(256) k_msm_item_table(const u32 *start, const u32 *cnt, const u32 *items, const u32 *item_start, u32 nkeys, uint4 *tab) {
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+        u32 key = msm_item_key(item_start, nkeys, item), b, e;
+        msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
+        tab[item] = make_uint4(key, b, e, items[key] == 1 ? 1u : 0u);
+    }
+}
 // Point-sharded MSM, SURVEY 8e option ii: own[i] += sum_p recv[p * own_len + i] -- the bucket sums the other devices hold for
 // the keys this device owns, added to its own before the bucket reduce.
 template <class F>

@@ -7,17 +7,6 @@
 // additions of an item in nine 29-bit limbs (162 multiplications and no carry instruction per product instead of 136 + 120;
 // lazy additions), the item's sum converted back to the standard XYZZ once at its end.  +13..16 % mixed additions per second
 // (tools/bench_limb29/madd29.hip: 13.1 against 11.3 G/s on L2-resident points, conversions included).
-// item -> (key, first entry, end entry, "this item is its key's only one"): the 19-step binary search over item_start and the four
-// dependent loads behind it, done once by a cheap, fully occupied kernel instead of at the head of every item of the heavy one
-// (which runs 2 waves per SIMD and cannot hide that chain).  16 B per item, read back as one coalesced load.
-__global__ void __launch_bounds__(256) k_msm_item_table(const u32 *start, const u32 *cnt, const u32 *items, const u32 *item_start, u32 nkeys, uint4 *tab) {
-    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
-    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
-        u32 key = msm_item_key(item_start, nkeys, item), b, e;
-        msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
-        tab[item] = make_uint4(key, b, e, items[key] == 1 ? 1u : 0u);
-    }
-}
 __global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
                                                            G1X *bucket, G1X *partial_out) {
     const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
@@ -46,7 +35,7 @@ __global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, 
 }
 static void launch_accum_affine29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
                                   const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab) {
-    hipLaunchKernelGGL(k_msm_item_table, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
+    hipLaunchKernelGGL(k_msm_item_table<Fp>, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
     hipLaunchKernelGGL(k_msm_accum_affine29, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
                        (G1X *)bucket, (G1X *)pout);
 }

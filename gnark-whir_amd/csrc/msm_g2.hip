@@ -1,5 +1,6 @@
 // G2 instantiation of the MSM point kernels (see msm_curve_kernels.cuh, msm.hip) + the LDS-accumulator level-1 kernel.
 #include "msm_curve_kernels.cuh"
+#include "curve29_g2.cuh"
 
 // G2 level-1 accumulation with the XYZZ accumulator resident in LDS ([word][lane] image, 16 KiB per 64-lane
 // workgroup): only the operands of the current step live in VGPRs, so the kernel needs no scratch (the register
@@ -69,7 +70,60 @@ static void launch_accum_affine_g2(hipStream_t st, unsigned grid, const void *pt
     hipLaunchKernelGGL(k_msm_accum_affine_g2_lds, dim3(grid), dim3(64), 0, st, (const G2Aff *)pts, sorted, start, cnt, items, item_start, nkeys, L,
                        (G2X *)bucket, (G2X *)pout);
 }
+// The same level-1 accumulation in the 9 x 29-bit representation (curve29_g2.cuh): accumulator image [word][lane] of 4 x 18 words
+// (18 KiB per 64-lane workgroup), points read in the R' packed form, an item's sum converted back to the standard XYZZ once.
+struct LdsAccG2_29 {
+    u32 *base;   // &lds[0][lane]
+    MI_D F2_29 ld(int comp) const {
+        F2_29 v;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { v.a0.l[i] = base[(comp * 18 + i) * 64]; v.a1.l[i] = base[(comp * 18 + 9 + i) * 64]; }
+        return v;
+    }
+    MI_D void st(int comp, const F2_29 &v) const {
+#pragma unroll
+        for (int i = 0; i < 9; i++) { base[(comp * 18 + i) * 64] = v.a0.l[i]; base[(comp * 18 + 9 + i) * 64] = v.a1.l[i]; }
+    }
+};
+__global__ void __launch_bounds__(64, 2) k_msm_accum_affine_g2_29(const G2Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+                                                                  G2X *bucket, G2X *partial_out) {
+    __shared__ u32 lds[72 * 64];
+    const LdsAccG2_29 A{&lds[threadIdx.x]};
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+        const uint4 rec = tab[item];
+        const u32 key = rec.x, b = rec.y, e = rec.z;
+        bool inf = true;
+        for (u32 k = b; k < e; k++) {
+            const u32 v = sorted[k];
+            const uint4 *q4 = reinterpret_cast<const uint4 *>(pts + (v & 0x7fffffffu));
+            u32 w[32];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const uint4 t = q4[j]; w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w; }
+            g2x29_madd(A, inf, w, (v >> 31) != 0);
+        }
+        G2X out = G2X::inf();
+        if (!inf) out = G2X{f2_29_to_std(A.ld(0)), f2_29_to_std(A.ld(1)), f2_29_to_std(A.ld(2)), f2_29_to_std(A.ld(3))};
+        if (rec.w) bucket[key] = out; else partial_out[item] = out;
+    }
+}
+static void launch_accum_affine_g2_29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
+                                      const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab) {
+    hipLaunchKernelGGL(k_msm_item_table<Fp2>, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
+    hipLaunchKernelGGL(k_msm_accum_affine_g2_29, dim3(grid), dim3(64), 0, st, (const G2Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
+                       (G2X *)bucket, (G2X *)pout);
+}
+__global__ void k_g2_to_rprime(G2Aff *dst, const G2Aff *src, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G2Aff a = src[i];
+    dst[i] = G2Aff{Fp2{fe_to_rprime_packed(a.x.a0), fe_to_rprime_packed(a.x.a1)}, Fp2{fe_to_rprime_packed(a.y.a0), fe_to_rprime_packed(a.y.a1)}};
+}
+static void launch_g2_to_rprime(hipStream_t st, void *dst, const void *src, size_t n) {
+    if (n) hipLaunchKernelGGL(k_g2_to_rprime, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (G2Aff *)dst, (const G2Aff *)src, n);
+}
+
 const MsmCurveOps &msm_g2_ops() {
-    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, host_combine_windows<Fp2>, launch_sum_slices<Fp2>, nullptr, nullptr};
+    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, launch_g2_to_rprime};
     return ops;
 }

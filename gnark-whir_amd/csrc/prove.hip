@@ -161,6 +161,15 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
         else { in_place(pk->a_full, pk->nb_wires); in_place(pk->k_full, pk->nb_wires); }
         if (pk->c_b) in_place(pk->pre_b1, nwin_of(pk->c_b) * pk->n_b);
         else r = own_or_copy(&pk->g1_b, &pk->b1_copy, pk->n_b);
+        {   // pk.G2.B the same way with the G2 conversion
+            const MsmCurveOps &g2 = mi_msm_ops(2);
+            if (pk->c_b) { if (pk->pre_b2 && pk->n_b) g2.to_rprime(ctx->stream, pk->pre_b2, pk->pre_b2, nwin_of(pk->c_b) * pk->n_b); }
+            else if (r == MI_OK && pk->g2_b && pk->n_b) {
+                if (pk->owns_points) g2.to_rprime(ctx->stream, pk->g2_b, pk->g2_b, pk->n_b);
+                else if (hipMalloc(&pk->b2_copy, pk->n_b * sizeof(G2Aff)) != hipSuccess) { (void)hipGetLastError(); ctx->err = "pk: no room for the converted copy of pk.G2.B"; r = MI_ENOMEM; }
+                else { g2.to_rprime(ctx->stream, pk->b2_copy, pk->g2_b, pk->n_b); pk->g2_b = pk->b2_copy; }
+            }
+        }
         if (pk->c_z) in_place(pk->pre_z, nwin_of(pk->c_z) * pk->n_z_msm);
         else if (r == MI_OK) r = own_or_copy(&pk->g1_z, &pk->z_copy, pk->n_z_msm);
         if (r == MI_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) { ctx->err = "pk: conversion of the G1 arrays failed"; r = MI_EHIP; }
@@ -259,7 +268,7 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
     (void)hipStreamSynchronize(ctx->stream);
     if (pk->owns_points) for (void *p : {pk->g1_a, pk->g1_b, pk->g1_k, pk->g1_z, pk->g2_b}) if (p) (void)hipFree(p);
     for (void *p : {(void *)pk->idx_a, (void *)pk->idx_b, (void *)pk->idx_k, (void *)pk->a_full, (void *)pk->k_full}) if (p) (void)hipFree(p);
-    for (void *p : {pk->pre_a, pk->pre_k, pk->pre_b1, pk->pre_b2, pk->pre_z, pk->b1_copy, pk->z_copy}) if (p) (void)hipFree(p);
+    for (void *p : {pk->pre_a, pk->pre_k, pk->pre_b1, pk->pre_b2, pk->pre_z, pk->b1_copy, pk->z_copy, pk->b2_copy}) if (p) (void)hipFree(p);
     delete pk;
     return MI_OK;
 }
@@ -271,7 +280,7 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
 int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
     // wire values are skewed (45 % of them 0 or 1): their sorts are sized by the counted entries, not by windows * n (msm.hip)
     const uint32_t df = (defer ? MI_MSM_DEFER_REDUCE : 0) | MI_MSM_EXACT_SIZE;
-    const uint32_t rp = pk->rprime ? MI_MSM_PTS_RPRIME : 0;   // G1 slots only: the G2 arrays stay in the standard form
+    const uint32_t rp = pk->rprime ? MI_MSM_PTS_RPRIME : 0;
     // wireValuesB by the static gather indices, on its MSM's stream; B2 (G2) shares B1's sort (same scalars)
     MI_TRY(mi_reserve(ctx, ctx->ws[17], (pk->n_b + 1) * sizeof(Fr)));
     hipStream_t st = ctx->msm[1].stream;
@@ -280,10 +289,10 @@ int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEv
     MI_CHECK_HIP(ctx, hipGetLastError());
     if (pk->pre_b1) {
         MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, pk->c_b));
-        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, df, nullptr, false, pk->c_b));
+        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, df | rp, nullptr, false, pk->c_b));
     } else {
         MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, 0, 0, pk->gen_c_b));
-        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, df, nullptr, false));
+        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, df | rp, nullptr, false));
     }
     // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
     // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less

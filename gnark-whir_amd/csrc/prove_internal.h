@@ -30,7 +30,7 @@ struct mi_pk {
     // coordinates times 2^5: the R' = 2^261 packed form of the 9 x 29-bit kernel (msm_curve_ops.h).  Arrays of the caller
     // (mi_pk_load_dev) are never rewritten: b1_copy / z_copy are the key's own converted copies of pk.G1.B / pk.G1.Z then.
     bool rprime = false;
-    void *b1_copy = nullptr, *z_copy = nullptr;   // generic-path window bits the parts of a sharded key agree on (0 = from n)
+    void *b1_copy = nullptr, *z_copy = nullptr, *b2_copy = nullptr;   // generic-path window bits the parts of a sharded key agree on (0 = from n)
 };
 
 

@@ -65,6 +65,22 @@ extern "C" int emu_g1_madd29_chain(void *out_aff, const void *pts_std, const uns
     *(G1Aff *)out_aff = xyzz_to_affine(g1x29_to_std(acc));
     return 0;
 }
+#include "../../gnark-whir_amd/csrc/curve29_g2.cuh"
+struct RegAccG2_29 { F2_29 c[4]; F2_29 ld(int k) const { return c[k]; } void st(int k, const F2_29 &v) { c[k] = v; } };
+extern "C" int emu_g2_madd29_chain(void *out_aff, const void *pts_std, const unsigned char *neg, size_t n) {
+    const G2Aff *p = (const G2Aff *)pts_std;
+    RegAccG2_29 A{};
+    bool inf = true;
+    for (size_t i = 0; i < n; i++) {
+        G2Aff rp{Fp2{fe_to_rprime_packed(p[i].x.a0), fe_to_rprime_packed(p[i].x.a1)}, Fp2{fe_to_rprime_packed(p[i].y.a0), fe_to_rprime_packed(p[i].y.a1)}};
+        u32 w[32];
+        memcpy(w, &rp, 128);
+        g2x29_madd(A, inf, w, neg[i] != 0);
+    }
+    G2X s = inf ? G2X::inf() : G2X{f2_29_to_std(A.ld(0)), f2_29_to_std(A.ld(1)), f2_29_to_std(A.ld(2)), f2_29_to_std(A.ld(3))};
+    *(G2Aff *)out_aff = xyzz_to_affine(s);
+    return 0;
+}
 extern "C" int emu_f29_roundtrip(void *out_std, const void *in_std, size_t n, int field) {   // std -> R' limbs -> std, and a product in both
     for (size_t i = 0; i < n; i++) {
         if (field == 1) {

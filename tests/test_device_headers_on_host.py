@@ -128,6 +128,32 @@ def test_limb29_mixed_addition_chain_matches_oracle(emu):
     allc = np.stack([g[5], g[5]]); assert not run(allc, np.array([0, 1], np.uint8)).any()
 
 
+def test_limb29_g2_mixed_addition_chain_matches_oracle(emu):
+    """curve29_g2.cuh on the host (overflow traps on): Fp2 over 29-bit limbs, dual products, the conditional -4p / -2p of X3; chains
+    with sign flips, doubling, cancellation, infinity entries"""
+    g = cref.gen_g2(80, 12)
+    def run(pts, neg):
+        out = np.zeros(16, np.uint64)
+        pts = np.ascontiguousarray(pts); neg = np.ascontiguousarray(neg, dtype=np.uint8)
+        emu.emu_g2_madd29_chain(_p(out), _p(pts), neg.ctypes.data_as(C.c_char_p), C.c_size_t(pts.shape[0]))
+        return out
+    def want(pts, neg):
+        acc = None
+        for p_, n_ in zip(g2_pts(pts), neg):
+            q = P.g2_neg(p_) if (n_ and p_ is not None) else p_
+            acc = q if acc is None else P.g2_add(acc, q)
+        return g2_arr([acc])[0]
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 3, 17, 80):
+        neg = rng.integers(0, 2, n)
+        assert np.array_equal(run(g[:n], neg), want(g[:n], neg)), n
+    dbl = np.stack([g[0], g[0], g[1], g[1], g[1]]); z = np.zeros(5, np.uint8)
+    assert np.array_equal(run(dbl, z), want(dbl, z))
+    canc = np.stack([g[2], g[2], g[3], np.zeros(16, np.uint64), g[4]]); ng = np.array([0, 1, 0, 0, 1], np.uint8)
+    assert np.array_equal(run(canc, ng), want(canc, ng))
+    assert not run(np.stack([g[5], g[5]]), np.array([0, 1], np.uint8)).any()
+
+
 def test_curve_ops_bit_exact(emu):
     g1 = cref.gen_g1(64, 5)
     a = np.concatenate([g1[:32], g1[:4], g1[4:8], np.zeros((2, 8), np.uint64), g1[8:9]])

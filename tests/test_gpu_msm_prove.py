@@ -414,6 +414,10 @@ def test_limb29_level1_kernel_on_and_off_agree_with_oracle(ctx):
     pts = cref.gen_g1(n, 88); sc = cref.gen_scalars(n, 89, 1)
     pts[3] = 0; pts[6] = pts[5]; sc[6] = sc[5]; pts[8] = g1_arr([P.g1_neg(g1_pts(pts[7:8])[0])])[0]; sc[8] = sc[7]; pts[100:200] = pts[99]
     want_msm = cref.msm_g1(pts, sc)
+    n2 = 1 << 15
+    p2 = cref.gen_g2(n2, 90); s2 = cref.gen_scalars(n2, 91, 1)
+    p2[3] = 0; p2[6] = p2[5]; s2[6] = s2[5]; p2[8] = g2_arr([P.g2_neg(g2_pts(p2[7:8])[0])])[0]; s2[8] = s2[7]; p2[40:60] = p2[39]
+    want_msm2 = cref.msm_g2(p2, s2)
     try:
         for on in (1, 0):
             assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, on) == 0
@@ -424,5 +428,6 @@ def test_limb29_level1_kernel_on_and_off_agree_with_oracle(ctx):
                 ctx.pk_free(pkh)
                 assert B.proof_write(got["raw"]) == want, (on, knob)
             assert np.array_equal(ctx.msm_g1(pts, sc), want_msm), on
+            assert np.array_equal(ctx.msm_g2(p2, s2), want_msm2), on
     finally:
         assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
