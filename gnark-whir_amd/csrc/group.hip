@@ -442,7 +442,7 @@ int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *d, mi_pk_sharded **out
             return c_auto;
         };
         plan[2] = choose(20, max_z, sizeof(G1Aff));
-        plan[1] = choose(18, max_b, sizeof(G1Aff) + sizeof(G2Aff));
+        plan[1] = choose(17, max_b, sizeof(G1Aff) + sizeof(G2Aff));
         plan[0] = choose(19, max_w, 2 * sizeof(G1Aff));
     }
     std::vector<int32_t> rcs(nl, MI_OK);

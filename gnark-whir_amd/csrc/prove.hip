@@ -92,7 +92,8 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
     };
     if (rc == MI_OK) rc = expand(&pk->a_full, pk->g1_a, pk->idx_a, pk->n_a);
     if (rc == MI_OK) rc = expand(&pk->k_full, pk->g1_k, pk->idx_k, pk->n_k);
-    // Fixed-base tables.  Measured at N = 2^23 with proofs overlapping: c = 19 / 18 / 20 for A+K / B / Z gives
+    // Fixed-base tables.  Measured at N = 2^23 with proofs overlapping: c = 19 / 17 / 20 for A+K / B / Z (round 2: B went
+    // from 18 to 17 when the G2 additions got 18 % cheaper and the 2^17-bucket G2 reduce weighed more: 30.2 vs 29.9 proofs/s) gives
     // +7 % proofs/s over the generic c = 16 path (13..15 windows instead of 16); wider windows lose it again to the bucket
     // reduce (2^(c-1) buckets, G2 first).  Automatic: a group gets tables when its MSM has >= 2^20 points and the tables of
     // the groups chosen so far fit in a third of the free device memory (smallest first: Z, B, A+K); the rest stays for the
@@ -111,7 +112,7 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
             return c_auto;
         };
         pk->c_z = choose(ctx->fixed_knob[2], 20, pk->n_z_msm, pk->n_z_msm * sizeof(G1Aff));
-        pk->c_b = choose(ctx->fixed_knob[1], 18, pk->n_b, pk->n_b * (sizeof(G1Aff) + sizeof(G2Aff)));
+        pk->c_b = choose(ctx->fixed_knob[1], 17, pk->n_b, pk->n_b * (sizeof(G1Aff) + sizeof(G2Aff)));
         pk->c_ak = choose(ctx->fixed_knob[0], 19, pk->nb_wires, pk->nb_wires * 2 * sizeof(G1Aff));
         auto pre = [&](void **dst, const void *base, size_t n, int curve, u32 c) -> int32_t {
             const size_t bytes = nwin_of(c) * n * (curve == 1 ? sizeof(G1Aff) : sizeof(G2Aff));
