@@ -13,6 +13,7 @@
 #include "ctx.h"
 #include "ntt_wave.cuh"
 #include <cstring>
+#include <cstdlib>
 
 struct NttState {
     u32 log_n = 0xffffffffu;
@@ -31,6 +32,7 @@ struct NttState {
     // defaults from the tools/tune.py sweep at N = 2^23: 2^9-element tiles (16 KiB of LDS, 8 workgroups of 256
     // threads per CU), radices 2^7 * 2^7 * 2^9: 1.46 ms per transform vs 1.99 ms for 2^11 tiles
     u32 log_e = 9, max_contig = 9, max_strided = 7, threads = 256;
+    u32 lds_floor = 0;     // bytes of LDS every pass workgroup requests at least: caps the workgroups per CU (0 = only what the tile needs)
     u32 plan_set = 0;      // the knobs above were set by the caller: no per-size defaults
     u32 wave_stages = 1;   // passes of radix >= 2^7 run their last / first seven stages in registers (k_ntt_pass_wave); 0 = all through LDS
 };
@@ -49,6 +51,7 @@ __global__ void k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t);
 void mi_ntt_state_init(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= sizeof(ctx->ntt_state), "NttState lives in ctx->ntt_state");
     new (ctx->ntt_state) NttState();
+    if (const char *e = getenv("MI_NTT_LDS_FLOOR_KB")) state_of(ctx)->lds_floor = (u32)atoi(e) * 1024u;
     (void)hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_pass_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -298,6 +301,7 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
         p.lds_pad = wave && p.log_s != 0 ? 1 : 0;
         u32 tiles = 1u << (log_n - p.log_r - p.log_c);
         size_t lds_bytes = (size_t)32 * ntt_plane_slots(p);
+        if (st->lds_floor > lds_bytes) lds_bytes = st->lds_floor;   // occupancy cap of the pass kernels (experiments: MI_NTT_LDS_FLOOR_KB)
         u32 E = 1u << (p.log_r + p.log_c);
         // one butterfly per thread per stage when the tile allows: 64 KiB of LDS admits two workgroups per CU,
         // so 1024-thread workgroups are what fills the SIMDs (8 waves each) and hides the mad->addc chains
