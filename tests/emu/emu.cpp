@@ -81,6 +81,32 @@ extern "C" int emu_g2_madd29_chain(void *out_aff, const void *pts_std, const uns
     *(G2Aff *)out_aff = xyzz_to_affine(s);
     return 0;
 }
+// raw primitives of field29.cuh on limb vectors chosen by the test (9 x u32 each); field 1 = Fp, 0 = Fr
+extern "C" int emu_f29_prim(int field, int op, u32 *out, const u32 *a, const u32 *b, const u32 *c, const u32 *d) {
+    F29 A, B, C, D, R;
+    memcpy(A.l, a, 36); memcpy(B.l, b, 36); memcpy(C.l, c, 36); memcpy(D.l, d, 36);
+    if (field == 1) {
+        switch (op) {
+        case 0: R = f29_mul<FpParams>(A, B); break;
+        case 1: R = f29_mul2<FpParams>(A, B, C, D); break;
+        case 2: R = f29_sub<FpParams>(A, B, P29<FpParams>::c8); break;
+        case 3: R = f29_sub<FpParams>(A, B, P29<FpParams>::c4); break;
+        case 4: R = f29_sub<FpParams>(A, B, P29<FpParams>::c2); break;
+        case 5: R = f29_wnorm(A); break;
+        case 6: R = f29_condsub(A, P29<FpParams>::p4); break;
+        case 7: R = f29_condsub(A, P29<FpParams>::p2); break;
+        default: return -1;
+        }
+    } else {
+        switch (op) {
+        case 0: R = f29_mul<FrParams>(A, B); break;
+        case 1: R = f29_mul2<FrParams>(A, B, C, D); break;
+        default: return -1;
+        }
+    }
+    memcpy(out, R.l, 36);
+    return 0;
+}
 extern "C" int emu_f29_roundtrip(void *out_std, const void *in_std, size_t n, int field) {   // std -> R' limbs -> std, and a product in both
     for (size_t i = 0; i < n; i++) {
         if (field == 1) {

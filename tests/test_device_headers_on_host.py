@@ -100,6 +100,57 @@ def test_limb29_field_roundtrip_and_product(emu):
         assert np.array_equal(out[1::2], cref.field_op(op_field, 2, X, Y))
 
 
+def test_limb29_primitives_at_their_documented_bounds(emu):
+    """field29.cuh primitives on limb vectors pushed to the edges of their contracts (limbs up to 2^30 / 2^31 - 1 where allowed,
+    values up to 8p x 8p), against Python big integers; the emu build traps on any 64-bit column overflow or limb underflow"""
+    M29 = (1 << 29) - 1
+    rng = np.random.default_rng(17)
+    def val(l):
+        return sum(int(x) << (29 * i) for i, x in enumerate(l))
+    def limbs_of(v):
+        return [(v >> (29 * i)) & M29 for i in range(8)] + [v >> 232]
+    def call(field, op, a, b=None, c=None, d=None):
+        z = [0] * 9
+        arrs = [np.array(x if x is not None else z, dtype=np.uint32) for x in (a, b, c, d)]
+        out = np.zeros(9, np.uint32)
+        assert emu.emu_f29_prim(field, op, _p(out), *[_p(x) for x in arrs]) == 0
+        return [int(x) for x in out]
+    for field, mod in ((1, P.Q_MOD), (0, P.R_MOD)):
+        Rinv = pow(1 << 261, -1, mod)
+        for trial in range(60):
+            # products: operands up to 8p, limbs up to 2^30 on one side (sum of two weak numbers)
+            x = int(rng.integers(0, 1 << 62)) * mod // (1 << 59) % (8 * mod); y = int(rng.integers(0, 1 << 62)) * mod // (1 << 59) % (8 * mod)
+            if trial < 8:
+                x, y = [(8 * mod - 1, 8 * mod - 1), (0, 5), (mod, mod), (8 * mod - 1, 1), ((1 << 257) - 1, (1 << 257) - 1), (1, 1), (mod - 1, mod + 1), (7 * mod + 12345, 3)][trial]
+            lx, ly = limbs_of(x), limbs_of(y)
+            if trial % 3 == 1:   # un-normalised: split x = u + v, add limb-wise (limbs up to 2^30)
+                u = x // 2; lx = [p_ + q_ for p_, q_ in zip(limbs_of(u), limbs_of(x - u))]
+            got = call(field, 0, lx, ly)
+            assert val(got) % mod == x * y * Rinv % mod and all(g <= M29 for g in got[:8]) and val(got) < (x * y // (1 << 261)) + mod + 1
+            # dual product
+            u_, v_ = (x * 7 + 3) % (8 * mod), (y * 5 + 1) % (8 * mod)
+            got = call(field, 1, limbs_of(x), limbs_of(y), limbs_of(u_), limbs_of(v_))
+            assert val(got) % mod == (x * y + u_ * v_) * Rinv % mod
+        if field == 1:
+            for K, op in ((8, 2), (4, 3), (2, 4)):
+                for trial in range(40):
+                    xv = int(rng.integers(0, 1 << 62)) * mod // (1 << 60) % (8 * mod)
+                    yv = int(rng.integers(0, 1 << 62)) * mod // (1 << 62) % (K * mod - (1 << 233))
+                    ly = limbs_of(yv)
+                    if trial % 2:   # weakly normalised subtrahend: limbs up to 2^29 + 7
+                        for i in range(8):
+                            if ly[i + 1] > 0 and ly[i] + (1 << 29) <= M29 + 8: ly[i + 1] -= 1; ly[i] += 1 << 29
+                    got = call(1, op, limbs_of(xv), ly)
+                    assert val(got) == xv + K * mod - val(ly) and all(g < (1 << 31) for g in got)
+                    wn = call(1, 5, got)
+                    assert val(wn) == val(got) and all(g <= M29 + 8 for g in wn[:8])
+            for K, op in ((4, 6), (2, 7)):
+                for v in [0, mod, K * mod - 1, K * mod, K * mod + (1 << 233), 2 * K * mod - 1, (K + 1) * mod, int(1.5 * K * mod)]:
+                    got = call(1, op, limbs_of(v))
+                    r = val(call(1, 5, got))
+                    assert r % mod == v % mod and r <= max(v - K * mod, K * mod + (1 << 233)) and r >= 0 and r < K * mod + (1 << 234)
+
+
 def test_limb29_mixed_addition_chain_matches_oracle(emu):
     """curve29.cuh: chains of mixed additions in 29-bit limbs (lazy bounds hand-tracked; the host build traps on any limb
     underflow or 64-bit column overflow) against the oracle's group law -- random chains with sign flips, the same point twice
