@@ -431,3 +431,16 @@ def test_limb29_level1_kernel_on_and_off_agree_with_oracle(ctx):
             assert np.array_equal(ctx.msm_g2(p2, s2), want_msm2), on
     finally:
         assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
+
+
+@pytest.mark.parametrize("g2,n", [(False, 65535), (False, 65536), (False, 65537), (False, 100003), (True, 16383), (True, 16384), (True, 16385), (True, 20011)])
+def test_msm_around_the_limb29_thresholds(ctx, g2, n):
+    """the public MSM entry points switch to the 29-bit level-1 kernels (bases converted into scratch) at 2^16 pairs (G1) and
+    2^14 (G2): sizes on both sides of the switch, with infinity / repeated / opposite points, against the oracle"""
+    sc = cref.gen_scalars(n, 3300 + n, 1)
+    if g2:
+        pts = cref.gen_g2(n, 3400 + n); pts[3] = 0; pts[6] = pts[5]; sc[6] = sc[5]; pts[8] = g2_arr([P.g2_neg(g2_pts(pts[7:8])[0])])[0]; sc[8] = sc[7]
+        assert np.array_equal(ctx.msm_g2(pts, sc), cref.msm_g2(pts, sc))
+    else:
+        pts = cref.gen_g1(n, 3400 + n); pts[3] = 0; pts[6] = pts[5]; sc[6] = sc[5]; pts[8] = g1_arr([P.g1_neg(g1_pts(pts[7:8])[0])])[0]; sc[8] = sc[7]
+        assert np.array_equal(ctx.msm_g1(pts, sc), cref.msm_g1(pts, sc))
