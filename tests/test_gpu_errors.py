@@ -59,3 +59,55 @@ def test_pool_rejects_second_waiter_and_unknown_ticket():
     assert p.lib.mi_prover_wait(p.h, C.c_uint64(12345)) != 0
     assert b"unknown ticket" in p.lib.mi_prover_last_error(p.h)
     p.close()
+
+
+def test_sharded_prove_and_pool_report_injected_failures_and_recover():
+    """fault injection through the multi-threaded paths: a group's sharded prove (one host thread per rank) and the prover pool's
+    upload stage + workers must turn an injected HIP failure into an error code -- no hang, no crash -- and work again afterwards"""
+    B = load_binding()
+    pk = synthetic_pk(12, 4000, 7, 199)
+    W = cref.gen_scalars(4000, 1, 1); a = cref.gen_scalars(4090, 2, 1); b = cref.gen_scalars(4090, 3, 0); cc = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, cc, r, s)["raw"])
+    g = B.Group([0, 0])
+    try:
+        spk = g.pk_load(pk)
+        assert B.proof_write(g.prove(spk, W, a, b, cc, r, s, mode=1)[0]["raw"]) == want
+        for nth in (1, 2, 5, 9, 17, 33, 70, 120):
+            for mode in (0, 1):
+                assert g.lib.mi_debug_inject_hip_failure(nth) == 0
+                try:
+                    failed = False
+                    try:
+                        g.prove(spk, W, a, b, cc, r, s, mode=mode)
+                    except B.MiError:
+                        failed = True
+                finally:
+                    g.lib.mi_debug_inject_hip_failure(0)
+                for i in range(g.n_local):
+                    g.ctx(i).sync()
+                got, _ = g.prove(spk, W, a, b, cc, r, s, mode=mode)      # whatever happened, the next proof is right
+                assert B.proof_write(got["raw"]) == want, (nth, mode, failed)
+        g.pk_free(spk)
+    finally:
+        g.close()
+    p = B.Prover(0, 2)
+    try:
+        c0 = p.ctx(0)
+        pkh = c0.pk_load(pk)
+        for nth in (1, 3, 8, 20, 50):
+            assert p.lib.mi_debug_inject_hip_failure(nth) == 0
+            tickets = [p.submit(pkh, W, a, b, cc, r, s) for _ in range(3)]
+            results = []
+            for t in tickets:
+                try:
+                    results.append(B.proof_write(p.wait(t)[0]["raw"]))
+                except B.MiError:
+                    results.append(None)
+            p.lib.mi_debug_inject_hip_failure(0)
+            assert all(x is None or x == want for x in results), nth     # a proof is either refused or right, never wrong
+            t = p.submit(pkh, W, a, b, cc, r, s)
+            assert B.proof_write(p.wait(t)[0]["raw"]) == want
+        c0.pk_free(pkh)
+    finally:
+        p.close()
