@@ -1,6 +1,6 @@
 """bench.py --gpus N --steps K --warmup W
 
-One step = one full Groth16 prove (computeH: 7 NTTs of size 2^23; 4 G1 MSMs + 1 G2 MSM; blinding and
+One step = one full Groth16 prove (computeH: gnark's 7 NTTs of size 2^23, done with 6; 4 G1 MSMs + 1 G2 MSM; blinding and
 assembly) of the synthetic WHIR-verifier-shaped workload of BASELINE.json configs[1] (2^20-variable
 multilinear -> FFT domain N = 2^23) with the proving key, the witness W and the
 solution vectors a, b, c already resident in HBM.  The K steps go through the prover pool (mi_prover_*: --in-flight
@@ -295,7 +295,7 @@ def main():
         solo = {"pairs": n_constraints, "scalars": "uniform", "msm_total_ms": st["total_ms"], "accum_launch_ms": st["g1_accum_kernel_ms"],
                 "accum_GBps_algorithmic": 96.0 * n_constraints / (st["g1_accum_kernel_ms"] * 1e-3) / 1e9,
                 "mixed_adds_per_s": st["g1_accum_entries"] / (st["g1_accum_kernel_ms"] * 1e-3), "msm_pts_per_s": n_constraints / (st["total_ms"] * 1e-3)}
-    # computeH alone on the GPU (7 transforms of size N + the pointwise step): the NTT's own roofline line
+    # computeH alone on the GPU (6 transforms of size N, the pointwise steps fused into the last one's edges): the NTT's own roofline line
     ntt_solo = None
     if rank == 0:
         hbuf = ctx.alloc(32 * N)
@@ -303,7 +303,7 @@ def main():
         ms_h = min((ctx.compute_h_dev(log_n, a.ptr, b.ptr, c.ptr, n_constraints, hbuf.ptr), ctx.stats()["compute_h_ms"])[1] for _ in range(3))
         launches = ctx.stats()["ntt_launches"]
         hbuf.free()
-        ntt_solo = {"compute_h_ms": ms_h, "transforms": 7, "pass_launches": launches, "ms_per_transform": ms_h / 7.0}
+        ntt_solo = {"compute_h_ms": ms_h, "transforms": 6, "pass_launches": launches, "ms_per_transform": ms_h / 6.0}
     # VALU context for the roofline line: the chip's measured 256-bit Montgomery product rate (dependent chains, all CUs)
     modmul_ms = min(ctx.bench_modmul(1, 256 * 4096, 256) for _ in range(3)) if rank == 0 else 0.0
     # ... and the memory system's ceiling for what that kernel asks of it: dependent random 64-byte gathers from a table far larger
@@ -330,8 +330,8 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")))
                 kname = "k_msm_accum_affine29"
                 traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
-                kn = "k_ntt_pass_wave"   # per pass launch; one transform = pass_launches / 7 launches
-                traffic_ntt = (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0 * ntt_solo["pass_launches"] / 7.0
+                kn = "k_ntt_pass_wave"   # per pass launch; one transform = pass_launches / 6 launches
+                traffic_ntt = (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0 * ntt_solo["pass_launches"] / 6.0
             except Exception:
                 traffic = traffic_ntt = None
         line = {
@@ -362,7 +362,7 @@ def main():
                          "traffic_source": "profiles/r02_pmc_bench_traffic.json (committed PMC passes of this workload, not this run)",
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
-            # time = computeH alone on the GPU / 7 transforms (the pointwise kernel, 0.1 ms, is inside: counted as fused)
+            # time = computeH alone on the GPU / its 6 transforms (gnark's 7th, the coset FFT of c, is never needed: DESIGN.md 4)
             "roofline_ntt": {"kernel": "k_ntt_pass_wave (all passes of one size-N transform)", "bound": "hbm",
                              "achieved": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9 / 8000.0, "traffic": traffic_ntt,

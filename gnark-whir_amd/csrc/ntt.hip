@@ -21,6 +21,7 @@ struct NttState {
     Fr *tw_lo_f = nullptr, *tw_hi_f = nullptr, *tw_lo_i = nullptr, *tw_hi_i = nullptr;
     Fr *g_lo = nullptr, *g_hi = nullptr, *gi_lo = nullptr, *gi_hi = nullptr, *ninv = nullptr;
     Fr *g_hi_n = nullptr, *gi_hi_nd = nullptr;   // computeH-internal: g^(j 2^h) / N  and  g^-(j 2^h) / N * den
+    Fr *ninv_den = nullptr;                      // computeH-internal: den / N
     u32 tw_h = 0;
     // computeH's direct factor tables in the data's layout (NttPass::tw_direct / sc_direct), N entries each, built for one
     // (log_n, first radix): twiddles of the M = N pass for the inverse and the forward root, coset shifts g^bitrev(i) / N and
@@ -58,7 +59,7 @@ void mi_ntt_state_init(mi_ctx *ctx) {
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
     Fr **all[] = {&st->small_f, &st->small_i, &st->tw64k_f, &st->tw64k_i, &st->g_hi_n, &st->gi_hi_nd, &st->tw_lo_f, &st->tw_hi_f, &st->tw_lo_i, &st->tw_hi_i,
-                  &st->g_lo, &st->g_hi, &st->gi_lo, &st->gi_hi, &st->ninv, &st->d_tw_inv, &st->d_tw_fwd, &st->d_sc_fwd, &st->d_sc_inv};
+                  &st->g_lo, &st->g_hi, &st->gi_lo, &st->gi_hi, &st->ninv, &st->ninv_den, &st->d_tw_inv, &st->d_tw_fwd, &st->d_sc_fwd, &st->d_sc_inv};
     for (Fr **p : all) if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
@@ -149,13 +150,6 @@ __global__ void k_sc_layout(Fr *out, u32 log_n, Fr base, Fr c) {     // out[i] =
     out[i] = acc;
 }
 
-// a[i] = a[i]*b[i] - c[i]      (computeH's pointwise step; its den factor is folded into the last transform)
-__global__ void k_h_pointwise(Fr *a, const Fr *b, const Fr *c, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    a[i] = a[i] * b[i] - c[i];
-}
-
 static Fr host_fr_from_u64x4(u64 a, u64 b, u64 c, u64 d) {
     Fr t;
     t.l[0] = (u32)a; t.l[1] = (u32)(a >> 32); t.l[2] = (u32)b; t.l[3] = (u32)(b >> 32);
@@ -211,6 +205,7 @@ static int32_t ensure_tables(mi_ctx *ctx, u32 log_n) {
     Fr den = fe_inv(gn - Fr::one());
     MI_TRY(build_table(ctx, &st->g_hi_n, nhi, g, ninv, h));
     MI_TRY(build_table(ctx, &st->gi_hi_nd, nhi, gi, ninv * den, h));
+    MI_TRY(build_table(ctx, &st->ninv_den, 1, Fr::one(), ninv * den, 0));
     st->log_n = log_n;
     return MI_OK;
 }
@@ -254,8 +249,11 @@ static int32_t ensure_direct(mi_ctx *ctx, u32 log_n) {
 
 // One transform of size 2^log_n: dst <- NTT(src[0..n_valid) zero padded).  dst == src allowed.
 // variant (computeH only): 1 = inverse without the 1/N scaling; 2 = forward coset with 1/N folded into the shift tables;
-// 3 = inverse coset with den folded into its scaling.  0 = exactly fft.Domain's FFT / FFTInverse.
-static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log_n, u32 flags, u32 variant = 0) {
+// 3 = inverse coset with den folded into its scaling; 4 = inverse scaled by den / N.  0 = exactly fft.Domain's FFT / FFTInverse.
+// load_mul / store_sub (computeH only, see NttPass): pointwise factor on the way into the first pass / pointwise subtrahend on the
+// way out of the last.
+static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log_n, u32 flags, u32 variant = 0,
+                       const Fr *load_mul = nullptr, const Fr *store_sub = nullptr) {
     NttState *st = state_of(ctx);
     MI_TRY(ensure_tables(ctx, log_n));
     const bool inverse = flags & MI_NTT_INVERSE, coset = flags & MI_NTT_COSET, dit = flags & MI_NTT_DIT;
@@ -268,7 +266,8 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
     u32 load_scale = 0, store_scale = 0;
     if (coset && !inverse) { t.sc_lo = st->g_lo; t.sc_hi = variant == 2 ? st->g_hi_n : st->g_hi; load_scale = dit ? 1 : 2; }
     else if (coset && inverse) { t.sc_lo = st->gi_lo; t.sc_hi = variant == 3 ? st->gi_hi_nd : st->gi_hi; store_scale = dit ? 4 : 3; }
-    else if (inverse && variant != 1) { t.sc_lo = st->ninv; t.sc_hi = st->ninv; store_scale = 5; }
+    else if (inverse && variant != 1) { t.sc_lo = t.sc_hi = variant == 4 ? st->ninv_den : st->ninv; store_scale = 5; }
+    if (load_mul && (load_scale || dit)) MI_FAIL(ctx, MI_EINVAL, "internal: load_mul on a pass whose load side already has a factor");
 
     const NttKnobs kn = knobs_for(st, log_n);
     NttPlan pl = ntt_make_plan(log_n, kn.max_contig, kn.max_strided);
@@ -292,6 +291,8 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
             p.scale = store_scale;
         }
         p.n_valid = step == 0 ? n_valid : (1u << log_n);
+        if (step == 0) p.load_mul = load_mul;
+        if (step == pl.n_pass - 1) p.store_sub = store_sub;
         // computeH's direct tables (variant != 0 only): the twiddle of the M = N pass, the coset shift of the contiguous pass
         const bool direct = variant != 0 && st->d_log_n == log_n && st->d_sc_fwd;
         if (direct && p.twiddle && i == 0 && pl.n_pass > 1) p.tw_direct = inverse ? st->d_tw_inv : st->d_tw_fwd;
@@ -327,20 +328,21 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
     MI_TRY(mi_reserve(ctx, ctx->ws[0], n * sizeof(Fr)));
     MI_TRY(mi_reserve(ctx, ctx->ws[1], n * sizeof(Fr)));
     Fr *A = (Fr *)h_out, *B = (Fr *)ctx->ws[0].p, *C = (Fr *)ctx->ws[1].p;
-    // 1. a,b,c <- FFTInverse(., DIF)  (zero padding fused into the first pass's load)
-    //    (their 1/N is applied by the coset shift of step 2 instead: same values, one product per element less)
+    // gnark's computeH (7 transforms): a, b, c <- FFTInverse; a, b, c <- FFT on the coset; a <- (a b - c) den; h <- FFTInverse on
+    // the coset.  The last transform is linear and undoes the coset FFT of c exactly:
+    //     h = cosetFFTInverse((ca cb - cc) den) = den cosetFFTInverse(ca cb) - den FFTInverse(c),
+    // so the coset FFT of c is never computed -- SIX transforms, the same field elements (exact arithmetic), for ANY a, b, c.
+    // 1. a, b <- N FFTInverse(., DIF) (zero padding fused into the first pass's load; the 1/N rides in step 2's coset shift);
+    //    c <- den FFTInverse(c, DIF) (one constant den / N on the way out), bit-reversed like h
     MI_TRY(ntt_run(ctx, A, (const Fr *)a, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
     MI_TRY(ntt_run(ctx, B, (const Fr *)b, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
-    MI_TRY(ntt_run(ctx, C, (const Fr *)c, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
-    // 2. a,b,c <- FFT(., DIT, OnCoset)
+    MI_TRY(ntt_run(ctx, C, (const Fr *)c, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4));
+    // 2. a, b <- FFT(., DIT, OnCoset)
     MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2));
     MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2));
-    MI_TRY(ntt_run(ctx, C, C, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2));
-    // 3. a <- a*b - c          (the factor den = 1/(g^n - 1) rides in the scaling of step 4)
-    hipLaunchKernelGGL(k_h_pointwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, A, B, C, n);
-    MI_CHECK_HIP(ctx, hipGetLastError());
-    // 4. h <- FFTInverse(a, DIF, OnCoset) * den, left bit-reversed like gnark
-    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3));
+    // 3. h <- den FFTInverse(a b, DIF, OnCoset) - c, left bit-reversed like gnark: the product a b is taken on the way into the
+    //    first pass, the subtraction on the way out of the last (no pointwise kernel, no extra round trip through HBM)
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C));
     return MI_OK;
 }
 

@@ -53,6 +53,11 @@ struct NttPass {
     // One product per element instead of two, for 32 B of extra traffic per element on a VALU-bound pass.
     const Fr *tw_direct;
     const Fr *sc_direct;
+    // computeH's two pointwise steps, fused into the edges of its last transform (both in the data's layout, or null):
+    // load_mul: every element is multiplied by load_mul[g] on its way in (only on a pass whose load side has no other factor);
+    // store_sub: store_sub[g] is subtracted from every element on its way out, after the scaling
+    const Fr *load_mul;
+    const Fr *store_sub;
 };
 
 MI_HD u32 bitrev_u32(u32 x, u32 bits) {
@@ -117,6 +122,9 @@ MI_HD bool ntt_edge_factor(const NttPass &p, const NttTables &t, u32 rho, u64 g,
         if (t.tw_64k && log_m <= 16) { f = t.tw_64k[x << (16 - log_m)]; return true; }   // w_M^x = w_65536^(x * 65536/M)
         e = x << (p.log_n - log_m);
         lo = t.tw_lo; hi = t.tw_hi;
+    } else if (phase == 0 && p.load_mul) {
+        f = p.load_mul[g];
+        return true;
     } else {
         return false;
     }
@@ -178,6 +186,7 @@ MI_HD void ntt_tile_store(const NttPass &p, const NttTables &t, Fr *data, u64 ti
         u64 g = ntt_global_index(p, tile, rho, col);
         Fr v = lds_get(lds, ntt_plane_slots(p), ntt_lds_slot(p, rho, col)), f;
         if (ntt_edge_factor(p, t, rho, g, 1, f)) v = v * f;
+        if (p.store_sub) v = v - p.store_sub[g];
         data[g] = v;
     }
 }

@@ -133,8 +133,9 @@ static Fr fr_from_u64x4(u64 a, u64 b, u64 c, u64 d) {
     t.l[4] = (u32)c; t.l[5] = (u32)(c >> 32); t.l[6] = (u32)d; t.l[7] = (u32)(d >> 32);
     return fe_to_mont(t);
 }
-extern "C" int emu_ntt(void *data_v, uint32_t log_n, uint32_t flags, uint32_t log_e, uint32_t max_contig, uint32_t max_strided,
-                       uint32_t nthr, uint32_t n_valid) {
+// load_mul / store_sub: computeH's fused pointwise steps (NttPass), or null
+extern "C" int emu_ntt_fused(void *data_v, uint32_t log_n, uint32_t flags, uint32_t log_e, uint32_t max_contig, uint32_t max_strided,
+                             uint32_t nthr, uint32_t n_valid, const void *load_mul, const void *store_sub) {
     Fr *data = (Fr *)data_v;
     const bool inverse = flags & 1, coset = flags & 2, dit = flags & 4;
     Fr root = fr_from_u64x4(0x9bd61b6e725b19f0ull, 0x402d111e41112ed4ull, 0x00e0a7eb8ef62abcull, 0x2a3c09f0a58a7e85ull);
@@ -176,6 +177,8 @@ extern "C" int emu_ntt(void *data_v, uint32_t log_n, uint32_t flags, uint32_t lo
         if (step == 0 && load_scale) p.scale = load_scale;
         if (step == pl.n_pass - 1 && store_scale) { if (p.scale) return -1; p.scale = store_scale; }
         p.n_valid = step == 0 ? n_valid : (1u << log_n);
+        if (step == 0) p.load_mul = (const Fr *)load_mul;
+        if (step == pl.n_pass - 1) p.store_sub = (const Fr *)store_sub;
         u32 tiles = 1u << (log_n - p.log_r - p.log_c);
         std::vector<U4> lds((size_t)2 << (p.log_r + p.log_c));
         for (u32 tile = 0; tile < tiles; tile++) {
@@ -186,6 +189,10 @@ extern "C" int emu_ntt(void *data_v, uint32_t log_n, uint32_t flags, uint32_t lo
         }
     }
     return (int)pl.n_pass;
+}
+extern "C" int emu_ntt(void *data_v, uint32_t log_n, uint32_t flags, uint32_t log_e, uint32_t max_contig, uint32_t max_strided,
+                       uint32_t nthr, uint32_t n_valid) {
+    return emu_ntt_fused(data_v, log_n, flags, log_e, max_contig, max_strided, nthr, n_valid, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------- MSM pipeline emulation (msm_core.cuh on the host)

@@ -257,6 +257,34 @@ def test_ntt_fused_zero_padding(emu):
     assert np.array_equal(got, cref.ntt(padded, log_n, 1))
 
 
+@pytest.mark.parametrize("log_n,log_e,mc,ms", [(4, 11, 11, 8), (9, 5, 4, 3), (10, 6, 3, 3)])
+def test_ntt_fused_pointwise_edges(emu, log_n, log_e, mc, ms):
+    """NttPass::load_mul / store_sub (computeH's last transform): FFTInverse on the coset of x * m, minus s, in one transform"""
+    n = 1 << log_n
+    x, m, s = (cref.gen_scalars(n, 7 + k, 0) for k in range(3))
+    got = x.copy()
+    emu.emu_ntt_fused(_p(got), log_n, 3, log_e, mc, ms, 64, n, _p(m), _p(s))
+    assert np.array_equal(got, cref.field_op(0, 1, cref.ntt(cref.field_op(0, 2, x, m), log_n, 3), s))
+
+
+@pytest.mark.parametrize("log_n,n_constraints", [(3, 8), (8, 200), (12, 4000)])
+def test_compute_h_needs_six_transforms(log_n, n_constraints):
+    """The identity the device's computeH rests on, with the oracle's own transforms: the coset FFT of c is undone by the last
+    (linear) transform, so  h = den * FFTInverse_coset(ca * cb) - den * FFTInverse(c)  for ANY a, b, c (c is NOT a * b here)."""
+    n = 1 << log_n
+    a, b, c = (cref.gen_scalars(n_constraints, 40 + k, k % 2) for k in range(3))
+    pad = lambda v: np.concatenate([v, np.zeros((n - len(v), 4), np.uint64)])
+    want = cref.compute_h(log_n, a, b, c)
+    ia, ib, ic = (cref.ntt(pad(v), log_n, 1) for v in (a, b, c))
+    ca, cb = cref.ntt(ia, log_n, 2 | 4), cref.ntt(ib, log_n, 2 | 4)
+    r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+    den = pow(pow(5, n, r) - 1, -1, r)
+    den_m = np.tile(np.array([[(den * (1 << 256) % r) >> (64 * k) & (2 ** 64 - 1) for k in range(4)]], np.uint64), (n, 1))
+    x = cref.ntt(cref.field_op(0, 2, ca, cb), log_n, 1 | 2)
+    got = cref.field_op(0, 1, cref.field_op(0, 2, x, den_m), cref.field_op(0, 2, ic, den_m))
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("n,dist,c,G,L,seg", [(1, 0, 4, 1, 4, 2), (2, 1, 3, 2, 2, 3), (37, 0, 5, 3, 4, 4), (300, 1, 4, 4, 3, 2),
                                               (300, 0, 8, 2, 32, 16), (1000, 1, 16, 3, 8, 64), (257, 1, 7, 5, 2, 8)])
 def test_msm_pipeline_matches_oracle(emu, n, dist, c, G, L, seg):
