@@ -60,7 +60,7 @@ MI_HD void g1x29_madd(G1X29 &acc, const u32 *q, bool negate) {
     const F29 S2 = f29_mul<P>(y2, acc.zzz);
     const F29 Pp = f29_wnorm(f29_sub<P>(U2, acc.x, P29<P>::c8));
     const F29 R = f29_wnorm(f29_sub<P>(S2, acc.y, P29<P>::c8));
-    const F29 PP = f29_mul<P>(Pp, Pp);
+    const F29 PP = f29_sqr<P>(Pp);
     // P = 0 mod p (same x: doubling or cancellation)  <=>  PP in {0, p}; PP is normalised, so its limbs decide.  Rare: the
     // standard arithmetic handles it.
     if (PP.l[0] == 0 || PP.l[0] == P29<P>::p[0]) {
@@ -78,7 +78,7 @@ MI_HD void g1x29_madd(G1X29 &acc, const u32 *q, bool negate) {
     const F29 PPP = f29_mul<P>(Pp, PP);
     const F29 Q = f29_mul<P>(acc.x, PP);
     const F29 T = f29_wnorm(f29_add(f29_add(PPP, Q), Q));
-    const F29 RR = f29_mul<P>(R, R);
+    const F29 RR = f29_sqr<P>(R);
     const F29 X3 = f29_wnorm(f29_sub<P>(RR, T, P29<P>::c4));
     const F29 D = f29_wnorm(f29_sub<P>(Q, X3, P29<P>::c8));
     const F29 nY = f29_wnorm(f29_sub<P>(f29_zero(), acc.y, P29<P>::c8));

@@ -45,13 +45,33 @@ MI_HD F29 f29_const(const u32 (&c)[9]) { F29 z;
     for (int i = 0; i < 9; i++) z.l[i] = c[i];
     return z; }
 
-// column accumulate with overflow detection in the checked host build
+// Column accumulate.  On the device every multiply-accumulate is an OPAQUE v_mad_u64_u32 into the one column accumulator.  Left to
+// itself the compiler starts a fresh accumulator per column and joins it to the shifted carry with a 64-bit add (v_lshl_add_u64:
+// 17 per product at ~4.7 cycles each, against ~5 for the multiply itself -- tools/bench_valu/instr_rate.hip); the chain form measures
+// 162 -> 180 G products/s at three waves per SIMD (tools/bench_valu/mul29_variants.hip) and 12.8 -> 13.7 G mixed additions/s in the
+// level-1 accumulate kernel.  One asm statement per multiply (the compiler pads each with an s_nop it does not need, but stays free
+// to interleave independent products; whole columns as single asm blocks measured 7 % SLOWER).  The host build (tests) is plain C
+// with overflow detection under MI_CHECK_NOWRAP.
 MI_HD void f29_mac(u64 &acc, u32 a, u32 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 carry_out;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry_out) : "v"(a), "v"(b));
+#else
     const u64 p = (u64)a * b;
-#if !defined(__HIP_DEVICE_COMPILE__) && defined(MI_CHECK_NOWRAP)
+#if defined(MI_CHECK_NOWRAP)
     if (acc + p < acc) __builtin_trap();
 #endif
     acc += p;
+#endif
+}
+// the same with a wave-uniform constant as the second factor (a limb of p): it stays in a scalar register
+MI_HD void f29_mac_k(u64 &acc, u32 a, u32 k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 carry_out;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry_out) : "v"(a), "s"(k));
+#else
+    f29_mac(acc, a, k);
+#endif
 }
 
 // x * y / 2^261 mod p, product scanning; no carry words (see the header)
@@ -66,9 +86,9 @@ MI_HD F29 f29_mul(const F29 &x, const F29 &y) {
 #pragma unroll
         for (int i = 0; i <= k; i++) f29_mac(acc, x.l[i], y.l[k - i]);
 #pragma unroll
-        for (int i = 0; i < k; i++) f29_mac(acc, m[i], P29<P>::p[k - i]);
+        for (int i = 0; i < k; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
         m[k] = ((u32)acc * P29<P>::inv) & M;
-        f29_mac(acc, m[k], P29<P>::p[0]);
+        f29_mac_k(acc, m[k], P29<P>::p[0]);
         acc >>= 29;
     }
 #pragma unroll
@@ -76,8 +96,42 @@ MI_HD F29 f29_mul(const F29 &x, const F29 &y) {
 #pragma unroll
         for (int i = k - 8; i < 9; i++) f29_mac(acc, x.l[i], y.l[k - i]);
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) f29_mac(acc, m[i], P29<P>::p[k - i]);
+        for (int i = k - 8; i < 9; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
         r.l[k - 9] = (u32)acc & M;
+        acc >>= 29;
+    }
+    F29_ASSERT(acc < ((u64)1 << 29));
+    r.l[8] = (u32)acc;
+    return r;
+}
+// x^2 / 2^261 mod p: 45 products x_i (2 x_j) instead of 81; same contract as f29_mul(x, x) (2 L(x) <= 60)
+template <class P>
+MI_HD F29 f29_sqr(const F29 &x) {
+    constexpr u32 M = (1u << 29) - 1;
+    u32 m[9], d[9];
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { d[i] = x.l[i] << 1; F29_ASSERT(x.l[i] < (1u << 31)); }
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        const int lo = k < 9 ? 0 : k - 8, hi = k < 9 ? k : 8;
+#pragma unroll
+        for (int i = lo; i <= hi; i++) {
+            const int j = k - i;
+            if (i < j) f29_mac(acc, d[i], x.l[j]);
+            else if (i == j) f29_mac(acc, x.l[i], x.l[i]);
+        }
+        if (k < 9) {
+#pragma unroll
+            for (int i = 0; i < k; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
+            m[k] = ((u32)acc * P29<P>::inv) & M;
+            f29_mac_k(acc, m[k], P29<P>::p[0]);
+        } else {
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
+            r.l[k - 9] = (u32)acc & M;
+        }
         acc >>= 29;
     }
     F29_ASSERT(acc < ((u64)1 << 29));
@@ -96,9 +150,9 @@ MI_HD F29 f29_mul2(const F29 &a, const F29 &b, const F29 &c, const F29 &d) {
 #pragma unroll
         for (int i = 0; i <= k; i++) { f29_mac(acc, a.l[i], b.l[k - i]); f29_mac(acc, c.l[i], d.l[k - i]); }
 #pragma unroll
-        for (int i = 0; i < k; i++) f29_mac(acc, m[i], P29<P>::p[k - i]);
+        for (int i = 0; i < k; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
         m[k] = ((u32)acc * P29<P>::inv) & M;
-        f29_mac(acc, m[k], P29<P>::p[0]);
+        f29_mac_k(acc, m[k], P29<P>::p[0]);
         acc >>= 29;
     }
 #pragma unroll
@@ -106,7 +160,7 @@ MI_HD F29 f29_mul2(const F29 &a, const F29 &b, const F29 &c, const F29 &d) {
 #pragma unroll
         for (int i = k - 8; i < 9; i++) { f29_mac(acc, a.l[i], b.l[k - i]); f29_mac(acc, c.l[i], d.l[k - i]); }
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) f29_mac(acc, m[i], P29<P>::p[k - i]);
+        for (int i = k - 8; i < 9; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
         r.l[k - 9] = (u32)acc & M;
         acc >>= 29;
     }

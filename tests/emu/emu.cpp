@@ -95,6 +95,7 @@ extern "C" int emu_f29_prim(int field, int op, u32 *out, const u32 *a, const u32
         case 5: R = f29_wnorm(A); break;
         case 6: R = f29_condsub(A, P29<FpParams>::p4); break;
         case 7: R = f29_condsub(A, P29<FpParams>::p2); break;
+        case 8: R = f29_sqr<FpParams>(A); break;
         default: return -1;
         }
     } else {

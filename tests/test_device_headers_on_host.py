@@ -127,6 +127,8 @@ def test_limb29_primitives_at_their_documented_bounds(emu):
                 u = x // 2; lx = [p_ + q_ for p_, q_ in zip(limbs_of(u), limbs_of(x - u))]
             got = call(field, 0, lx, ly)
             assert val(got) % mod == x * y * Rinv % mod and all(g <= M29 for g in got[:8]) and val(got) < (x * y // (1 << 261)) + mod + 1
+            if field == 1:   # the 45-product square: the same limbs as the product with itself
+                assert call(1, 8, lx) == call(1, 0, lx, lx)
             # dual product
             u_, v_ = (x * 7 + 3) % (8 * mod), (y * 5 + 1) % (8 * mod)
             got = call(field, 1, limbs_of(x), limbs_of(y), limbs_of(u_), limbs_of(v_))

@@ -45,9 +45,9 @@ def round_(X, Y, ZZ, ZZZ):
     x2 = B(1, 29, "x2"); y2 = B(1, 29, "y2")
     U2 = mul(x2, ZZ, "U2"); S2 = mul(y2, ZZZ, "S2")
     P = wnorm(sub(U2, X, 8, "P")); R = wnorm(sub(S2, Y, 8, "R"))
-    PP = mul(P, P, "PP"); PPP = mul(P, PP, "PPP"); Q = mul(X, PP, "Q")
+    PP = mul(P, P, "PP (f29_sqr: same columns as the product)"); PPP = mul(P, PP, "PPP"); Q = mul(X, PP, "Q")
     T = wnorm(add(add(PPP, Q, "T"), Q, "T"))
-    RR = mul(R, R, "RR")
+    RR = mul(R, R, "RR (f29_sqr)")
     X3 = wnorm(sub(RR, T, 4, "X3"))
     D = wnorm(sub(Q, X3, 8, "D"))
     nY = wnorm(sub(B(0, 0, "0"), Y, 8, "nY"))
