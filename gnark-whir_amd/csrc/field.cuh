@@ -275,7 +275,7 @@ MI_HD void mac96_first(u64 &acc, u32 a, u32 b) {
 
 // Montgomery product x*y/R mod p: product scanning (column-wise, "FIPS") over 32-bit limbs with a
 // 96-bit accumulator.  Column k collects x_i*y_(k-i) and m_i*p_(k-i); m_k makes the column's low word 0.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_MONT_PER_MAC)
 #include "mont_cols.inc"   // generated: one asm block per column (tools/gen_mont_cols.py)
 #define MI_MONT_LO(k)                                   \
     mont_col##k<P>(acc, c, x, y, m);                    \
@@ -339,7 +339,7 @@ MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
 // (x*y + u*v) / R mod p with ONE Montgomery reduction ("lazy reduction" of a sum of two products): 128 + 72 mads instead
 // of 2 * 136.  Inputs may be <= p (a raw p - a is accepted as the negation of a), the result is canonical.
 // Bound: (xy + uv + mp) / R < (2p^2 + Rp) / R < 2p because 2p < R.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MI_MONT_PER_MAC)
 #define MI_MONT2_LO(k)                                  \
     mont2_col##k<P>(acc, c, x, y, u, v, m);             \
     m[k] = (u32)acc * P::inv;                           \

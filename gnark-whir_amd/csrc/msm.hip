@@ -22,6 +22,7 @@
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
     u32 no_rprime = 0;                          // 1: G1 level 1 stays on the 8 x 32-bit kernel everywhere (tests compare both)
+    u32 std_partials = 0;                       // 1: partial sums between the levels in the standard form even after a 29-bit level 1
     u32 one_pass_sort = 0;                      // 1: large generic MSMs keep the one-pass counting sort (tests compare both)
     u32 chunk = 0;                              // fixed-base sort: entries per pass-2 chunk (tests shrink it)
     u32 gbits = 0;                              // fixed-base sort: log2 buckets per pass-1 group (0 = automatic)
@@ -348,6 +349,9 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
     u64 m = max_count;  // bound on entries of the largest key at this level
     u32 L = L_first;
     const u32 scan_blocks = (nkeys + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    // partial sums between the levels in the packed R' form (curve29.cuh) when level 1 runs in 29-bit limbs and the curve has the
+    // matching upper-level kernel
+    const bool rp_partials = pts && rprime && ops.accum_affine_rp && ops.accum_xyzz_rp && !knobs_of(ctx)->std_partials;
     MI_TRY(exclusive_scan(ctx, st, cur.items, nkeys, cur.item_start, sl.buf[B_SCAN]));
     for (u32 level = 0;; level++) {
         DevBuf &pout_buf = sl.buf[(level & 1) ? B_PART1 : B_PART0];
@@ -364,8 +368,9 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
         if (level == 0 && pts && rprime && ops.accum_affine_rp) {
             MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
-            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p);
+            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p, rp_partials ? 1u : 0u);
         } else if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
+        else if (rp_partials) ops.accum_xyzz_rp(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         MI_CHECK_HIP(ctx, hipGetLastError());
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], st));
@@ -709,8 +714,9 @@ int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_f
     return msm_fixed_dev_entry<Fp2>(ctx, 2, pre_dev, scalars_dev, n, c, flags, out);
 }
 int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on) {
-    if (!ctx || on > 1) return MI_EINVAL;
+    if (!ctx || on > 2) return MI_EINVAL;
     knobs_of(ctx)->no_rprime = on ? 0 : 1;
+    knobs_of(ctx)->std_partials = on == 2 ? 1 : 0;
     return MI_OK;
 }
 int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on) {

@@ -8,7 +8,7 @@
 // lazy additions), the item's sum converted back to the standard XYZZ once at its end.  +13..16 % mixed additions per second
 // (tools/bench_limb29/madd29.hip: 13.1 against 11.3 G/s on L2-resident points, conversions included).
 __global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
-                                                           G1X *bucket, G1X *partial_out) {
+                                                           G1X *bucket, G1X *partial_out, u32 rp_partials) {
     const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
     for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
         const uint4 rec = tab[item];
@@ -29,15 +29,37 @@ __global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, 
             }
             g1x29_madd(acc, w, neg);
         }
-        const G1X out = g1x29_to_std(acc);
-        if (rec.w) bucket[key] = out; else partial_out[item] = out;
+        // a bucket's only item leaves in the standard form (what the bucket reduce reads); a partial sum stays in the R' form for
+        // the next level (k_msm_accum_xyzz29) -- a pack instead of four conversion products
+        if (rec.w) bucket[key] = g1x29_to_std(acc);
+        else if (rp_partials) g1x29_store_rp(acc, reinterpret_cast<u32 *>(partial_out + item));
+        else partial_out[item] = g1x29_to_std(acc);
     }
 }
+// Levels >= 2 of the item machinery over partial sums in the packed R' form: k_msm_accum_xyzz's decomposition, the additions in
+// nine 29-bit limbs (g1x29_add), no conversion on the way in, one on the way out only for a bucket's final sum.
+__global__ void __launch_bounds__(64, 3) k_msm_accum_xyzz29(const G1X *partial_in, const u32 *start, const u32 *cnt, const u32 *items, const u32 *item_start,
+                                                         u32 nkeys, G1X *bucket, G1X *partial_out) {
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+        const u32 key = msm_item_key(item_start, nkeys, item);
+        u32 b, e;
+        msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
+        G1X29 acc = g1x29_load_rp(reinterpret_cast<const u32 *>(partial_in + b));
+        for (u32 k = b + 1; k < e; k++) g1x29_add(acc, g1x29_load_rp(reinterpret_cast<const u32 *>(partial_in + k)));
+        if (items[key] == 1) bucket[key] = g1x29_to_std(acc);
+        else g1x29_store_rp(acc, reinterpret_cast<u32 *>(partial_out + item));
+    }
+}
+static void launch_accum_xyzz29(hipStream_t st, unsigned grid, const void *pin, const u32 *start, const u32 *cnt, const u32 *items, const u32 *item_start,
+                                u32 nkeys, u32 L, void *bucket, void *pout) {
+    hipLaunchKernelGGL(k_msm_accum_xyzz29, dim3(grid), dim3(64), 0, st, (const G1X *)pin, start, cnt, items, item_start, nkeys, (G1X *)bucket, (G1X *)pout);
+}
 static void launch_accum_affine29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
-                                  const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab) {
+                                  const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab, u32 rp_partials) {
     hipLaunchKernelGGL(k_msm_item_table<Fp>, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
     hipLaunchKernelGGL(k_msm_accum_affine29, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
-                       (G1X *)bucket, (G1X *)pout);
+                       (G1X *)bucket, (G1X *)pout, rp_partials);
 }
 __global__ void k_g1_to_rprime(G1Aff *dst, const G1Aff *src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,6 +72,6 @@ static void launch_to_rprime(hipStream_t st, void *dst, const void *src, size_t 
 }
 
 const MsmCurveOps &msm_g1_ops() {
-    static const MsmCurveOps ops = {sizeof(G1X), launch_accum_affine<Fp>, launch_accum_xyzz<Fp>, launch_bucket_reduce<Fp>, SumT<Fp>::value, launch_sum_tree<Fp>, launch_precompute<Fp>, host_combine_windows<Fp>, launch_sum_slices<Fp>, launch_accum_affine29, launch_to_rprime};
+    static const MsmCurveOps ops = {sizeof(G1X), launch_accum_affine<Fp>, launch_accum_xyzz<Fp>, launch_bucket_reduce<Fp>, SumT<Fp>::value, launch_sum_tree<Fp>, launch_precompute<Fp>, host_combine_windows<Fp>, launch_sum_slices<Fp>, launch_accum_affine29, launch_accum_xyzz29, launch_to_rprime};
     return ops;
 }

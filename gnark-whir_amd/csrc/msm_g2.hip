@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64, 2) k_msm_accum_affine_g2_29(const G2Aff *p
     }
 }
 static void launch_accum_affine_g2_29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
-                                      const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab) {
+                                      const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab, u32 /* rp_partials: G2 keeps the standard form */) {
     hipLaunchKernelGGL(k_msm_item_table<Fp2>, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
     hipLaunchKernelGGL(k_msm_accum_affine_g2_29, dim3(grid), dim3(64), 0, st, (const G2Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
                        (G2X *)bucket, (G2X *)pout);
@@ -124,6 +124,6 @@ static void launch_g2_to_rprime(hipStream_t st, void *dst, const void *src, size
 }
 
 const MsmCurveOps &msm_g2_ops() {
-    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, launch_g2_to_rprime};
+    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, nullptr, launch_g2_to_rprime};
     return ops;
 }

@@ -348,7 +348,8 @@ int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, 
 /* 1: generic MSMs of >= 2^18 pairs keep the one-pass counting sort instead of the LDS-staged two-pass one (parity tests run both) */
 int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on);
 /* on = 1 (default): the G1 level-1 bucket accumulation runs in nine 29-bit limbs (keys loaded afterwards keep their G1 points in
- * the matching packed form); 0: the 8 x 32-bit kernel everywhere.  Set before mi_pk_load; parity tests run both. */
+ * the matching packed form) and the G1 partial sums between the levels stay in that form; 2: the same level 1 with standard-form
+ * partial sums; 0: the 8 x 32-bit kernels everywhere.  Set before mi_pk_load; parity tests run all three. */
 int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on);
 /* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
  * running; 0 disarms.  Used to prove that init / load / prove unwind without leaks or crashes. */

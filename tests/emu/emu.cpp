@@ -52,6 +52,7 @@ void emu_g2_b(void *out) { Fp2 b = curve_b((const Fp2 *)0); memcpy(out, &b, size
 
 // ---------------------------------------------------------------- 9 x 29-bit level-1 accumulation (curve29.cuh on the host; traps on any
 // violated limb / carry assumption because this file is built with -DMI_CHECK_NOWRAP)
+#include <vector>
 #include "../../gnark-whir_amd/csrc/curve29.cuh"
 extern "C" int emu_g1_madd29_chain(void *out_aff, const void *pts_std, const unsigned char *neg, size_t n) {
     const G1Aff *p = (const G1Aff *)pts_std;
@@ -63,6 +64,38 @@ extern "C" int emu_g1_madd29_chain(void *out_aff, const void *pts_std, const uns
         g1x29_madd(acc, w, neg[i] != 0);
     }
     *(G1Aff *)out_aff = xyzz_to_affine(g1x29_to_std(acc));
+    return 0;
+}
+// items of `item_len` mixed additions each, their sums packed in the R' form and added up with g1x29_add (levels >= 2 of the device's
+// item machinery): level-1 kernel -> store_rp -> load_rp -> full additions -> standard form
+extern "C" int emu_g1_rp_levels(void *out_aff, const void *pts_std, const unsigned char *neg, size_t n, size_t item_len) {
+    const G1Aff *p = (const G1Aff *)pts_std;
+    std::vector<G1X> partial;
+    for (size_t b = 0; b < n; b += item_len) {
+        G1X29 acc = g1x29_inf();
+        for (size_t i = b; i < n && i < b + item_len; i++) {
+            G1Aff rp{fe_to_rprime_packed(p[i].x), fe_to_rprime_packed(p[i].y)};
+            u32 w[16];
+            memcpy(w, &rp, 64);
+            g1x29_madd(acc, w, neg[i] != 0);
+        }
+        G1X slot;
+        g1x29_store_rp(acc, reinterpret_cast<u32 *>(&slot));
+        partial.push_back(slot);
+    }
+    while (partial.size() > 1) {   // levels of up to three partial sums per item
+        std::vector<G1X> next;
+        for (size_t b = 0; b < partial.size(); b += 3) {
+            G1X29 acc = g1x29_load_rp(reinterpret_cast<const u32 *>(&partial[b]));
+            for (size_t k = b + 1; k < partial.size() && k < b + 3; k++) g1x29_add(acc, g1x29_load_rp(reinterpret_cast<const u32 *>(&partial[k])));
+            G1X slot;
+            g1x29_store_rp(acc, reinterpret_cast<u32 *>(&slot));
+            next.push_back(slot);
+        }
+        partial.swap(next);
+    }
+    G1X29 fin = partial.empty() ? g1x29_inf() : g1x29_load_rp(reinterpret_cast<const u32 *>(&partial[0]));
+    *(G1Aff *)out_aff = xyzz_to_affine(g1x29_to_std(fin));
     return 0;
 }
 #include "../../gnark-whir_amd/csrc/curve29_g2.cuh"

@@ -401,8 +401,9 @@ def test_generic_msm_two_pass_and_one_pass_sorts_agree_with_oracle(ctx, n, dist)
 
 
 def test_limb29_level1_kernel_on_and_off_agree_with_oracle(ctx):
-    """the G1 level-1 accumulation in nine 29-bit limbs (default) and in 8 x 32-bit limbs (knob), generic and fixed-base keys:
-    proof bytes and a generic MSM with repeated / opposite / infinity points against the oracle"""
+    """the G1 level-1 accumulation in nine 29-bit limbs with partial sums in the R' form (default, 1), with standard-form partial
+    sums (2), and in 8 x 32-bit limbs (0), generic and fixed-base keys: proof bytes and a generic MSM with repeated / opposite /
+    infinity points (100 copies of one point: equal partial sums, the doubling path of the R'-form addition) against the oracle"""
     B = load_binding()
     log_n = 15
     N = 1 << log_n
@@ -419,7 +420,7 @@ def test_limb29_level1_kernel_on_and_off_agree_with_oracle(ctx):
     p2[3] = 0; p2[6] = p2[5]; s2[6] = s2[5]; p2[8] = g2_arr([P.g2_neg(g2_pts(p2[7:8])[0])])[0]; s2[8] = s2[7]; p2[40:60] = p2[39]
     want_msm2 = cref.msm_g2(p2, s2)
     try:
-        for on in (1, 0):
+        for on in (1, 2, 0):
             assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, on) == 0
             for knob in ((0, 0, 0), (17, 18, 17)):
                 assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0

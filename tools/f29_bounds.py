@@ -60,4 +60,23 @@ for it in range(12):
     state = round_(*state)
 print("fixed point of the accumulator bounds:", ", ".join(f"{b.name} V < {b.V:.2f} (L {b.L:.2f})" for b in state))
 assert state[0].V < 5.7 and state[1].V < 1.8 and state[2].V < 1.04 and state[3].V < 1.04
+
+
+def add_round(a, b):
+    """g1x29_add: a = running sum, b = a loaded partial sum (normalised, X < 4.02 after g1x29_store_rp's conditional subtraction)"""
+    (Xa, Ya, ZZa, ZZZa), (Xb, Yb, ZZb, ZZZb) = a, b
+    U1 = mul(Xa, ZZb, "U1"); U2 = mul(Xb, ZZa, "U2"); S1 = mul(Ya, ZZZb, "S1"); S2 = mul(Yb, ZZZa, "S2")
+    P = wnorm(sub(U2, U1, 2, "P")); R = wnorm(sub(S2, S1, 2, "R"))
+    PP = mul(P, P, "PP"); PPP = mul(P, PP, "PPP"); Q = mul(U1, PP, "Q")
+    T = wnorm(add(add(PPP, Q, "T"), Q, "T")); RR = mul(R, R, "RR")
+    X3 = wnorm(sub(RR, T, 4, "X3")); D = wnorm(sub(Q, X3, 8, "D")); nS1 = wnorm(sub(B(0, 0, "0"), S1, 2, "nS1"))
+    return X3, mul2(R, D, nS1, PPP, "Y3"), mul(mul(ZZa, ZZb, "ZZab"), PP, "ZZ3"), mul(mul(ZZZa, ZZZb, "ZZZab"), PPP, "ZZZ3")
+
+
+stored = (B(4.02, 29, "Xb"), B(state[1].V, 29, "Yb"), B(state[2].V, 29, "ZZb"), B(state[3].V, 29, "ZZZb"))   # what g1x29_load_rp returns at worst
+run = (B(5.7, WEAK, "Xa"), stored[1], stored[2], stored[3])
+for it in range(12):
+    run = add_round(run, stored)
+    assert run[0].V < 5.7 and run[1].V < 1.8 and run[2].V < 1.04 and run[3].V < 1.04, [b.V for b in run]
+print("g1x29_add keeps the accumulator invariant:", ", ".join(f"{b.name} V < {b.V:.2f}" for b in run))
 print("all preconditions hold; to_std needs V <= 128:", max(b.V for b in state), "ok")
