@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
                                                                       uint16_t *part_lo, u32 *part_val) {
     extern __shared__ u32 lds_u32[];
     u32 *hist = lds_u32, *loff = hist + s.ngroups, *gbase = loff + s.ngroups + 1, *tmp = gbase + s.ngroups, *stage_val = tmp + 256;
-    uint16_t *stage_lo = (uint16_t *)(stage_val + cap);
+    uint16_t *stage_lo = (uint16_t *)(stage_val + cap), *stage_grp = stage_lo + cap;
     for (u32 g = threadIdx.x; g < s.ngroups; g += blockDim.x) hist[g] = 0;
     // a slice has at most MSM2_SLICE = blockDim scalars: one per thread, loaded and made canonical once, kept in registers for
     // both the count and the place phase
@@ -131,9 +131,9 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
     }
     if (threadIdx.x == 0) loff[s.ngroups] = carry;
     __syncthreads();
-    if (have) msm2_place_one(s, dg, i, hist, stage_lo, stage_val);
+    if (have) msm2_place_one(s, dg, i, hist, stage_lo, stage_val, stage_grp);
     __syncthreads();
-    msm2_stage_copy_body(s, gbase, loff, stage_lo, stage_val, part_lo, part_val, threadIdx.x, blockDim.x);
+    msm2_stage_copy_body(s, gbase, loff, stage_lo, stage_val, stage_grp, part_lo, part_val, threadIdx.x, blockDim.x);
 }
 __global__ void k_msm2_chunk_count(Msm2Shape s, const u32 *S1, u32 *gstart, u32 *nchunks) {
     u32 hi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -484,7 +484,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     u32 *part_val = (u32 *)sl.buf[B_PVAL].p, *gstart = (u32 *)sl.buf[B_CHUNKS].p, *cstart = gstart + s.ngroups + 1, *nchunks = cstart + s.ngroups + 1;
     u32 *H2 = (u32 *)sl.buf[B_H].p, *keystart = (u32 *)sl.buf[B_S].p, *total = keystart + s.nkeys + 1, *sorted = (u32 *)sl.buf[B_SORTED].p;
     const u32 cap = ((n + G - 1) / G) * s.nwin;   // entries of one slice at most
-    const size_t part_lds = ((size_t)3 * s.ngroups + 1 + 256 + cap) * 4 + (size_t)cap * 2;
+    const size_t part_lds = ((size_t)3 * s.ngroups + 1 + 256 + cap) * 4 + (size_t)cap * 2 * 2;   // ... + stage_val | stage_lo, stage_grp (u16)
     if (part_lds > 160 * 1024) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: pass-1 slice does not fit in LDS");
     hipLaunchKernelGGL(k_msm2_partition, dim3(G), dim3(MSM2_PART_THREADS), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val);
     hipLaunchKernelGGL(k_msm2_chunk_count, dim3((s.ngroups + 63) / 64), dim3(64), 0, st, s, S1, gstart, nchunks);

@@ -83,38 +83,36 @@ MI_HD void msm2_count_body(const Msm2Shape &s, const Fr *scalars, bool montgomer
 // of the slice), cursor[hi] = loff[hi].  place: every entry goes to its group's run inside the LDS staging area;
 // copy: entry e of the staging area belongs to the group hi with loff[hi] <= e < loff[hi+1] and lands at
 // gbase[hi] + (e - loff[hi]), gbase[hi] = S1[hi * G + g]: consecutive e of a group are consecutive in part_lo / part_val.
-// one scalar i (canonical in dg): its entries go to their groups' runs of the staging area
-MI_HD void msm2_place_one(const Msm2Shape &s, Msm2Digits dg, u32 i, u32 *cursor, uint16_t *stage_lo, u32 *stage_val) {
+// one scalar i (canonical in dg): its entries go to their groups' runs of the staging area.  stage_grp keeps every entry's group
+// next to it: the copy phase then needs two LDS reads per entry instead of a binary search over loff (8 dependent reads).
+MI_HD void msm2_place_one(const Msm2Shape &s, Msm2Digits dg, u32 i, u32 *cursor, uint16_t *stage_lo, u32 *stage_val, uint16_t *stage_grp) {
     for (u32 w = 0; w < s.nwin; w++) {
         int32_t d = dg.next(s);
         if (!d) continue;
         u32 key = (u32)(d < 0 ? -d : d) - 1 + (s.wkeys ? w * s.half : 0u);
         u32 pos = MI_LDS_ATOMIC_ADD(&cursor[key >> s.gbits], 1u);
         stage_lo[pos] = (uint16_t)(key & (s.gsize - 1));
+        stage_grp[pos] = (uint16_t)(key >> s.gbits);
         stage_val[pos] = (s.wkeys ? i : w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
     }
 }
 MI_HD void msm2_stage_place_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *cursor, uint16_t *stage_lo, u32 *stage_val,
-                                 u32 tid, u32 nthr) {
+                                 uint16_t *stage_grp, u32 tid, u32 nthr) {
     u32 begin, end;
     msm2_slice_range(s, g, begin, end);
     for (u32 i = begin + tid; i < end; i += nthr) {
         Msm2Digits dg;
         dg.start(scalars[i], montgomery);
-        msm2_place_one(s, dg, i, cursor, stage_lo, stage_val);
+        msm2_place_one(s, dg, i, cursor, stage_lo, stage_val, stage_grp);
     }
 }
 // gbase[hi] = S1[hi * G + g] (the slice's run of group hi in the partitioned arrays), loaded once per workgroup
 MI_HD void msm2_stage_copy_body(const Msm2Shape &s, const u32 *gbase, const u32 *loff, const uint16_t *stage_lo, const u32 *stage_val,
-                                uint16_t *part_lo, u32 *part_val, u32 tid, u32 nthr) {
+                                const uint16_t *stage_grp, uint16_t *part_lo, u32 *part_val, u32 tid, u32 nthr) {
     const u32 total = loff[s.ngroups];
     for (u32 e = tid; e < total; e += nthr) {
-        u32 lo_g = 0, hi_g = s.ngroups;   // largest group with loff <= e (empty groups share a start with their successor)
-        while (hi_g - lo_g > 1) {
-            u32 mid = (lo_g + hi_g) >> 1;
-            if (loff[mid] <= e) lo_g = mid; else hi_g = mid;
-        }
-        u32 pos = gbase[lo_g] + (e - loff[lo_g]);
+        const u32 grp = stage_grp[e];
+        u32 pos = gbase[grp] + (e - loff[grp]);
         part_lo[pos] = stage_lo[e];
         part_val[pos] = stage_val[e];
     }

@@ -350,7 +350,7 @@ extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uin
     std::vector<uint16_t> part_lo(T + 1);
     std::vector<u32> part_val(T + 1);
     const u32 cap = ((n + G - 1) / G) * s.nwin;
-    std::vector<uint16_t> stage_lo(cap + 1);
+    std::vector<uint16_t> stage_lo(cap + 1), stage_grp(cap + 1);
     std::vector<u32> stage_val(cap + 1), hist(s.ngroups), loff;
     for (u32 g = 0; g < G; g++) {   // LDS-staged partition: count again, scan, place, copy
         for (u32 h = 0; h < s.ngroups; h++) hist[h] = 0;
@@ -358,10 +358,10 @@ extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uin
         excl_scan(hist, loff);
         if (loff[s.ngroups] > cap) return -1;
         for (u32 h = 0; h < s.ngroups; h++) hist[h] = loff[h];
-        for (u32 t = 0; t < nthr; t++) msm2_stage_place_body(s, (const Fr *)sc_v, mont != 0, g, hist.data(), stage_lo.data(), stage_val.data(), t, nthr);
+        for (u32 t = 0; t < nthr; t++) msm2_stage_place_body(s, (const Fr *)sc_v, mont != 0, g, hist.data(), stage_lo.data(), stage_val.data(), stage_grp.data(), t, nthr);
         std::vector<u32> gbase(s.ngroups);
         for (u32 h = 0; h < s.ngroups; h++) gbase[h] = S1[(size_t)h * G + g];
-        for (u32 t = 0; t < nthr; t++) msm2_stage_copy_body(s, gbase.data(), loff.data(), stage_lo.data(), stage_val.data(), part_lo.data(), part_val.data(), t, nthr);
+        for (u32 t = 0; t < nthr; t++) msm2_stage_copy_body(s, gbase.data(), loff.data(), stage_lo.data(), stage_val.data(), stage_grp.data(), part_lo.data(), part_val.data(), t, nthr);
     }
     std::vector<u32> gstart(s.ngroups + 1), cstart, nch(s.ngroups);
     for (u32 h = 0; h < s.ngroups; h++) msm2_chunk_count_body(s, S1.data(), gstart.data(), nch.data(), h);
