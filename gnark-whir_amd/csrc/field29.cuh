@@ -48,8 +48,8 @@ MI_HD F29 f29_const(const u32 (&c)[9]) { F29 z;
 // Column accumulate.  On the device every multiply-accumulate is an OPAQUE v_mad_u64_u32 into the one column accumulator.  Left to
 // itself the compiler starts a fresh accumulator per column and joins it to the shifted carry with a 64-bit add (v_lshl_add_u64:
 // 17 per product at ~4.7 cycles each, against ~5 for the multiply itself -- tools/bench_valu/instr_rate.hip); the chain form measures
-// 162 -> 180 G products/s at three waves per SIMD (tools/bench_valu/mul29_variants.hip) and 12.8 -> 13.7 G mixed additions/s in the
-// level-1 accumulate kernel.  One asm statement per multiply (the compiler pads each with an s_nop it does not need, but stays free
+// 169 -> 178 G products/s at three waves per SIMD and 147 -> 169 at eight (tools/bench_valu/mul29_variants.hip,
+// profiles/r02_probe_mul29_variants.txt) and 12.8 -> 13.7 G mixed additions/s in the level-1 accumulate kernel.  One asm statement per multiply (the compiler pads each with an s_nop it does not need, but stays free
 // to interleave independent products; whole columns as single asm blocks measured 7 % SLOWER).  The host build (tests) is plain C
 // with overflow detection under MI_CHECK_NOWRAP.
 MI_HD void f29_mac(u64 &acc, u32 a, u32 b) {

@@ -3,7 +3,7 @@
  * Drop-in boundary for the one hot path of reilabs/gnark-whir: everything that happens inside
  *     proof, _ := groth16.Prove(ccs, pk, witness, backend.WithSolverOptions(...))
  * at /root/reference/mt.go:496 *after* gnark's R1CS solver has produced the wire vector W
- * and the per-constraint vectors a, b, c — i.e. computeH (7 NTTs), the scalar filters, four
+ * and the per-constraint vectors a, b, c — i.e. computeH (gnark's 7 NTTs, done with 6), the scalar filters, four
  * G1 MSMs, one G2 MSM and proof assembly (SURVEY.md section 3.3 steps 4-8, section 8a rows
  * a3-a9).  The reference has no FFI of its own; the seam a maintainer binds is gnark's
  * accelerator seam (backend/groth16/bn254/icicle in gnark v0.11.0, go.mod:6), whose shape

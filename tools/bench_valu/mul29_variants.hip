@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) kk(F29 *out, u32 iters, u32 inv) {
     for (int i = 0; i < 9; i++) { a.l[i] = (threadIdx.x * 2654435761u + i * 40503u) & ((1u << 28) - 1); b.l[i] = (blockIdx.x * 2246822519u + i * 7919u) & ((1u << 28) - 1); }
     for (u32 it = 0; it < iters; it++) { a = mul29<V, SQ>(a, b, inv); b = mul29<V, SQ>(b, a, inv); }
     if (a.l[0] == 0xdeadbeef) { out[0] = b; lds[threadIdx.x] = 1; }
-    out[((size_t)blockIdx.x * blockDim.x + threadIdx.x) & 1023] = a;
+    if (blockIdx.x == 0) out[threadIdx.x] = a;   // one writer per slot: the signature below is deterministic
 }
 // host check of the variants against each other is left to the production tests; here the three kernels must agree on out[]
 template <int V, bool SQ> static void run(const char *name, u32 inv, F29 *buf, size_t lds, u32 *sig) {
