@@ -36,6 +36,7 @@ struct NttState {
     u32 lds_floor = 0;     // bytes of LDS every pass workgroup requests at least: caps the workgroups per CU (0 = only what the tile needs)
     u32 plan_set = 0;      // the knobs above were set by the caller: no per-size defaults
     u32 wave_stages = 1;   // passes of radix >= 2^7 run their last / first seven stages in registers (k_ntt_pass_wave); 0 = all through LDS
+    u32 fuse_pair = 1;     // computeH: inverse last pass + coset first pass of a and b as one launch (k_ntt_contig_pair)
 };
 // Tile / radix knobs for a transform of 2^log_n: the caller's (mi_debug_set_ntt_plan) or, untouched, the measured best per size
 // (tools/ntt_probe.py sweep, profiles/r02_tune_ntt_sweep.json): 2^9 tiles and radices 2^7 2^7 2^9 up to 2^23; 2^10 tiles and
@@ -49,12 +50,14 @@ static NttState *state_of(mi_ctx *ctx) {
 
 __global__ void k_ntt_pass(Fr *dst, const Fr *src, NttPass p, NttTables t);
 __global__ void k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t);
+__global__ void k_ntt_contig_pair(Fr *data, NttPass pi, NttTables ti, NttPass pf, NttTables tf);
 void mi_ntt_state_init(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= sizeof(ctx->ntt_state), "NttState lives in ctx->ntt_state");
     new (ctx->ntt_state) NttState();
     if (const char *e = getenv("MI_NTT_LDS_FLOOR_KB")) state_of(ctx)->lds_floor = (u32)atoi(e) * 1024u;
     (void)hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_pass_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_contig_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
@@ -129,6 +132,47 @@ __global__ void __launch_bounds__(256) k_ntt_pass_wave(Fr *dst, const Fr *src, N
             __syncthreads();
         }
     ntt_tile_store(p, t, dst, tile, threadIdx.x, blockDim.x, lds);
+}
+
+// computeH's a and b: the LAST pass of the inverse transform (DIF, contiguous tiles) and the FIRST pass of the coset transform that
+// follows (DIT, the same contiguous tiles, coset shift on the way in) as one launch -- the tile is loaded once, runs the inverse
+// stages, is multiplied by the shift, runs the forward stages and is stored once; in the register stages the two transforms meet
+// without an LDS round trip (a lane ends the DIF stages holding positions 2L, 2L + 1 -- what the DIT stages start from).  One store
+// and one load of the vector (0.54 GB at N = 2^23) and one launch less per vector.  pi / ti: the inverse pass as ntt_run would have
+// launched it, pf / tf: the forward one.  Radix >= 2^7, equal tile shapes.
+__global__ void __launch_bounds__(256) k_ntt_contig_pair(Fr *data, NttPass pi, NttTables ti, NttPass pf, NttTables tf) {
+    extern __shared__ U4 lds[];
+    const u64 tile = blockIdx.x;
+    const u32 PL = ntt_plane_slots(pi);
+    ntt_tile_load(pi, ti, data, tile, threadIdx.x, blockDim.x, lds);
+    __syncthreads();
+    for (u32 s = 0; s + 7 < pi.log_r; s++) {   // DIF distances R/2 ... 128
+        ntt_tile_stage(pi, ti, s, threadIdx.x, blockDim.x, lds);
+        __syncthreads();
+    }
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const u32 nsub = 1u << (pi.log_r + pi.log_c - 7);
+    for (u32 sb = wave; sb < nsub; sb += nwaves) {
+        const u32 col = sb & ((1u << pi.log_c) - 1), base = (sb >> pi.log_c) << 7;
+        Fr x0 = lds_get(lds, PL, ntt_lds_slot(pi, base + lane, col)), x1 = lds_get(lds, PL, ntt_lds_slot(pi, base + lane + 64, col));
+        wave_ntt128(x0, x1, lane, false, ti.small);
+        // what the inverse pass would have stored at rows 2L, 2L + 1 and the forward pass loaded with its edge factor
+        const u32 r0 = base + 2 * lane, r1 = r0 + 1;
+        Fr f;
+        if (ntt_edge_factor(pi, ti, r0, ntt_global_index(pi, tile, r0, col), 1, f)) x0 = x0 * f;
+        if (ntt_edge_factor(pf, tf, r0, ntt_global_index(pf, tile, r0, col), 0, f)) x0 = x0 * f;
+        if (ntt_edge_factor(pi, ti, r1, ntt_global_index(pi, tile, r1, col), 1, f)) x1 = x1 * f;
+        if (ntt_edge_factor(pf, tf, r1, ntt_global_index(pf, tile, r1, col), 0, f)) x1 = x1 * f;
+        wave_ntt128(x0, x1, lane, true, tf.small);
+        lds_put(lds, PL, ntt_lds_slot(pf, base + lane, col), x0);
+        lds_put(lds, PL, ntt_lds_slot(pf, base + lane + 64, col), x1);
+    }
+    __syncthreads();
+    for (u32 s = 7; s < pf.log_r; s++) {   // DIT distances 128 ... R/2
+        ntt_tile_stage(pf, tf, s, threadIdx.x, blockDim.x, lds);
+        __syncthreads();
+    }
+    ntt_tile_store(pf, tf, data, tile, threadIdx.x, blockDim.x, lds);
 }
 
 // direct factor tables (NttPass::tw_direct / sc_direct), one thread per entry, square-and-multiply
@@ -252,8 +296,10 @@ static int32_t ensure_direct(mi_ctx *ctx, u32 log_n) {
 // 3 = inverse coset with den folded into its scaling; 4 = inverse scaled by den / N.  0 = exactly fft.Domain's FFT / FFTInverse.
 // load_mul / store_sub (computeH only, see NttPass): pointwise factor on the way into the first pass / pointwise subtrahend on the
 // way out of the last.
+// skip (computeH's fused contiguous pair, k_ntt_contig_pair): bit 0 = the first pass, bit 1 = the last pass is not launched but
+// returned in *cap / *cap_t for the fused kernel; bit 2 = nothing is launched at all (capture only).
 static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log_n, u32 flags, u32 variant = 0,
-                       const Fr *load_mul = nullptr, const Fr *store_sub = nullptr) {
+                       const Fr *load_mul = nullptr, const Fr *store_sub = nullptr, u32 skip = 0, NttPass *cap = nullptr, NttTables *cap_t = nullptr) {
     NttState *st = state_of(ctx);
     MI_TRY(ensure_tables(ctx, log_n));
     const bool inverse = flags & MI_NTT_INVERSE, coset = flags & MI_NTT_COSET, dit = flags & MI_NTT_DIT;
@@ -300,6 +346,12 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
         if (direct && variant == 3 && p.scale == 3) p.sc_direct = st->d_sc_inv;
         const bool wave = p.log_r >= 7 && st->wave_stages;
         p.lds_pad = wave && p.log_s != 0 ? 1 : 0;
+        if (((skip & 1) && step == 0) || ((skip & 2) && step == pl.n_pass - 1)) {
+            if (cap) { *cap = p; *cap_t = t; }
+            cur_src = dst;
+            continue;
+        }
+        if (skip & 4) continue;
         u32 tiles = 1u << (log_n - p.log_r - p.log_c);
         size_t lds_bytes = (size_t)32 * ntt_plane_slots(p);
         if (st->lds_floor > lds_bytes) lds_bytes = st->lds_floor;   // occupancy cap of the pass kernels (experiments: MI_NTT_LDS_FLOOR_KB)
@@ -313,7 +365,7 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
         cur_src = dst;
         ctx->stats.ntt_launches++;
     }
-    ctx->stats.ntt_elems += (u64)1 << log_n;
+    if (!(skip & 4)) ctx->stats.ntt_elems += (u64)1 << log_n;
     return MI_OK;
 }
 
@@ -334,12 +386,33 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
     // so the coset FFT of c is never computed -- SIX transforms, the same field elements (exact arithmetic), for ANY a, b, c.
     // 1. a, b <- N FFTInverse(., DIF) (zero padding fused into the first pass's load; the 1/N rides in step 2's coset shift);
     //    c <- den FFTInverse(c, DIF) (one constant den / N on the way out), bit-reversed like h
-    MI_TRY(ntt_run(ctx, A, (const Fr *)a, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
-    MI_TRY(ntt_run(ctx, B, (const Fr *)b, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
+    //    a and b: the contiguous last pass of the inverse transform and the contiguous first pass of the coset transform run as ONE
+    //    launch on the same tiles (k_ntt_contig_pair) when the plan has such a pair of radix >= 2^7
+    NttState *st = state_of(ctx);
+    const NttKnobs kn = knobs_for(st, log_n);
+    const NttPlan pl = ntt_make_plan(log_n, kn.max_contig, kn.max_strided);
+    const bool pair = st->fuse_pair && st->wave_stages && pl.n_pass >= 2 && pl.log_r[pl.n_pass - 1] >= 7;
+    Fr *vec[2] = {A, B};
+    const Fr *in[2] = {(const Fr *)a, (const Fr *)b};
+    for (int k = 0; k < 2; k++) {
+        if (!pair) {
+            MI_TRY(ntt_run(ctx, vec[k], in[k], (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
+            continue;
+        }
+        NttPass pi{}, pf{};
+        NttTables ti{}, tf{};
+        MI_TRY(ntt_run(ctx, vec[k], in[k], (u32)n_constraints, log_n, MI_NTT_INVERSE, 1, nullptr, nullptr, 2, &pi, &ti));
+        MI_TRY(ntt_run(ctx, vec[k], vec[k], (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, 1 | 4, &pf, &tf));
+        if (pi.log_r != pf.log_r || pi.log_c != pf.log_c || pi.log_s || pf.log_s) MI_FAIL(ctx, MI_EINVAL, "internal: contiguous pass pair does not match");
+        hipLaunchKernelGGL(k_ntt_contig_pair, dim3(1u << (log_n - pi.log_r - pi.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pi), ctx->stream,
+                           vec[k], pi, ti, pf, tf);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+        ctx->stats.ntt_launches++;
+    }
     MI_TRY(ntt_run(ctx, C, (const Fr *)c, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4));
-    // 2. a, b <- FFT(., DIT, OnCoset)
-    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2));
-    MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2));
+    // 2. a, b <- FFT(., DIT, OnCoset)  (the rest of it when the first pass ran in the pair)
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, pair ? 1u : 0u));
+    MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, pair ? 1u : 0u));
     // 3. h <- den FFTInverse(a b, DIF, OnCoset) - c, left bit-reversed like gnark: the product a b is taken on the way into the
     //    first pass, the subtraction on the way out of the last (no pointwise kernel, no extra round trip through HBM)
     MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C));
@@ -361,6 +434,11 @@ int32_t mi_debug_set_ntt_wave_stages(mi_ctx *ctx, uint32_t on, uint32_t direct_m
     NttState *st = state_of(ctx);
     st->wave_stages = on; st->direct_min_log_n = direct_min_log_n;
     st->d_npass = 0;   // force the next computeH to re-decide about its direct tables
+    return MI_OK;
+}
+int32_t mi_debug_set_ntt_fuse_pair(mi_ctx *ctx, uint32_t on) {
+    if (!ctx || on > 1) return MI_EINVAL;
+    state_of(ctx)->fuse_pair = on;
     return MI_OK;
 }
 int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads) {

@@ -191,3 +191,23 @@ def test_ntt_register_and_lds_stage_paths_agree_with_oracle(ctx, log_n):
             assert np.array_equal(ctx.compute_h(log_n, a[: n - 3], b[: n - 3], c[: n - 3]), want_h), (on, dmin)
     finally:
         assert ctx.lib.mi_debug_set_ntt_wave_stages(ctx.h, 1, 12) == 0
+
+
+@pytest.mark.parametrize("log_n,plan", [(10, None), (14, (8, 7, 7)), (16, None), (17, (10, 10, 7)), (20, None)])
+def test_compute_h_with_and_without_the_fused_contiguous_pair(ctx, log_n, plan):
+    """computeH with the inverse transform's last pass and the coset transform's first pass of a and b as one launch (default
+    wherever the plan's contiguous radix is >= 2^7) and as two, against the oracle: all of h, with zero padding, c unrelated to a b"""
+    n = 1 << log_n
+    nc = n - 11
+    a = cref.gen_scalars(nc, 600 + log_n, 1); b = cref.gen_scalars(nc, 601 + log_n, 0); c = cref.gen_scalars(nc, 602 + log_n, 0)
+    want = cref.compute_h(log_n, a, b, c)
+    try:
+        if plan:
+            assert ctx.lib.mi_debug_set_ntt_plan(ctx.h, *plan) == 0
+        for on in (1, 0, 1):
+            assert ctx.lib.mi_debug_set_ntt_fuse_pair(ctx.h, on) == 0
+            assert np.array_equal(ctx.compute_h(log_n, a, b, c), want), (on, log_n)
+    finally:
+        assert ctx.lib.mi_debug_set_ntt_fuse_pair(ctx.h, 1) == 0
+        if plan:
+            assert ctx.lib.mi_debug_set_ntt_plan(ctx.h, 9, 9, 7) == 0
