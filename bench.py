@@ -330,8 +330,11 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")))
                 kname = "k_msm_accum_affine29"
                 traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
-                kn = "k_ntt_pass_wave"   # per pass launch; one transform = pass_launches / 6 launches
-                traffic_ntt = (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0 * ntt_solo["pass_launches"] / 6.0
+                # per pass launch (the fused contiguous pair counted with its own figures, two launches per computeH); one transform =
+                # a sixth of computeH's launches
+                per = lambda kn: (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0
+                n_pair = 2 if "k_ntt_contig_pair" in pmc["FETCH_SIZE"] else 0
+                traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0)) / 6.0
             except Exception:
                 traffic = traffic_ntt = None
         line = {
@@ -366,7 +369,7 @@ def main():
             "roofline_ntt": {"kernel": "k_ntt_pass_wave (all passes of one size-N transform)", "bound": "hbm",
                              "achieved": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9 / 8000.0, "traffic": traffic_ntt,
-                             "traffic_source": "profiles/r02_pmc_bench_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) per pass launch x passes per transform",
+                             "traffic_source": "profiles/r02_pmc_bench_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) per pass launch x pass launches per transform",
                              "compute_h_solo_ms": ntt_solo["compute_h_ms"], "pass_launches_per_compute_h": ntt_solo["pass_launches"],
                              "algorithmic_bytes_per_transform": 64.0 * N},
             # why the HBM fraction is small: the kernel is bound by 256-bit modular products on the VALU (no MFMA form exists)
