@@ -58,27 +58,14 @@ def cpu_baseline(pk_host, W, a, b, c, r, s, log_n, gpu_proof_bytes):
             "proof_bytes_match": True}
 
 
-def _guard(result, fn, *a):
-    try:
-        fn(*a)
-    except BaseException as e:   # reported in the line, never fatal for the proofs/s measurement
-        result["error"] = f"{type(e).__name__}: {e}"
-
-
-def sharded_msm_section(B, torch, dist, rank, local_rank, world, log_n_msm, steps, result):
+def sharded_msm_section(B, rank, local_rank, world, uid, log_n_msm, steps):
     """BASELINE configs[4]: ONE G1 MSM of 2^log_n_msm pairs, bases point-sharded over the ranks (one per GPU), through the C-ABI's
     device group (mi_group_create_rank + mi_msm_g1_sharded_dev, csrc/group.hip): mode 0 = all-gather of per-rank partial sums,
     mode 1 = reduce-scatter of bucket sums (grouped ncclSend / ncclRecv) before the bucket reduce.  Strong scaling: total work
-    fixed.  Fills `result` (a dict) in place so that a watchdog can give up on it."""
+    fixed.  Runs in the HELPER PROCESS (see main): no torch, no torch.distributed -- the ranks meet in the group's own collectives;
+    returns this rank's seconds per mode, the caller takes the maximum over the ranks."""
     import numpy as np
-    torch.cuda.set_device(local_rank)   # this runs on a thread of its own: the current device is per thread
-    uid = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        uid = torch.tensor(list(B.Group.unique_id()), dtype=torch.uint8)
-    if dist is not None:
-        dev = torch.device("cuda", local_rank)
-        t = uid.to(dev); dist.broadcast(t, src=0); uid = t.cpu()
-    g = B.Group.rank(local_rank, rank, world, bytes(uid.tolist()))
+    g = B.Group.rank(local_rank, rank, world, uid)
     try:
         n = 1 << log_n_msm
         lo, hi = B.shard_range(n, world, rank)
@@ -87,32 +74,42 @@ def sharded_msm_section(B, torch, dist, rank, local_rank, world, log_n_msm, step
         c.sync()
         out = {}
         for mode in (0, 1):
-            ref = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)   # warm-up: sizes the workspaces
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
+            ref = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)   # warm-up: sizes the workspaces, and lines the ranks up
+            c.sync()
             t0 = time.perf_counter()
             for _ in range(steps):
                 got = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
+            c.sync()
             dt = time.perf_counter() - t0
-            if dist is not None:
-                tt = torch.tensor([dt], device=torch.device("cuda", local_rank), dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
             assert np.array_equal(got, ref)
             out[mode] = (got, dt)
-        agree = bool(np.array_equal(out[0][0], out[1][0]))
-        result.update({"workload": f"one G1 MSM, 2^{log_n_msm} uniform pairs, bases point-sharded over {world} rank(s) (BASELINE configs[4])",
-                       "scaling": "strong", "transport": g.transport(), "steps": steps,
-                       "mode0_partial_sums_pts_per_s": n * steps / out[0][1], "mode0_ms": out[0][1] / steps * 1e3,
-                       "mode1_bucket_exchange_pts_per_s": n * steps / out[1][1], "mode1_ms": out[1][1] / steps * 1e3,
-                       "modes_agree": agree, "done": True})
+        res = {"transport": g.transport(), "steps": steps, "dt0": out[0][1], "dt1": out[1][1], "modes_agree": bool(np.array_equal(out[0][0], out[1][0]))}
         pts.free(); sc.free()
+        return res
     finally:
         g.close()
+
+
+def sharded_helper_main():
+    """`bench.py --sharded-helper`: started by main() BEFORE the parent touches the GPU (a process that has initialised the GPU must not
+    exec), idle until the parent writes one JSON line of parameters, then runs the point-sharded MSM on its own GPU context and
+    answers with one JSON line.  A fault or a stuck collective in this never-before-multi-GPU path then costs the parent nothing
+    but the `sharded_msm` block of its line."""
+    req = sys.stdin.readline()
+    if not req.strip():
+        return
+    q = json.loads(req)
+    if os.environ.get("MI_BENCH_HELPER_FAULT") == "abort":   # rehearsal of the failure this process exists for
+        os.abort()
+    if os.environ.get("MI_BENCH_HELPER_FAULT") == "hang":
+        time.sleep(10000)
+    try:
+        B = _binding()
+        res = sharded_msm_section(B, q["rank"], q["local_rank"], q["world"], bytes.fromhex(q["uid"]), q["log_n"], q["steps"])
+        res["ok"] = True
+    except BaseException as e:
+        res = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+    print(json.dumps(res), flush=True)
 
 
 def main():
@@ -136,7 +133,15 @@ def main():
     ap.add_argument("--sharded-msm-log-n", type=int, default=26, help="configs[4]: size of the point-sharded G1 MSM run after the proofs (0 = skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank control-flow rehearsal on a 1-GPU box: every rank uses device 0 and the collectives run over gloo")
+    ap.add_argument("--sharded-helper", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.sharded_helper:
+        return sharded_helper_main()
+    # the point-sharded MSM leg runs in a helper process of its own; it is started NOW, before anything here touches the GPU
+    helper = None
+    if args.sharded_msm_log_n and not args.rehearse_on_one_gpu:
+        import subprocess
+        helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--sharded-helper"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 
     import torch
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -274,17 +279,61 @@ def main():
                 raise SystemExit("bench.py: a host-input proof differs from the device-input proof of the same inputs")
         host_rate, host_ms = args.steps * world / dth, dth / args.steps * 1e3
 
-    # configs[4]: one G1 MSM point-sharded over the ranks through the C-ABI's device group (RCCL).  Bounded by a watchdog: a
-    # stuck collective must not cost the run its proofs/s line.
+    # configs[4]: one G1 MSM point-sharded over the ranks through the C-ABI's device group (RCCL), in the helper process started at
+    # the top; bounded by a watchdog: a stuck collective or a fault there must not cost the run its proofs/s line.
     sharded = {"done": False}
-    if args.sharded_msm_log_n and not args.rehearse_on_one_gpu:
+    if helper is not None:
         import threading
-        th = threading.Thread(target=lambda: _guard(sharded, sharded_msm_section, B, torch, dist, rank, local_rank, world,
-                                                    args.sharded_msm_log_n, 3, sharded), daemon=True)
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            uid = torch.tensor(list(B.Group.unique_id()), dtype=torch.uint8)
+        if dist is not None:
+            t = uid.to(torch.device("cuda", local_rank)); dist.broadcast(t, src=0); uid = t.cpu()
+            dist.barrier()
+        steps_msm = 3
+        answer = {}
+        def ask():
+            try:
+                helper.stdin.write(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "uid": bytes(uid.tolist()).hex(),
+                                               "log_n": args.sharded_msm_log_n, "steps": steps_msm}) + "\n")
+                helper.stdin.flush()
+                while True:   # the answer is the first line that is a JSON object (anything a library prints before it is skipped)
+                    ln = helper.stdout.readline()
+                    if not ln or ln.lstrip().startswith("{"):
+                        break
+                answer["line"] = ln
+            except BaseException as e:
+                answer["line"] = json.dumps({"ok": False, "error": f"{type(e).__name__}: {e}"})
+        th = threading.Thread(target=ask, daemon=True)
         th.start()
         th.join(timeout=150)
+        res = {"ok": False, "error": "timeout after 150 s (collective stuck?)"}
         if th.is_alive():
-            sharded["error"] = "timeout after 150 s (collective stuck?)"
+            helper.kill()
+        else:
+            try:
+                res = json.loads(answer.get("line") or "") if (answer.get("line") or "").strip() else {"ok": False, "error": "helper ended without an answer"}
+            except ValueError:
+                res = {"ok": False, "error": "helper answered garbage"}
+        ok = 1.0 if res.get("ok") else 0.0
+        v = [ok, float(res.get("dt0", 0.0)), float(res.get("dt1", 0.0)), 1.0 if res.get("modes_agree") else 0.0]
+        if dist is not None:   # every rank takes part, whatever its helper did: all ok?  slowest rank's times; all agree?
+            tmin = torch.tensor([v[0], v[3]], device="cuda", dtype=torch.float64); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+            tmax = torch.tensor([v[1], v[2]], device="cuda", dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            v = [float(tmin[0]), float(tmax[0]), float(tmax[1]), float(tmin[1])]
+        n_msm = 1 << args.sharded_msm_log_n
+        if v[0] == 1.0 and v[1] > 0 and v[2] > 0:
+            sharded.update({"workload": f"one G1 MSM, 2^{args.sharded_msm_log_n} uniform pairs, bases point-sharded over {world} rank(s) (BASELINE configs[4])",
+                            "scaling": "strong", "transport": res.get("transport"), "steps": steps_msm, "process": "helper process per rank (own GPU context)",
+                            "mode0_partial_sums_pts_per_s": n_msm * steps_msm / v[1], "mode0_ms": v[1] / steps_msm * 1e3,
+                            "mode1_bucket_exchange_pts_per_s": n_msm * steps_msm / v[2], "mode1_ms": v[2] / steps_msm * 1e3,
+                            "modes_agree": v[3] == 1.0, "done": True})
+        else:
+            sharded["error"] = res.get("error", "a rank's helper failed")
+        try:
+            helper.stdin.close(); helper.wait(timeout=10)
+        except BaseException:
+            helper.kill()
 
     # the same kernel measured alone (no other stream competing for the CUs): one uniform-scalar G1 MSM over pk.G1.Z
     solo = None
@@ -394,8 +443,6 @@ def main():
             line["cpu_baseline"] = cpu_baseline(pk_host, dl(W, nb_wires, 4), dl(a, n_constraints, 4), dl(b, n_constraints, 4),
                                                 dl(c, n_constraints, 4), rs[0], rs[1], log_n, serial_bytes)
         print(json.dumps(line), flush=True)
-    if sharded.get("error", "").startswith("timeout"):
-        os._exit(0)   # a rank is stuck inside a collective: do not wait for it in destroy_process_group
     if dist is not None:
         dist.destroy_process_group()
     ctx.pk_free(pkh)
