@@ -7,7 +7,11 @@
 // additions of an item in nine 29-bit limbs (162 multiplications and no carry instruction per product instead of 136 + 120;
 // lazy additions), the item's sum converted back to the standard XYZZ once at its end.  +13..16 % mixed additions per second
 // (tools/bench_limb29/madd29.hip: 13.1 against 11.3 G/s on L2-resident points, conversions included).
-__global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+// Two waves per SIMD (196 VGPRs, no scratch), not three (168 VGPRs: 504 of a SIMD's 512 registers): alone on the GPU three are 3 %
+// faster (14.0 against 13.5 G additions/s), but inside a proof they leave no room for another kernel's waves on the same SIMD and the
+// job loses 2 % (same-box A/B: 32.0 against 32.6 proofs/s) -- with two, a wave of the NTT passes (86 VGPRs) fits beside them and
+// fills the gaps their gathers leave.  Four would spill (332 B of scratch: 28.5 proofs/s).
+__global__ void __launch_bounds__(64, 2) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
                                                            G1X *bucket, G1X *partial_out, u32 rp_partials) {
     const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
     for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
@@ -15,7 +19,7 @@ __global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, 
         const u32 key = rec.x, b = rec.y, e = rec.z;
         G1X29 acc = g1x29_inf();
         // software pipelining: the gather of entry k + 1 is in flight while entry k is added (the kernel runs 2 waves per SIMD --
-        // 177 VGPRs -- so the ~2 us of a random 64-B HBM read are not hidden by other waves alone)
+        // 196 VGPRs -- so the ~2 us of a random 64-B HBM read are not hidden by other waves alone)
         u32 v = sorted[b];
         const uint4 *q4 = reinterpret_cast<const uint4 *>(pts + (v & 0x7fffffffu));
         uint4 q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];   // 64 B: x | y

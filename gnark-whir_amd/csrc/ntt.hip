@@ -102,7 +102,10 @@ __global__ void __launch_bounds__(1024) k_ntt_pass(Fr *dst, const Fr *src, NttPa
 // The same pass with the seven stages at distance <= 64 of every 128-row group done in REGISTERS by one wavefront
 // (ntt_wave.cuh): the tile makes two LDS round trips (in and out of the registers) plus one per stage at distance >= 128,
 // instead of one per stage, and two barriers plus one per such stage.  Needs log_r >= 7.
-__global__ void __launch_bounds__(256) k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t) {
+#ifndef MI_NTT_WAVES_PER_EU
+#define MI_NTT_WAVES_PER_EU 1   // experiment switch: 6 = no change (79 VGPRs either way), 8 = 64 VGPRs + 52 B of scratch, slower alone and in a proof
+#endif
+__global__ void __launch_bounds__(256, MI_NTT_WAVES_PER_EU) k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t) {
     extern __shared__ U4 lds[];
     const u64 tile = blockIdx.x;
     const u32 PL = ntt_plane_slots(p);
