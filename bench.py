@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--ntt-plan", default="", help="tuning: log_e,max_contig,max_strided[,threads] for mi_debug_set_ntt_plan / _threads on every context")
     ap.add_argument("--msm-group-bits", type=int, default=0, help="tuning: mi_debug_set_msm_group_bits on every context")
     ap.add_argument("--no-limb29", action="store_true", help="tuning: G1 level-1 accumulation in 8 x 32-bit limbs (mi_debug_set_msm_limb29(0)) instead of 9 x 29-bit")
+    ap.add_argument("--g1-waves", type=int, default=3, choices=(2, 3), help="tuning: build of the G1 level-1 kernel (mi_debug_set_msm_l1_waves): 3 waves per SIMD (default) or 2")
     ap.add_argument("--msm-chunk", type=int, default=0, help="tuning: mi_debug_set_msm_chunk on every context")
     ap.add_argument("--sharded-msm-log-n", type=int, default=26, help="configs[4]: size of the point-sharded G1 MSM run after the proofs (0 = skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -166,6 +167,7 @@ def main():
     ctx = pool.ctx(0)
     for i in range(pool.in_flight):
         assert pool.lib.mi_debug_set_msm_limb29(pool.ctx(i).h, 0 if args.no_limb29 else 1) == 0
+        assert pool.lib.mi_debug_set_msm_l1_waves(pool.ctx(i).h, args.g1_waves) == 0
         assert pool.lib.mi_debug_set_msm_group_bits(pool.ctx(i).h, args.msm_group_bits) == 0
         assert pool.lib.mi_debug_set_msm_chunk(pool.ctx(i).h, args.msm_chunk) == 0
     if args.ntt_plan:

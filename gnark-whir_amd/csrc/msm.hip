@@ -17,11 +17,13 @@
 #include "msm2_core.cuh"
 #include "msm_curve_ops.h"
 #include <cstring>
+#include <cstdlib>
 #include <new>
 
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
     u32 no_rprime = 0;                          // 1: G1 level 1 stays on the 8 x 32-bit kernel everywhere (tests compare both)
+    u32 l1_waves = 3;                           // G1 level-1 29-bit kernel: the build for 3 (default) or 2 waves per SIMD (msm_g1.hip)
     u32 std_partials = 0;                       // 1: partial sums between the levels in the standard form even after a 29-bit level 1
     u32 one_pass_sort = 0;                      // 1: large generic MSMs keep the one-pass counting sort (tests compare both)
     u32 chunk = 0;                              // fixed-base sort: entries per pass-2 chunk (tests shrink it)
@@ -362,13 +364,19 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         // other MSM streams wait for the end of the launch: 128..4096 per CU measured +1.5 % proofs/s and -1 ms latency over 32.
         // Levels that turn out to be (nearly) empty -- the bound is a worst case -- still cost microseconds, not a full dispatch.
         u32 grid = (u32)((items_bound + 63) / 64);
-        const u32 grid_cap = (u32)ctx->cu_count * 128;
+        u32 grid_cap = (u32)ctx->cu_count * 128;
+        {   // experiment switches: resident-grid caps per CU for the level-1 kernels (MI_G1_GRID_PER_CU / MI_G2_GRID_PER_CU)
+            static const int g1cap = getenv("MI_G1_GRID_PER_CU") ? atoi(getenv("MI_G1_GRID_PER_CU")) : 0;
+            static const int g2cap = getenv("MI_G2_GRID_PER_CU") ? atoi(getenv("MI_G2_GRID_PER_CU")) : 0;
+            const int capx = ops.xyzz_bytes == 256 ? g2cap : g1cap;
+            if (level == 0 && capx > 0) grid_cap = (u32)ctx->cu_count * (u32)capx;
+        }
         if (grid > grid_cap) grid = grid_cap;
         if (grid == 0) grid = 1;
         if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
         if (level == 0 && pts && rprime && ops.accum_affine_rp) {
             MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
-            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p, rp_partials ? 1u : 0u);
+            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p, (rp_partials ? 1u : 0u) | (knobs_of(ctx)->l1_waves == 2 ? 2u : 0u));
         } else if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else if (rp_partials) ops.accum_xyzz_rp(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
@@ -717,6 +725,11 @@ int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on) {
     if (!ctx || on > 2) return MI_EINVAL;
     knobs_of(ctx)->no_rprime = on ? 0 : 1;
     knobs_of(ctx)->std_partials = on == 2 ? 1 : 0;
+    return MI_OK;
+}
+int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves) {
+    if (!ctx || (waves != 2 && waves != 3)) return MI_EINVAL;
+    knobs_of(ctx)->l1_waves = waves;
     return MI_OK;
 }
 int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on) {

@@ -7,19 +7,21 @@
 // additions of an item in nine 29-bit limbs (162 multiplications and no carry instruction per product instead of 136 + 120;
 // lazy additions), the item's sum converted back to the standard XYZZ once at its end.  +13..16 % mixed additions per second
 // (tools/bench_limb29/madd29.hip: 13.1 against 11.3 G/s on L2-resident points, conversions included).
-// Two waves per SIMD (196 VGPRs, no scratch), not three (168 VGPRs: 504 of a SIMD's 512 registers): alone on the GPU three are 3 %
-// faster (14.0 against 13.5 G additions/s), but inside a proof they leave no room for another kernel's waves on the same SIMD and the
-// job loses 2 % (same-box A/B: 32.0 against 32.6 proofs/s) -- with two, a wave of the NTT passes (86 VGPRs) fits beside them and
-// fills the gaps their gathers leave.  Four would spill (332 B of scratch: 28.5 proofs/s).
-__global__ void __launch_bounds__(64, 2) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
-                                                           G1X *bucket, G1X *partial_out, u32 rp_partials) {
+// Built twice.  Three waves per SIMD (168 VGPRs: 504 of a SIMD's 512 registers) is the default: alone on the GPU it is the faster
+// build (14.0 against 13.5 G additions/s; N = 2^26, one proof filling the GPU: 3.86 against 3.76 proofs/s) and its launches are the
+// short ones the roofline line is quoted on.  Two waves (196 VGPRs, no scratch; flag bit 1, mi_debug_set_msm_l1_waves) leaves room for
+// a wave of the NTT passes (86 VGPRs) on the same SIMD, which fills the gaps the gathers leave: with three proofs in flight at
+// N = 2^23 the JOB is 1.7 % faster and the single-proof latency 1 ms shorter (same-box A/B 32.9-33.0 against 32.0-32.6 proofs/s) while
+// every launch of this kernel takes 8.8 instead of 5.5 ms.  Four waves would spill (332 B of scratch: 28.5 proofs/s).
+static __device__ __forceinline__ void msm_accum_affine29_body(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+                                                               G1X *bucket, G1X *partial_out, u32 rp_partials) {
     const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
     for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
         const uint4 rec = tab[item];
         const u32 key = rec.x, b = rec.y, e = rec.z;
         G1X29 acc = g1x29_inf();
-        // software pipelining: the gather of entry k + 1 is in flight while entry k is added (the kernel runs 2 waves per SIMD --
-        // 196 VGPRs -- so the ~2 us of a random 64-B HBM read are not hidden by other waves alone)
+        // software pipelining: the gather of entry k + 1 is in flight while entry k is added (the kernel runs 2 or 3 waves per SIMD --
+        // 196 / 168 VGPRs -- so the ~2 us of a random 64-B HBM read are not hidden by other waves alone)
         u32 v = sorted[b];
         const uint4 *q4 = reinterpret_cast<const uint4 *>(pts + (v & 0x7fffffffu));
         uint4 q0 = q4[0], q1 = q4[1], q2 = q4[2], q3 = q4[3];   // 64 B: x | y
@@ -39,6 +41,14 @@ __global__ void __launch_bounds__(64, 2) k_msm_accum_affine29(const G1Aff *pts, 
         else if (rp_partials) g1x29_store_rp(acc, reinterpret_cast<u32 *>(partial_out + item));
         else partial_out[item] = g1x29_to_std(acc);
     }
+}
+__global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+                                                           G1X *bucket, G1X *partial_out, u32 rp_partials) {
+    msm_accum_affine29_body(pts, sorted, tab, item_start, nkeys, bucket, partial_out, rp_partials);
+}
+__global__ void __launch_bounds__(64, 2) k_msm_accum_affine29_w2(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+                                                              G1X *bucket, G1X *partial_out, u32 rp_partials) {
+    msm_accum_affine29_body(pts, sorted, tab, item_start, nkeys, bucket, partial_out, rp_partials);
 }
 // Levels >= 2 of the item machinery over partial sums in the packed R' form: k_msm_accum_xyzz's decomposition, the additions in
 // nine 29-bit limbs (g1x29_add), no conversion on the way in, one on the way out only for a bucket's final sum.
@@ -62,8 +72,11 @@ static void launch_accum_xyzz29(hipStream_t st, unsigned grid, const void *pin, 
 static void launch_accum_affine29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
                                   const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab, u32 rp_partials) {
     hipLaunchKernelGGL(k_msm_item_table<Fp>, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
-    hipLaunchKernelGGL(k_msm_accum_affine29, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
-                       (G1X *)bucket, (G1X *)pout, rp_partials);
+    // rp_partials: bit 0 = partial sums stay in the R' form, bit 1 = the two-waves-per-SIMD build
+    if (rp_partials & 2) hipLaunchKernelGGL(k_msm_accum_affine29_w2, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
+                                            (G1X *)bucket, (G1X *)pout, rp_partials & 1u);
+    else hipLaunchKernelGGL(k_msm_accum_affine29, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
+                            (G1X *)bucket, (G1X *)pout, rp_partials & 1u);
 }
 __global__ void k_g1_to_rprime(G1Aff *dst, const G1Aff *src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -354,6 +354,10 @@ int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on);
  * the matching packed form) and the G1 partial sums between the levels stay in that form; 2: the same level 1 with standard-form
  * partial sums; 0: the 8 x 32-bit kernels everywhere.  Set before mi_pk_load; parity tests run all three. */
 int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on);
+/* 3 (default) or 2: which build of the G1 level-1 29-bit kernel runs -- three waves per SIMD (fastest alone, shortest launches) or two
+ * (leaves registers for other kernels' waves on the same SIMD: +1.7 % proofs/s with three proofs in flight at N = 2^23, slower when
+ * one proof fills the GPU).  Same results. */
+int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves);
 /* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
  * running; 0 disarms.  Used to prove that init / load / prove unwind without leaks or crashes. */
 int32_t mi_debug_inject_hip_failure(int32_t nth);

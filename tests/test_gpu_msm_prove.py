@@ -420,8 +420,9 @@ def test_limb29_level1_kernel_on_and_off_agree_with_oracle(ctx):
     p2[3] = 0; p2[6] = p2[5]; s2[6] = s2[5]; p2[8] = g2_arr([P.g2_neg(g2_pts(p2[7:8])[0])])[0]; s2[8] = s2[7]; p2[40:60] = p2[39]
     want_msm2 = cref.msm_g2(p2, s2)
     try:
-        for on in (1, 2, 0):
-            assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, on) == 0
+        for on in (1, 2, 0, 3):   # 3: the default arithmetic with the level-1 kernel's two-waves-per-SIMD build
+            assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1 if on == 3 else on) == 0
+            assert ctx.lib.mi_debug_set_msm_l1_waves(ctx.h, 2 if on == 3 else 3) == 0
             for knob in ((0, 0, 0), (17, 18, 17)):
                 assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0
                 pkh = ctx.pk_load(pk)
@@ -432,6 +433,7 @@ def test_limb29_level1_kernel_on_and_off_agree_with_oracle(ctx):
             assert np.array_equal(ctx.msm_g2(p2, s2), want_msm2), on
     finally:
         assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
+        assert ctx.lib.mi_debug_set_msm_l1_waves(ctx.h, 3) == 0
 
 
 @pytest.mark.parametrize("g2,n", [(False, 65535), (False, 65536), (False, 65537), (False, 100003), (True, 16383), (True, 16384), (True, 16385), (True, 20011)])
