@@ -75,3 +75,14 @@ def test_host_pedersen_fold_matches_oracle():
     pts = cref.gen_g1(4, 81); ch = cref.gen_scalars(1, 82, 0)[0]
     assert np.array_equal(B.pedersen_fold(pts, ch), cref.pedersen_fold(pts, ch))
     assert np.array_equal(B.pedersen_fold(pts[:1], ch), pts[0])          # challenge^0 = 1
+
+
+def test_bench_refuses_to_run_without_a_gpu_and_its_helper_idles_quietly():
+    """bench.py has no CPU path (it must say so, not fall back), and its sharded-MSM helper process -- started before the parent touches
+    the GPU -- ends without a word when the parent never sends it work"""
+    import subprocess, sys
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--sharded-helper"], stdin=subprocess.DEVNULL, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, bench, "--steps", "1", "--warmup", "0", "--sharded-msm-log-n", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "no CPU path" in (r.stderr + r.stdout)
