@@ -24,6 +24,7 @@ struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
     u32 no_rprime = 0;                          // 1: G1 level 1 stays on the 8 x 32-bit kernel everywhere (tests compare both)
     u32 l1_waves = 3;                           // G1 level-1 29-bit kernel: the build for 3 (default) or 2 waves per SIMD (msm_g1.hip)
+    u32 precompute_unbatched = 0;               // 1: window tables by the one-kernel form (one inversion per point per window)
     u32 std_partials = 0;                       // 1: partial sums between the levels in the standard form even after a 29-bit level 1
     u32 one_pass_sort = 0;                      // 1: large generic MSMs keep the one-pass counting sort (tests compare both)
     u32 chunk = 0;                              // fixed-base sort: entries per pass-2 chunk (tests shrink it)
@@ -598,8 +599,19 @@ static int32_t msm_finish(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, void
 int32_t mi_msm_precompute(mi_ctx *ctx, int curve, const void *base_dev, void *pre_dev, size_t n, uint32_t c) {
     if (!ctx || !base_dev || !pre_dev || c < 17 || c > 22 || n >= ((size_t)1 << 31)) return MI_EINVAL;
     const MsmCurveOps &ops = curve == 1 ? msm_g1_ops() : msm_g2_ops();
-    if (n) ops.precompute(ctx->stream, base_dev, pre_dev, (u32)n, c, (256 + c - 1) / c);
-    MI_CHECK_HIP(ctx, hipGetLastError());
+    if (!n) return MI_OK;
+    // batched conversions (one inversion per 16 points per window instead of one per point: ~2.7x less work) need n XYZZ + n coordinates
+    // of scratch for the duration of the build; without room for them the one-kernel form runs
+    void *state = nullptr, *prefix = nullptr;
+    const bool batched = !knobs_of(ctx)->precompute_unbatched && hipMalloc(&state, n * ops.xyzz_bytes) == hipSuccess && hipMalloc(&prefix, n * ops.coord_bytes) == hipSuccess;
+    if (!batched) (void)hipGetLastError();
+    if (batched) ops.precompute_batched(ctx->stream, base_dev, pre_dev, (u32)n, c, (256 + c - 1) / c, state, prefix);
+    else ops.precompute(ctx->stream, base_dev, pre_dev, (u32)n, c, (256 + c - 1) / c);
+    hipError_t e = hipGetLastError();
+    if (batched && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // the scratch goes away below
+    if (state) (void)hipFree(state);
+    if (prefix) (void)hipFree(prefix);
+    MI_CHECK_HIP(ctx, e);
     return MI_OK;
 }
 int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
@@ -725,6 +737,11 @@ int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on) {
     if (!ctx || on > 2) return MI_EINVAL;
     knobs_of(ctx)->no_rprime = on ? 0 : 1;
     knobs_of(ctx)->std_partials = on == 2 ? 1 : 0;
+    return MI_OK;
+}
+int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on) {
+    if (!ctx || on > 1) return MI_EINVAL;
+    knobs_of(ctx)->precompute_unbatched = on ? 0 : 1;
     return MI_OK;
 }
 int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves) {

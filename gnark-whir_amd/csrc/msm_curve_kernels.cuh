@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "msm2_core.cuh"
 #include "msm_curve_ops.h"
+#include "batch_affine.cuh"
 
 // Occupancy target per curve (measured with tools/bench_g2 on MI355X): the G1 mixed add needs ~60 VGPRs and runs
 // 8 waves/SIMD; the G2 one wants > 256 -- 2 waves/SIMD with the Fp multiplier out of line (480 B of scratch) is the

@@ -17,6 +17,9 @@ struct MsmCurveOps {
     uint32_t sum_T;
     void (*sum_tree)(hipStream_t st, unsigned nout, unsigned nwin, const void *in, uint32_t n, void *out);
     void (*precompute)(hipStream_t st, const void *base, void *pre, uint32_t n, uint32_t c, uint32_t nwin);   // fixed-base window copies
+    // the same copies with one inversion per 16 points instead of one per point (batch_affine.cuh); state: n XYZZ, prefix: n coordinates of scratch
+    void (*precompute_batched)(hipStream_t st, const void *base, void *pre, uint32_t n, uint32_t c, uint32_t nwin, void *state, void *prefix);
+    size_t coord_bytes;   // sizeof(F): 32 (G1) / 64 (G2)
     // total = sum_w 2^(c*w) * wsum[w] on the host; nwin == 0 yields the point at infinity
     void (*combine_windows)(const void *host_wsum, uint32_t nwin, uint32_t c, void *out_xyzz);
     // own[i] += sum_p recv[p * own_len + i]  (XYZZ; bucket slices received from the other devices of a sharded MSM)

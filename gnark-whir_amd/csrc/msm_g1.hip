@@ -89,6 +89,6 @@ static void launch_to_rprime(hipStream_t st, void *dst, const void *src, size_t 
 }
 
 const MsmCurveOps &msm_g1_ops() {
-    static const MsmCurveOps ops = {sizeof(G1X), launch_accum_affine<Fp>, launch_accum_xyzz<Fp>, launch_bucket_reduce<Fp>, SumT<Fp>::value, launch_sum_tree<Fp>, launch_precompute<Fp>, host_combine_windows<Fp>, launch_sum_slices<Fp>, launch_accum_affine29, launch_accum_xyzz29, launch_to_rprime};
+    static const MsmCurveOps ops = {sizeof(G1X), launch_accum_affine<Fp>, launch_accum_xyzz<Fp>, launch_bucket_reduce<Fp>, SumT<Fp>::value, launch_sum_tree<Fp>, launch_precompute<Fp>, launch_precompute_batched<Fp>, sizeof(Fp), host_combine_windows<Fp>, launch_sum_slices<Fp>, launch_accum_affine29, launch_accum_xyzz29, launch_to_rprime};
     return ops;
 }

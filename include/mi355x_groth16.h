@@ -358,6 +358,9 @@ int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on);
  * (leaves registers for other kernels' waves on the same SIMD: +1.7 % proofs/s with three proofs in flight at N = 2^23, slower when
  * one proof fills the GPU).  Same results. */
 int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves);
+/* on = 1 (default): the fixed-base window tables of mi_pk_load / mi_msm_precompute_* convert to affine with one inversion per 16 points
+ * (needs n XYZZ + n coordinates of scratch while building; falls back by itself without room); 0: one inversion per point.  Same tables. */
+int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
 /* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
  * running; 0 disarms.  Used to prove that init / load / prove unwind without leaks or crashes. */
 int32_t mi_debug_inject_hip_failure(int32_t nth);

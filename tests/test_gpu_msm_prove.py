@@ -447,3 +447,30 @@ def test_msm_around_the_limb29_thresholds(ctx, g2, n):
     else:
         pts = cref.gen_g1(n, 3400 + n); pts[3] = 0; pts[6] = pts[5]; sc[6] = sc[5]; pts[8] = g1_arr([P.g1_neg(g1_pts(pts[7:8])[0])])[0]; sc[8] = sc[7]
         assert np.array_equal(ctx.msm_g1(pts, sc), cref.msm_g1(pts, sc))
+
+
+@pytest.mark.parametrize("g2,n,c", [(False, 1, 17), (False, 1000, 20), (False, 4099, 19), (True, 777, 17)])
+def test_window_tables_batched_and_per_point_conversions_are_identical(ctx, g2, n, c):
+    """mi_msm_precompute: the tables built with one inversion per 16 points per window (default) and with one per point have the same
+    bytes -- infinity bases, a ragged tail (n not a multiple of 16), both curves; a row of the table against the oracle's scalar
+    multiplication"""
+    pts = cref.gen_g2(n, 2100 + n) if g2 else cref.gen_g1(n, 2000 + n)
+    if n > 20:
+        pts[0] = 0; pts[17] = 0; pts[n - 1] = 0; pts[5] = pts[4]
+    dp = ctx.to_dev(pts)
+    nwin = (256 + c - 1) // c
+    tabs = []
+    try:
+        for on in (1, 0):
+            assert ctx.lib.mi_debug_set_msm_precompute_batched(ctx.h, on) == 0
+            pre = ctx.msm_precompute(dp.ptr, n, c, g2=g2)
+            tabs.append(pre.download((nwin * n, 16 if g2 else 8)))
+            pre.free()
+    finally:
+        assert ctx.lib.mi_debug_set_msm_precompute_batched(ctx.h, 1) == 0
+    assert np.array_equal(tabs[0], tabs[1])
+    assert np.array_equal(tabs[0][:n], pts)
+    if not g2:
+        i = min(3, n - 1)
+        assert np.array_equal(tabs[0][(nwin - 1) * n + i], cref.g1_scalar_mul(pts[i], 1 << (c * (nwin - 1))))
+    dp.free()
