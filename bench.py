@@ -32,6 +32,25 @@ def _binding():
     return mod
 
 
+def _sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def _last_commit(rel):
+    """hash of the last commit that touched `rel` (None where there is no git history, e.g. on the GPU box's snapshot: the sha256 of
+    the file's bytes next to it identifies the file there)"""
+    import subprocess
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "log", "-n", "1", "--format=%h", "--", rel], capture_output=True, text=True, timeout=10)
+        return out.stdout.strip() or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(pk_host, W, a, b, c, r, s, log_n, gpu_proof_bytes):
     """Times the oracle's prove (oracle/groth16_ref.c, OpenMP, all host cores) ON THE BENCHMARKED WORKLOAD ITSELF -- the
     same key, witness, solution vectors and (r, s) the GPU proofs above used, downloaded from the device -- and compares
@@ -58,43 +77,131 @@ def cpu_baseline(pk_host, W, a, b, c, r, s, log_n, gpu_proof_bytes):
             "proof_bytes_match": True}
 
 
-def sharded_msm_section(B, rank, local_rank, world, uid, log_n_msm, steps):
+def sharded_msm_section(B, g, rank, world, log_n_msm, steps):
     """BASELINE configs[4]: ONE G1 MSM of 2^log_n_msm pairs, bases point-sharded over the ranks (one per GPU), through the C-ABI's
-    device group (mi_group_create_rank + mi_msm_g1_sharded_dev, csrc/group.hip): mode 0 = all-gather of per-rank partial sums,
+    device group g (mi_group_create_rank + mi_msm_g1_sharded_dev, csrc/group.hip): mode 0 = all-gather of per-rank partial sums,
     mode 1 = reduce-scatter of bucket sums (grouped ncclSend / ncclRecv) before the bucket reduce.  Strong scaling: total work
     fixed.  Runs in the HELPER PROCESS (see main): no torch, no torch.distributed -- the ranks meet in the group's own collectives;
     returns this rank's seconds per mode, the caller takes the maximum over the ranks."""
     import numpy as np
-    g = B.Group.rank(local_rank, rank, world, uid)
-    try:
-        n = 1 << log_n_msm
-        lo, hi = B.shard_range(n, world, rank)
-        c = g.ctx(0)
-        pts = c.gen_g1(hi - lo, 4242 + 17 * rank); sc = c.gen_scalars(hi - lo, 2424 + 17 * rank, 0)
+    n = 1 << log_n_msm
+    lo, hi = B.shard_range(n, world, rank)
+    c = g.ctx(0)
+    pts = c.gen_g1(hi - lo, 4242 + 17 * rank); sc = c.gen_scalars(hi - lo, 2424 + 17 * rank, 0)
+    c.sync()
+    out = {}
+    for mode in (0, 1):
+        ref = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)   # warm-up: sizes the workspaces, and lines the ranks up
         c.sync()
-        out = {}
-        for mode in (0, 1):
-            ref = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)   # warm-up: sizes the workspaces, and lines the ranks up
-            c.sync()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                got = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)
-            c.sync()
-            dt = time.perf_counter() - t0
-            assert np.array_equal(got, ref)
-            out[mode] = (got, dt)
-        res = {"transport": g.transport(), "steps": steps, "dt0": out[0][1], "dt1": out[1][1], "modes_agree": bool(np.array_equal(out[0][0], out[1][0]))}
-        pts.free(); sc.free()
-        return res
-    finally:
-        g.close()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            got = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)
+        c.sync()
+        dt = time.perf_counter() - t0
+        assert np.array_equal(got, ref)
+        out[mode] = (got, dt)
+    res = {"steps": steps, "dt0": out[0][1], "dt1": out[1][1], "modes_agree": bool(np.array_equal(out[0][0], out[1][0]))}
+    pts.free(); sc.free()
+    return res
+
+
+def sharded_prove_section(B, g, rank, world, log_n, steps):
+    """BASELINE configs[4] as north_star states it: ONE groth16.Prove of an N = 2^log_n circuit over the ranks of the group
+    (mi_pk_load_sharded_dev + mi_groth16_prove_sharded_dev, csrc/group.hip): every rank keeps its slice of pk.G1.{A,B,K,Z} / pk.G2.B
+    (generated on its own device), rank 0 runs computeH and hands out h slices over the group's transport, the MSMs run point-sharded,
+    mode 0 combines per-rank partial sums, mode 1 reduce-scatters bucket sums first.  Inputs resident in HBM.  Strong scaling.
+    Validity: (1) a small key (N = 2^16, the SAME on every rank) proved sharded in both modes must give the bytes of the unsharded
+    mi_groth16_prove on this rank's own device; (2) at N = 2^log_n both modes must give the same bytes, and with one rank those of the
+    unsharded prove of the same key."""
+    import numpy as np
+    c = g.ctx(0)
+    out = {}
+
+    def masks(nb_wires, seed):
+        rng = np.random.default_rng(seed)
+        return (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8), (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
+
+    # ---- (1) small parity: whole key on every rank (device generators, same seeds), host arrays -> mi_pk_load_sharded
+    ls = 16
+    Ns = 1 << ls
+    nw, npub, ncs = Ns - 50, 300, Ns - 10
+    ia, ib = masks(nw, 99)
+    na, nb, nk = int((ia == 0).sum()), int((ib == 0).sum()), nw - npub
+
+    def pull(d, shape):
+        o = d.download(shape); d.free(); return o
+    small = pull(c.gen_g1(3, 206), (3, 8)); small2 = pull(c.gen_g2(2, 207), (2, 16))
+    pk = {"log_n": ls, "nb_public": npub, "nb_wires": nw, "g1_a": pull(c.gen_g1(na, 201), (na, 8)), "g1_b": pull(c.gen_g1(nb, 202), (nb, 8)),
+          "g1_k": pull(c.gen_g1(nk, 203), (nk, 8)), "g1_z": pull(c.gen_g1(Ns, 204), (Ns, 8)), "g2_b": pull(c.gen_g2(nb, 205), (nb, 16)),
+          "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": ia, "infinity_b": ib}
+    W = pull(c.gen_scalars(nw, 208, 1), (nw, 4)); a = pull(c.gen_scalars(ncs, 209, 1), (ncs, 4)); b = pull(c.gen_scalars(ncs, 210, 0), (ncs, 4))
+    cc = c.field_op(0, 2, a, b)
+    rs = pull(c.gen_scalars(2, 211, 0), (2, 4))
+    pkh = c.pk_load(pk)
+    want = B.proof_write(c.prove(pkh, W, a, b, cc, rs[0], rs[1])[0]["raw"])
+    c.pk_free(pkh)
+    spk = g.pk_load(pk)
+    small_ok = all(B.proof_write(g.prove(spk, W, a if rank == 0 else None, b if rank == 0 else None, cc if rank == 0 else None, rs[0], rs[1], mode=m)[0]["raw"]) == want
+                   for m in (0, 1))
+    g.pk_free(spk)
+    out["small_parity"] = {"log_n": ls, "sharded_equals_unsharded_both_modes": bool(small_ok)}
+    if not small_ok:
+        raise RuntimeError("sharded proof of the small key differs from the unsharded proof")
+
+    # ---- (2) the big proof: every rank generates ITS slices on its device
+    N = 1 << log_n
+    nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
+    seed = 0x57484952 + 4
+    ia, ib = masks(nb_wires, seed)
+    lo, hi = B.shard_range(nb_wires, world, rank); zlo, zhi = B.shard_range(N - 1, world, rank)
+    na, nb = int((ia[lo:hi] == 0).sum()), int((ib[lo:hi] == 0).sum())
+    nk = max(hi, nb_public) - max(lo, nb_public)
+    rseed = seed + 1000 * rank
+    arrs = {"g1_a": (c.gen_g1(na, rseed + 1), na), "g1_b": (c.gen_g1(nb, rseed + 2), nb), "g1_k": (c.gen_g1(nk, rseed + 3), nk),
+            "g1_z": (c.gen_g1(zhi - zlo, rseed + 4), zhi - zlo), "g2_b": (c.gen_g2(nb, rseed + 5), nb)}
+    hdr = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "alpha1": small[0], "beta1": small[1], "delta1": small[2],
+           "beta2": small2[0], "delta2": small2[1], "infinity_a": ia, "infinity_b": ib}
+    Wd = c.gen_scalars(hi - lo, rseed + 8, 1)
+    da = db = dc = None
+    if rank == 0:
+        da = c.gen_scalars(n_constraints, seed + 9, 1); db = c.gen_scalars(n_constraints, seed + 10, 0); dc = c.alloc(32 * n_constraints)
+        c.field_op_dev(0, 2, dc.ptr, da.ptr, db.ptr, n_constraints)
+    c.sync()
+    ptr = lambda d: None if d is None else d.ptr
+    unsharded = None
+    if world == 1:   # the same key through the unsharded entry points first (both keys at once would not fit at N = 2^26)
+        full = dict(hdr); full.update({k: (v[0].ptr, v[1]) for k, v in arrs.items()})
+        pkh = c.pk_load(full, device_points=True)
+        unsharded = B.proof_write(c.prove(pkh, Wd.ptr, da.ptr, db.ptr, dc.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)[0]["raw"])
+        c.pk_free(pkh)
+    t0 = time.perf_counter()
+    spk = g.pk_load_dev(hdr, [{k: (v[0].ptr, v[1]) for k, v in arrs.items()}])
+    out["pk_load_sharded_s"] = time.perf_counter() - t0
+    got = {}
+    for mode in (0, 1):
+        pr, _ = g.prove_dev(spk, [Wd.ptr], nb_wires, ptr(da), ptr(db), ptr(dc), n_constraints, rs[0], rs[1], mode=mode)   # warm-up: sizes the workspaces, lines the ranks up
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pr, st = g.prove_dev(spk, [Wd.ptr], nb_wires, ptr(da), ptr(db), ptr(dc), n_constraints, rs[0], rs[1], mode=mode)
+        got[mode] = (B.proof_write(pr["raw"]), time.perf_counter() - t0, st)
+    g.pk_free(spk)
+    for d in [v[0] for v in arrs.values()] + [Wd, da, db, dc]:
+        if d is not None:
+            d.free()
+    out.update({"log_n": log_n, "steps": steps, "dt0": got[0][1], "dt1": got[1][1], "modes_agree": got[0][0] == got[1][0],
+                "equals_unsharded": None if unsharded is None else bool(got[0][0] == unsharded),
+                "compute_h_ms_on_rank0": got[0][2]["compute_h_ms"] if rank == 0 else None})
+    if not out["modes_agree"] or out["equals_unsharded"] is False:
+        raise RuntimeError("sharded proofs disagree (mode 0 vs mode 1, or sharded vs unsharded)")
+    return out
 
 
 def sharded_helper_main():
     """`bench.py --sharded-helper`: started by main() BEFORE the parent touches the GPU (a process that has initialised the GPU must not
-    exec), idle until the parent writes one JSON line of parameters, then runs the point-sharded MSM on its own GPU context and
-    answers with one JSON line.  A fault or a stuck collective in this never-before-multi-GPU path then costs the parent nothing
-    but the `sharded_msm` block of its line."""
+    exec), idle until the parent writes one JSON line of parameters, then runs the multi-GPU legs on its own GPU context -- the
+    transport self-test first (a broken communicator is diagnosed, not timed out), the point-sharded MSM, the point-sharded PROVE --
+    and answers with one JSON line.  A fault or a stuck collective in these never-before-multi-GPU paths then costs the parent
+    nothing but the `sharded_*` blocks of its line."""
     req = sys.stdin.readline()
     if not req.strip():
         return
@@ -103,13 +210,114 @@ def sharded_helper_main():
         os.abort()
     if os.environ.get("MI_BENCH_HELPER_FAULT") == "hang":
         time.sleep(10000)
+    res = {"ok": False, "selftest": "not run"}
+    g = None
     try:
         B = _binding()
-        res = sharded_msm_section(B, q["rank"], q["local_rank"], q["world"], bytes.fromhex(q["uid"]), q["log_n"], q["steps"])
-        res["ok"] = True
+        g = B.Group.rank(q["local_rank"], q["rank"], q["world"], bytes.fromhex(q["uid"]))
+        try:
+            g.exchange_selftest(1 << 20)
+            res["selftest"] = "ok"
+        except BaseException as e:
+            res["selftest"] = f"FAILED: {e}"
+            raise
+        res["transport"] = g.transport()
+        if q["log_n"]:
+            res["msm"] = sharded_msm_section(B, g, q["rank"], q["world"], q["log_n"], q["steps"])
+        res["ok"] = True   # the MSM block is valid from here on, whatever the prove leg does
+        if q.get("prove_log_n"):
+            try:
+                res["prove"] = sharded_prove_section(B, g, q["rank"], q["world"], q["prove_log_n"], q["prove_steps"])
+                res["prove"]["ok"] = True
+            except BaseException as e:
+                res["prove"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
     except BaseException as e:
-        res = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+        res["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        if g is not None:
+            g.close()
     print(json.dumps(res), flush=True)
+
+
+def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
+    """configs[4] through the C-ABI's device group (RCCL), in the helper process started at the top of main(): the transport self-test,
+    one G1 MSM point-sharded over the ranks, and ONE PROOF point-sharded over the ranks.  Bounded by a watchdog: a stuck collective or
+    a fault there must not cost the run its proofs/s line.  Called after this process has released its own pool, key and buffers
+    (an N = 2^26 proof wants most of a GPU)."""
+    import threading
+    sharded, sharded_prove = {"done": False}, {"done": False}
+    uid = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        uid = torch.tensor(list(B.Group.unique_id()), dtype=torch.uint8)
+    if dist is not None:
+        t = uid.to(torch.device("cuda", local_rank)); dist.broadcast(t, src=0); uid = t.cpu()
+        dist.barrier()
+    steps_msm, steps_prove = 3, 3
+    answer = {}
+
+    def ask():
+        try:
+            helper.stdin.write(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "uid": bytes(uid.tolist()).hex(),
+                                           "log_n": args.sharded_msm_log_n, "steps": steps_msm,
+                                           "prove_log_n": args.sharded_prove_log_n, "prove_steps": steps_prove}) + "\n")
+            helper.stdin.flush()
+            while True:   # the answer is the first line that is a JSON object (anything a library prints before it is skipped)
+                ln = helper.stdout.readline()
+                if not ln or ln.lstrip().startswith("{"):
+                    break
+            answer["line"] = ln
+        except BaseException as e:
+            answer["line"] = json.dumps({"ok": False, "error": f"{type(e).__name__}: {e}"})
+    th = threading.Thread(target=ask, daemon=True)
+    th.start()
+    watchdog_s = 360
+    th.join(timeout=watchdog_s)
+    res = {"ok": False, "error": f"timeout after {watchdog_s} s (collective stuck?)"}
+    if th.is_alive():
+        helper.kill()
+    else:
+        try:
+            res = json.loads(answer.get("line") or "") if (answer.get("line") or "").strip() else {"ok": False, "error": "helper ended without an answer"}
+        except ValueError:
+            res = {"ok": False, "error": "helper answered garbage"}
+    m, pv = res.get("msm") or {}, res.get("prove") or {}
+    ok = 1.0 if res.get("ok") and m else 0.0
+    okp = 1.0 if pv.get("ok") else 0.0
+    v = [ok, float(m.get("dt0", 0.0)), float(m.get("dt1", 0.0)), 1.0 if m.get("modes_agree") else 0.0]
+    w = [okp, float(pv.get("dt0", 0.0)), float(pv.get("dt1", 0.0))]
+    if dist is not None:   # every rank takes part, whatever its helper did: all ok?  slowest rank's times; all agree?
+        tmin = torch.tensor([v[0], v[3], w[0]], device="cuda", dtype=torch.float64); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        tmax = torch.tensor([v[1], v[2], w[1], w[2]], device="cuda", dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        v = [float(tmin[0]), float(tmax[0]), float(tmax[1]), float(tmin[1])]
+        w = [float(tmin[2]), float(tmax[2]), float(tmax[3])]
+    n_msm = 1 << args.sharded_msm_log_n
+    sharded["selftest"] = sharded_prove["selftest"] = res.get("selftest", "not run")
+    if v[0] == 1.0 and v[1] > 0 and v[2] > 0:
+        sharded.update({"workload": f"one G1 MSM, 2^{args.sharded_msm_log_n} uniform pairs, bases point-sharded over {world} rank(s) (BASELINE configs[4])",
+                        "scaling": "strong", "transport": res.get("transport"), "steps": steps_msm, "process": "helper process per rank (own GPU context)",
+                        "mode0_partial_sums_pts_per_s": n_msm * steps_msm / v[1], "mode0_ms": v[1] / steps_msm * 1e3,
+                        "mode1_bucket_exchange_pts_per_s": n_msm * steps_msm / v[2], "mode1_ms": v[2] / steps_msm * 1e3,
+                        "modes_agree": v[3] == 1.0, "done": True})
+    else:
+        sharded["error"] = res.get("error", "a rank's helper failed")
+    if w[0] == 1.0 and w[1] > 0 and w[2] > 0:
+        sharded_prove.update({"workload": f"ONE Groth16 proof, FFT domain N=2^{args.sharded_prove_log_n}, WHIR-verifier-shaped synthetic key point-sharded over {world} rank(s): "
+                                          "slice r of pk.G1.{A,B,K,Z} / pk.G2.B resident on rank r, computeH on rank 0, h slices over the group's transport (BASELINE configs[4])",
+                              "scaling": "strong", "transport": res.get("transport"), "steps": steps_prove, "inputs": "resident in HBM (mi_groth16_prove_sharded_dev)",
+                              "mode0_partial_sums_ms_per_proof": w[1] / steps_prove * 1e3, "mode0_proofs_per_s": steps_prove / w[1],
+                              "mode1_bucket_exchange_ms_per_proof": w[2] / steps_prove * 1e3, "mode1_proofs_per_s": steps_prove / w[2],
+                              "modes_agree": pv.get("modes_agree"), "equals_unsharded_prove": pv.get("equals_unsharded"),
+                              "small_parity": pv.get("small_parity"), "compute_h_ms_on_rank0": pv.get("compute_h_ms_on_rank0"),
+                              "pk_load_sharded_s": pv.get("pk_load_sharded_s"),
+                              "note": "ranks on distinct devices have only ever run if n_gpus > 1 in this line; with n_gpus = 1 this is the same code path over a world-1 RCCL communicator",
+                              "done": True})
+    else:
+        sharded_prove["error"] = pv.get("error") or res.get("error", "a rank's helper failed")
+    try:
+        helper.stdin.close(); helper.wait(timeout=10)
+    except BaseException:
+        helper.kill()
+    return sharded, sharded_prove
 
 
 def main():
@@ -132,6 +340,7 @@ def main():
     ap.add_argument("--g1-waves", type=int, default=3, choices=(2, 3), help="tuning: build of the G1 level-1 kernel (mi_debug_set_msm_l1_waves): 3 waves per SIMD (default) or 2")
     ap.add_argument("--msm-chunk", type=int, default=0, help="tuning: mi_debug_set_msm_chunk on every context")
     ap.add_argument("--sharded-msm-log-n", type=int, default=26, help="configs[4]: size of the point-sharded G1 MSM run after the proofs (0 = skip)")
+    ap.add_argument("--sharded-prove-log-n", type=int, default=26, help="configs[4]: FFT domain of the ONE proof point-sharded over the ranks, run after the proofs (0 = skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank control-flow rehearsal on a 1-GPU box: every rank uses device 0 and the collectives run over gloo")
     ap.add_argument("--sharded-helper", action="store_true", help=argparse.SUPPRESS)
@@ -140,7 +349,7 @@ def main():
         return sharded_helper_main()
     # the point-sharded MSM leg runs in a helper process of its own; it is started NOW, before anything here touches the GPU
     helper = None
-    if args.sharded_msm_log_n and not args.rehearse_on_one_gpu:
+    if (args.sharded_msm_log_n or args.sharded_prove_log_n) and not args.rehearse_on_one_gpu:
         import subprocess
         helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--sharded-helper"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 
@@ -281,62 +490,6 @@ def main():
                 raise SystemExit("bench.py: a host-input proof differs from the device-input proof of the same inputs")
         host_rate, host_ms = args.steps * world / dth, dth / args.steps * 1e3
 
-    # configs[4]: one G1 MSM point-sharded over the ranks through the C-ABI's device group (RCCL), in the helper process started at
-    # the top; bounded by a watchdog: a stuck collective or a fault there must not cost the run its proofs/s line.
-    sharded = {"done": False}
-    if helper is not None:
-        import threading
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            uid = torch.tensor(list(B.Group.unique_id()), dtype=torch.uint8)
-        if dist is not None:
-            t = uid.to(torch.device("cuda", local_rank)); dist.broadcast(t, src=0); uid = t.cpu()
-            dist.barrier()
-        steps_msm = 3
-        answer = {}
-        def ask():
-            try:
-                helper.stdin.write(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "uid": bytes(uid.tolist()).hex(),
-                                               "log_n": args.sharded_msm_log_n, "steps": steps_msm}) + "\n")
-                helper.stdin.flush()
-                while True:   # the answer is the first line that is a JSON object (anything a library prints before it is skipped)
-                    ln = helper.stdout.readline()
-                    if not ln or ln.lstrip().startswith("{"):
-                        break
-                answer["line"] = ln
-            except BaseException as e:
-                answer["line"] = json.dumps({"ok": False, "error": f"{type(e).__name__}: {e}"})
-        th = threading.Thread(target=ask, daemon=True)
-        th.start()
-        th.join(timeout=150)
-        res = {"ok": False, "error": "timeout after 150 s (collective stuck?)"}
-        if th.is_alive():
-            helper.kill()
-        else:
-            try:
-                res = json.loads(answer.get("line") or "") if (answer.get("line") or "").strip() else {"ok": False, "error": "helper ended without an answer"}
-            except ValueError:
-                res = {"ok": False, "error": "helper answered garbage"}
-        ok = 1.0 if res.get("ok") else 0.0
-        v = [ok, float(res.get("dt0", 0.0)), float(res.get("dt1", 0.0)), 1.0 if res.get("modes_agree") else 0.0]
-        if dist is not None:   # every rank takes part, whatever its helper did: all ok?  slowest rank's times; all agree?
-            tmin = torch.tensor([v[0], v[3]], device="cuda", dtype=torch.float64); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-            tmax = torch.tensor([v[1], v[2]], device="cuda", dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            v = [float(tmin[0]), float(tmax[0]), float(tmax[1]), float(tmin[1])]
-        n_msm = 1 << args.sharded_msm_log_n
-        if v[0] == 1.0 and v[1] > 0 and v[2] > 0:
-            sharded.update({"workload": f"one G1 MSM, 2^{args.sharded_msm_log_n} uniform pairs, bases point-sharded over {world} rank(s) (BASELINE configs[4])",
-                            "scaling": "strong", "transport": res.get("transport"), "steps": steps_msm, "process": "helper process per rank (own GPU context)",
-                            "mode0_partial_sums_pts_per_s": n_msm * steps_msm / v[1], "mode0_ms": v[1] / steps_msm * 1e3,
-                            "mode1_bucket_exchange_pts_per_s": n_msm * steps_msm / v[2], "mode1_ms": v[2] / steps_msm * 1e3,
-                            "modes_agree": v[3] == 1.0, "done": True})
-        else:
-            sharded["error"] = res.get("error", "a rank's helper failed")
-        try:
-            helper.stdin.close(); helper.wait(timeout=10)
-        except BaseException:
-            helper.kill()
-
     # the same kernel measured alone (no other stream competing for the CUs): one uniform-scalar G1 MSM over pk.G1.Z
     solo = None
     if rank == 0:
@@ -364,6 +517,37 @@ def main():
         gtab = ctx.alloc(64 << 27)
         gather_ms = min(ctx.bench_gather(gtab.ptr, 1 << 27, 256 * 4 * 64 * 4, 128) for _ in range(3))
         gtab.free()
+    # HBM ledger while everything of the proofs/s run is still resident (key + tables, every context's workspaces, inputs)
+    hbm_in_use_gb = (lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info())
+    hbm_ledger = None
+    if rank == 0:
+        hbm_ledger = ctx.mem_ledger(pkh)   # the key + context 0; the other contexts of the pool add their own workspaces
+        for i in range(1, pool.in_flight):
+            for k, v in pool.ctx(i).mem_ledger().items():
+                if k.startswith("ctx_"):
+                    hbm_ledger[k] += v
+        hbm_ledger["pool_contexts"] = pool.in_flight
+        hbm_ledger["pool_input_sets_gb"] = (pool.in_flight + 1) * (nb_wires + 3 * n_constraints) * 32 / 1e9 if not args.no_host_inputs else 0.0
+        hbm_ledger["bench_inputs_gb"] = (nb_wires + 3 * n_constraints) * 32 / 1e9
+        hbm_ledger["bench_key_source_arrays_gb"] = ((na + nb + nk + N) * 64 + nb * 128) / 1e9   # the caller's bases (mi_pk_load_dev adopts by reference)
+    # inputs of the CPU baseline leave the device before it is emptied for the sharded legs
+    cpu_inputs = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        dl = lambda d, n, k: d.download((n, k))
+        pk_host = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": dl(g1a, na, 8), "g1_b": dl(g1b, nb, 8),
+                   "g1_k": dl(g1k, nk, 8), "g1_z": dl(g1z, N, 8), "g2_b": dl(g2b, nb, 16), "alpha1": small[0], "beta1": small[1],
+                   "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b}
+        cpu_inputs = (pk_host, dl(W, nb_wires, 4), dl(a, n_constraints, 4), dl(b, n_constraints, 4), dl(c, n_constraints, 4))
+    # configs[4]: this process gives its GPU memory back first (an N = 2^26 proof wants most of a GPU), then the helper runs the
+    # transport self-test, the point-sharded MSM and the point-sharded PROVE over all ranks
+    in_flight = pool.in_flight
+    ctx.pk_free(pkh)
+    for d in (g1a, g1b, g1k, g1z, g2b, W, a, b, c):
+        d.free()
+    pool.close()
+    sharded, sharded_prove = {"done": False}, {"done": False}
+    if helper is not None:
+        sharded, sharded_prove = run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args)
     if rank == 0:
         proofs = args.steps * world
         # dominant kernel: G1 level-1 bucket accumulate; algorithmic bytes = 96 B per (point, scalar) pair
@@ -376,9 +560,13 @@ def main():
         # reported when this run has the profiled shape (N = 2^23, WHIR mix, automatic plans).  The accumulate kernel gathers 64-B
         # points, so its FETCH_SIZE is taken raw; the NTT passes stream 16 B per lane, so theirs gets the guide's x2 correction.
         traffic = traffic_ntt = None
+        pmc_file = os.path.join("profiles", "r03_pmc_bench_traffic.json")
+        if not os.path.exists(os.path.join(ROOT, pmc_file)):
+            pmc_file = os.path.join("profiles", "r02_pmc_bench_traffic.json")
+        pmc_src = f"{pmc_file} (committed PMC passes of this workload, not this run; file sha256 {_sha16(os.path.join(ROOT, pmc_file))}, last commit {_last_commit(pmc_file)})"
         if log_n == 23 and args.dist == "whir" and not (args.msm_plan or args.fixed_base or args.ntt_plan or args.msm_group_bits or args.msm_chunk):
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, pmc_file)))
                 kname = "k_msm_accum_affine29"
                 traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
                 # per pass launch (the fused contiguous pair counted with its own figures, two launches per computeH); one transform =
@@ -396,7 +584,7 @@ def main():
             "config": {"workload": f"full Groth16 prove, WHIR-verifier-shaped synthetic key/witness, FFT domain N=2^{log_n} "
                                    f"(BASELINE {'configs[1]' if log_n == 23 else 'configs[2]' if log_n == 26 else 'non-baseline size'}; configs[3] = one such proof stream per GPU when n_gpus>1)",
                        "nb_wires": nb_wires, "nb_public": nb_public, "n_constraints": n_constraints, "scalar_dist": args.dist,
-                       "g1_msm_sizes": [na, nb, nk, N - 1], "g2_msm_size": nb, "proofs_in_flight_per_gpu": pool.in_flight},
+                       "g1_msm_sizes": [na, nb, nk, N - 1], "g2_msm_size": nb, "proofs_in_flight_per_gpu": in_flight},
             # latency of ONE proof with nothing else on the GPU (untimed region, context 0); value above is throughput with
             # proofs_in_flight_per_gpu proofs overlapping, every one of the K steps submitted and completed inside the timed region
             "single_proof_latency_ms": serial_ms,
@@ -404,23 +592,25 @@ def main():
             "value_host_inputs": host_rate, "ms_per_step_host_inputs": host_ms,
             # BASELINE configs[4] (one MSM point-sharded over the ranks, strong scaling); n_gpus = 1: the same code path with one rank
             "sharded_msm": sharded,
+            # BASELINE configs[4] as north_star states it: ONE proof point-sharded over the ranks (strong scaling)
+            "sharded_prove": sharded_prove,
             "proofs_validated": f"{len(timed_proofs)} timed + {0 if host_rate is None else args.steps} host-input proofs byte-equal to the untimed serial proof",
             "pk_load_s": t_load,
-            "hbm_in_use_gb": (lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info()),
+            "hbm_in_use_gb": hbm_in_use_gb, "hbm_ledger_gb": hbm_ledger,
             # second half of BASELINE's metric: one G1 MSM of 2^23 uniform pairs alone on the GPU (standard MSM benchmark shape);
             # inside a proof the five MSMs overlap on five streams, so per-MSM spans there are not rates
             "g1_msm_pts_per_s": solo["msm_pts_per_s"], "g1_pairs_per_proof": g1_pairs_per_proof,
             "phase_ms": {k: last[k] for k in ("compute_h_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "msm_k_ms", "msm_z_ms", "assemble_ms", "total_ms")},
             "roofline": {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "traffic_source": "profiles/r02_pmc_bench_traffic.json (committed PMC passes of this workload, not this run)",
+                         "traffic_source": pmc_src,
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
             # time = computeH alone on the GPU / its 6 transforms (gnark's 7th, the coset FFT of c, is never needed: DESIGN.md 4)
             "roofline_ntt": {"kernel": "k_ntt_pass_wave (all passes of one size-N transform)", "bound": "hbm",
                              "achieved": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9 / 8000.0, "traffic": traffic_ntt,
-                             "traffic_source": "profiles/r02_pmc_bench_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) per pass launch x pass launches per transform",
+                             "traffic_source": pmc_src + ": (2 x FETCH_SIZE + WRITE_SIZE) per pass launch x pass launches per transform",
                              "compute_h_solo_ms": ntt_solo["compute_h_ms"], "pass_launches_per_compute_h": ntt_solo["pass_launches"],
                              "algorithmic_bytes_per_transform": 64.0 * N},
             # why the HBM fraction is small: the kernel is bound by 256-bit modular products on the VALU (no MFMA form exists)
@@ -437,18 +627,11 @@ def main():
                      "kernel_modmul_per_s": 10.0 * accum_entries / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,
                      "note": "one XYZZ mixed addition = 8M + 2S Fp products (+ ~7 add/sub); frac = kernel_modmul_per_s / modmul_ceiling_per_s"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            dl = lambda d, n, k: d.download((n, k))
-            pk_host = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": dl(g1a, na, 8), "g1_b": dl(g1b, nb, 8),
-                       "g1_k": dl(g1k, nk, 8), "g1_z": dl(g1z, N, 8), "g2_b": dl(g2b, nb, 16), "alpha1": small[0], "beta1": small[1],
-                       "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b}
-            line["cpu_baseline"] = cpu_baseline(pk_host, dl(W, nb_wires, 4), dl(a, n_constraints, 4), dl(b, n_constraints, 4),
-                                                dl(c, n_constraints, 4), rs[0], rs[1], log_n, serial_bytes)
+        if cpu_inputs is not None:
+            line["cpu_baseline"] = cpu_baseline(*cpu_inputs, rs[0], rs[1], log_n, serial_bytes)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
-    ctx.pk_free(pkh)
-    pool.close()
 
 
 if __name__ == "__main__":

@@ -30,7 +30,8 @@ EXPORTS = [
     "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait",
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
     "mi_group_last_error", "mi_group_transport", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
-    "mi_groth16_prove_sharded", "mi_msm_g1_sharded", "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
+    "mi_groth16_prove_sharded", "mi_groth16_prove_sharded_dev", "mi_pk_load_sharded_dev", "mi_msm_g1_sharded", "mi_msm_g2_sharded",
+    "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
     "mi_pk_raw_inspect", "mi_pk_load_raw",
 ]
 
@@ -46,6 +47,10 @@ class PkDesc(C.Structure):
         ("infinity_a", C.c_void_p), ("infinity_b", C.c_void_p),
         ("committed_wires", C.c_void_p), ("n_committed", C.c_uint64),
     ]
+
+
+class MemLedger(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("key_bases", "key_tables", "key_indices", "ctx_ntt_tables", "ctx_ntt_vectors", "ctx_msm", "ctx_other")]
 
 
 class PkRawInfo(C.Structure):
@@ -340,6 +345,11 @@ class Context:
     def stats(self):
         st = Stats(); self._ck(self.lib.mi_get_stats(self.h, C.byref(st))); return st.as_dict()
 
+    def mem_ledger(self, pkh=None):
+        """device memory held by the key `pkh` and by this context, in GB (mi_get_mem_ledger)"""
+        m = MemLedger(); self._ck(self.lib.mi_get_mem_ledger(self.h, pkh, C.byref(m)))
+        return {n: getattr(m, n) / 1e9 for n, _ in MemLedger._fields_}
+
 
 # ---- host-only helpers (no ctx)
 class Prover:
@@ -470,19 +480,56 @@ class Group:
         self._ck(self.lib.mi_pk_load_sharded(self.h, C.byref(d), C.byref(h)))
         return h
 
+    def pk_load_dev(self, pk: dict, slices):
+        """pk: header + masks of the WHOLE key (host); slices[i] = {name: (device pointer on local rank i's device, count)} for
+        g1_a, g1_b, g1_k, g1_z, g2_b: that rank's slices (mi_pk_load_sharded_dev)"""
+        descs = (PkDesc * len(slices))(); keep = []
+        ia = np.ascontiguousarray(pk["infinity_a"], dtype=np.uint8); ib = np.ascontiguousarray(pk["infinity_b"], dtype=np.uint8)
+        cw = pk.get("committed_wires")
+        cw = np.ascontiguousarray(cw, dtype=np.uint32) if cw is not None and len(cw) else None
+        keep += [ia, ib, cw]
+        for d, sl in zip(descs, slices):
+            d.log_n, d.nb_public, d.nb_wires = pk["log_n"], pk["nb_public"], pk["nb_wires"]
+            for name in ("g1_a", "g1_b", "g1_k", "g1_z", "g2_b"):
+                ptr, cnt = sl[name]
+                setattr(d, name, int(ptr)); setattr(d, "n_" + name, int(cnt))
+            for name, k in (("alpha1", 8), ("beta1", 8), ("delta1", 8), ("beta2", 16), ("delta2", 16)):
+                setattr(d, name, (C.c_uint64 * k)(*[int(v) for v in _u64(pk[name]).reshape(-1)]))
+            d.infinity_a, d.infinity_b = ia.ctypes.data, ib.ctypes.data
+            if cw is not None:
+                d.committed_wires, d.n_committed = cw.ctypes.data, cw.shape[0]
+        h = C.c_void_p()
+        self._ck(self.lib.mi_pk_load_sharded_dev(self.h, descs, C.byref(h)))
+        return h
+
     def pk_free(self, spk):
         self._ck(self.lib.mi_pk_sharded_free(self.h, spk))
 
     def prove(self, spk, W, a, b, c, r, s, mode=0):
+        """host inputs; a, b, c may be None in a process that does not hold rank 0"""
         out = np.zeros(32, np.uint64); st = Stats()
-        W, a, b, c, r, s = (_u64(x) for x in (W, a, b, c, r, s))
-        self._ck(self.lib.mi_groth16_prove_sharded(self.h, spk, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c), C.c_size_t(a.shape[0]),
+        W, r, s = _u64(W), _u64(r), _u64(s)
+        a, b, c = (None if x is None else _u64(x) for x in (a, b, c))
+        self._ck(self.lib.mi_groth16_prove_sharded(self.h, spk, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c), C.c_size_t(0 if a is None else a.shape[0]),
                                                    _p(r), _p(s), C.c_uint32(mode), _p(out), C.byref(st)))
+        return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
+
+    def prove_dev(self, spk, W_ptrs, n_wires, a_ptr, b_ptr, c_ptr, n_constraints, r, s, mode=0):
+        """inputs resident: W_ptrs[i] = wire range of local rank i on its device; a, b, c on rank 0's device (None elsewhere)"""
+        out = np.zeros(32, np.uint64); st = Stats(); r, s = _u64(r), _u64(s)
+        ww = (C.c_void_p * len(W_ptrs))(*[int(p) for p in W_ptrs])
+        self._ck(self.lib.mi_groth16_prove_sharded_dev(self.h, spk, ww, C.c_size_t(n_wires), _p(a_ptr), _p(b_ptr), _p(c_ptr), C.c_size_t(n_constraints),
+                                                       _p(r), _p(s), C.c_uint32(mode), _p(out), C.byref(st)))
         return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
 
     def msm_g1(self, pts, sc, flags=0, mode=0):
         out = np.zeros(12, np.uint64); pts, sc = _u64(pts), _u64(sc)
         self._ck(self.lib.mi_msm_g1_sharded(self.h, _p(pts), _p(sc), C.c_size_t(pts.shape[0]), C.c_uint32(flags), C.c_uint32(mode), _p(out)))
+        return out
+
+    def msm_g2(self, pts, sc, flags=0, mode=0):
+        out = np.zeros(24, np.uint64); pts, sc = _u64(pts), _u64(sc)
+        self._ck(self.lib.mi_msm_g2_sharded(self.h, _p(pts), _p(sc), C.c_size_t(pts.shape[0]), C.c_uint32(flags), C.c_uint32(mode), _p(out)))
         return out
 
     def msm_dev(self, pts_ptrs, sc_ptrs, n_local, n_total, flags=0, mode=0, g2=False):

@@ -87,6 +87,7 @@ int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t 
 int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                               size_t n_constraints, mi_fr *h_out);
 void mi_ntt_state_init(mi_ctx *ctx);
+size_t mi_ntt_table_bytes(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);
 int32_t mi_msm_state_init(mi_ctx *ctx);   // MI_OK or the first failing HIP call; partial state is freed by mi_msm_state_free
 // Stream priority schemes (3 hardware levels; comment in msm.hip).  A context on its own ranks computeH high, the wire MSMs

@@ -23,6 +23,7 @@
 #include "prove_internal.h"
 #include "msm_curve_ops.h"
 #include <rccl/rccl.h>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <future>
@@ -40,6 +41,7 @@ struct mi_group {
     std::vector<DevBuf> recv;      // per local rank: bucket slices received from the other ranks
     std::vector<DevBuf> stage;     // per local rank: small staging area for the partial-sum all-gather
     std::string err;
+    std::atomic<bool> busy{false};   // calls on one group must not overlap: an entry point that finds it set returns MI_EINVAL (GroupCall)
     int n_local() const { return (int)ctx.size(); }
     bool local(int r) const { return r >= rank0 && r < rank0 + n_local(); }
 };
@@ -56,6 +58,15 @@ struct mi_pk_sharded {
 #define G_NCCL(g, call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { (g)->err = std::string(#call) + ": " + ncclGetErrorString(r__); \
                              return MI_EHIP; } } while (0)
 #define G_CTX(g, i, expr) do { int32_t rc__ = (expr); if (rc__ != MI_OK) { (g)->err = mi_last_error((g)->ctx[i]); return rc__; } } while (0)
+
+// Entry-point guard: the group's exchange streams, receive buffers and per-rank contexts serve ONE call at a time.  A second call that
+// arrives while one is running is refused (MI_EINVAL, the running call's error text is left alone) instead of corrupting g->recv.
+struct GroupCall {
+    mi_group *g; bool ok;
+    explicit GroupCall(mi_group *g_) : g(g_), ok(g_ && !g_->busy.exchange(true, std::memory_order_acquire)) {}
+    ~GroupCall() { if (ok) g->busy.store(false, std::memory_order_release); }
+};
+#define G_ENTER(g) GroupCall call__(g); if (!call__.ok) return MI_EINVAL
 
 static void range_of(u64 total, int world, int r, u64 &lo, u64 &hi) { lo = total * (u64)r / (u64)world; hi = total * (u64)(r + 1) / (u64)world; }
 
@@ -205,6 +216,7 @@ int32_t mi_group_transport(const mi_group *g) { return !g ? 0 : (g->comm.empty()
 // received: the transport (RCCL grouped send / recv, or peer copies) in isolation.  All ranks of the group call it together.
 int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes) {
     if (!g || !bytes || bytes > ((size_t)1 << 28)) return MI_EINVAL;
+    G_ENTER(g);
     const int nl = g->n_local(), W = g->world;
     std::vector<void *> sbuf(nl, nullptr), rbuf(nl, nullptr);
     std::vector<hipStream_t> xs(nl);
@@ -295,7 +307,7 @@ static int32_t exchange_buckets(mi_group *g, int slot, int curve) {
 }
 
 // Sum of the per-rank partial results of one MSM (XYZZ on the host).  Single process: plain additions.  One rank per process:
-// byte-typed ncclAllGather of the partials, then the same additions on every rank.
+// byte-typed ncclAllGather of the partials, then the same additions (in rank order) on every rank.
 template <class F>
 static int32_t combine_partials(mi_group *g, const std::vector<XYZZ<F>> &local, XYZZ<F> *out) {
     XYZZ<F> acc = XYZZ<F>::inf();
@@ -304,6 +316,7 @@ static int32_t combine_partials(mi_group *g, const std::vector<XYZZ<F>> &local, 
         *out = acc;
         return MI_OK;
     }
+    if (g->n_local() != 1 || g->comm.size() != 1) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
     const size_t B = sizeof(XYZZ<F>);
     std::vector<XYZZ<F>> all((size_t)g->world);
     (void)hipSetDevice(g->dev[0]);
@@ -316,6 +329,27 @@ static int32_t combine_partials(mi_group *g, const std::vector<XYZZ<F>> &local, 
     G_HIP(g, hipStreamSynchronize(s));
     for (const auto &p : all) xyzz_add(acc, p);
     *out = acc;
+    return MI_OK;
+}
+
+// Group-wide minimum and maximum of one 64-bit value per local rank (plans every rank must agree on: table budgets, window widths).
+// Single process: over the local values.  One rank per process: ncclAllGather of the 8 bytes.
+static int32_t group_min_max(mi_group *g, const std::vector<u64> &local, u64 *mn, u64 *mx) {
+    std::vector<u64> all = local;
+    if (g->n_local() != g->world) {
+        if (g->n_local() != 1 || g->comm.size() != 1) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
+        all.assign((size_t)g->world, 0);
+        (void)hipSetDevice(g->dev[0]);
+        G_CTX(g, 0, mi_reserve(g->ctx[0], g->stage[0], 8 * (size_t)(g->world + 1)));
+        char *st = (char *)g->stage[0].p;
+        hipStream_t s = g->xs[0];
+        G_HIP(g, hipMemcpyAsync(st, &local[0], 8, hipMemcpyHostToDevice, s));
+        G_NCCL(g, ncclAllGather(st, st + 8, 8, ncclUint8, g->comm[0], s));
+        G_HIP(g, hipMemcpyAsync(all.data(), st + 8, 8 * (size_t)g->world, hipMemcpyDeviceToHost, s));
+        G_HIP(g, hipStreamSynchronize(s));
+    }
+    *mn = ~(u64)0; *mx = 0;
+    for (u64 v : all) { if (v < *mn) *mn = v; if (v > *mx) *mx = v; }
     return MI_OK;
 }
 
@@ -357,18 +391,9 @@ static int32_t msm_sharded_dev(mi_group *g, int curve, const void *const *pts_de
     return MI_OK;
 }
 
-extern "C" {
-
-int32_t mi_msm_g1_sharded_dev(mi_group *g, const mi_g1_affine *const *pts_dev, const mi_fr *const *scalars_dev, const size_t *n_local, size_t n_total,
-                              uint32_t flags, uint32_t mode, mi_g1_jac *out) {
-    return msm_sharded_dev<Fp>(g, 1, (const void *const *)pts_dev, (const void *const *)scalars_dev, n_local, n_total, flags, mode, out);
-}
-int32_t mi_msm_g2_sharded_dev(mi_group *g, const mi_g2_affine *const *pts_dev, const mi_fr *const *scalars_dev, const size_t *n_local, size_t n_total,
-                              uint32_t flags, uint32_t mode, mi_g2_jac *out) {
-    return msm_sharded_dev<Fp2>(g, 2, (const void *const *)pts_dev, (const void *const *)scalars_dev, n_local, n_total, flags, mode, out);
-}
 // Host arrays, one process: cut into contiguous slices, upload slice r to rank r, run the sharded MSM.
-int32_t mi_msm_g1_sharded(mi_group *g, const mi_g1_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags, uint32_t mode, mi_g1_jac *out) {
+template <class F, class AffT, class JacT>
+static int32_t msm_sharded_host(mi_group *g, int curve, const AffT *pts, const mi_fr *scalars, size_t n, uint32_t flags, uint32_t mode, JacT *out) {
     if (!g || !out || ((!pts || !scalars) && n)) return MI_EINVAL;
     if (g->n_local() != g->world) G_FAIL(g, MI_EINVAL, "group: host-array entry points need all ranks in this process");
     const int nl = g->n_local();
@@ -379,31 +404,62 @@ int32_t mi_msm_g1_sharded(mi_group *g, const mi_g1_affine *pts, const mi_fr *sca
         range_of(n, g->world, i, lo, hi);
         (void)hipSetDevice(g->dev[i]);
         mi_ctx *ctx = g->ctx[i];
-        G_CTX(g, i, mi_reserve(ctx, ctx->ws[2], (hi - lo) * sizeof(mi_g1_affine) + 64));
+        G_CTX(g, i, mi_reserve(ctx, ctx->ws[2], (hi - lo) * sizeof(AffT) + 64));
         G_CTX(g, i, mi_reserve(ctx, ctx->ws[3], (hi - lo) * sizeof(mi_fr) + 64));
         if (hi > lo) {
-            G_HIP(g, hipMemcpyAsync(ctx->ws[2].p, pts + lo, (hi - lo) * sizeof(mi_g1_affine), hipMemcpyHostToDevice, ctx->stream));
+            G_HIP(g, hipMemcpyAsync(ctx->ws[2].p, pts + lo, (hi - lo) * sizeof(AffT), hipMemcpyHostToDevice, ctx->stream));
             G_HIP(g, hipMemcpyAsync(ctx->ws[3].p, scalars + lo, (hi - lo) * sizeof(mi_fr), hipMemcpyHostToDevice, ctx->stream));
         }
         pp[i] = ctx->ws[2].p; ss[i] = ctx->ws[3].p; nn[i] = hi - lo;
     }
-    return msm_sharded_dev<Fp>(g, 1, pp.data(), ss.data(), nn.data(), n, flags, mode, out);
+    return msm_sharded_dev<F>(g, curve, pp.data(), ss.data(), nn.data(), n, flags, mode, out);
+}
+
+extern "C" {
+
+int32_t mi_msm_g1_sharded_dev(mi_group *g, const mi_g1_affine *const *pts_dev, const mi_fr *const *scalars_dev, const size_t *n_local, size_t n_total,
+                              uint32_t flags, uint32_t mode, mi_g1_jac *out) {
+    G_ENTER(g);
+    return msm_sharded_dev<Fp>(g, 1, (const void *const *)pts_dev, (const void *const *)scalars_dev, n_local, n_total, flags, mode, out);
+}
+int32_t mi_msm_g2_sharded_dev(mi_group *g, const mi_g2_affine *const *pts_dev, const mi_fr *const *scalars_dev, const size_t *n_local, size_t n_total,
+                              uint32_t flags, uint32_t mode, mi_g2_jac *out) {
+    G_ENTER(g);
+    return msm_sharded_dev<Fp2>(g, 2, (const void *const *)pts_dev, (const void *const *)scalars_dev, n_local, n_total, flags, mode, out);
+}
+int32_t mi_msm_g1_sharded(mi_group *g, const mi_g1_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags, uint32_t mode, mi_g1_jac *out) {
+    G_ENTER(g);
+    return msm_sharded_host<Fp>(g, 1, pts, scalars, n, flags, mode, out);
+}
+int32_t mi_msm_g2_sharded(mi_group *g, const mi_g2_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags, uint32_t mode, mi_g2_jac *out) {
+    G_ENTER(g);
+    return msm_sharded_host<Fp2>(g, 2, pts, scalars, n, flags, mode, out);
 }
 
 // ---------------------------------------------------------------- sharded proving key
 int32_t mi_pk_sharded_free(mi_group *g, mi_pk_sharded *spk) {
     if (!g || !spk) return MI_EINVAL;
+    G_ENTER(g);
     for (size_t i = 0; i < spk->part.size(); i++) if (spk->part[i]) { (void)hipSetDevice(g->dev[i]); mi_pk_free(g->ctx[i], spk->part[i]); }
     delete spk;
     return MI_OK;
 }
+
+}  // extern "C"
+
 // Splits pk.G1.{A,B,K,Z} and pk.G2.B into `world` contiguous slices (by wire; Z by index) and makes slice r resident on rank r.
-// The desc is the same whole-key descriptor mi_pk_load takes (host arrays); every process of a multi-process group passes it.
-int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *d, mi_pk_sharded **out) {
-    if (!g || !d || !out) return MI_EINVAL;
+//   host arrays    descs = ONE whole-key descriptor (what mi_pk_load takes); every process of a multi-process group passes it.
+//   device arrays  descs = one descriptor per LOCAL rank: header and masks of the WHOLE key (host), point arrays = that rank's
+//                  slices already on that rank's device (counts = points of the slice), adopted by reference as mi_pk_load_dev does.
+static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool device_points, mi_pk_sharded **out) {
+    if (!g || !descs || !out) return MI_EINVAL;
     *out = nullptr;
+    const mi_pk_desc *d = descs;
     if (d->log_n > 28 || !d->infinity_a || !d->infinity_b || d->nb_public > d->nb_wires) G_FAIL(g, MI_EINVAL, "pk: bad header");
     const int nl = g->n_local(), W = g->world;
+    if (device_points) for (int i = 1; i < nl; i++)
+        if (descs[i].log_n != d->log_n || descs[i].nb_wires != d->nb_wires || descs[i].nb_public != d->nb_public || !descs[i].infinity_a || !descs[i].infinity_b)
+            G_FAIL(g, MI_EINVAL, "pk: the per-rank descriptors disagree on the key's header");
     const u64 N = (u64)1 << d->log_n;
     mi_pk_sharded *spk = new (std::nothrow) mi_pk_sharded();
     if (!spk) return MI_ENOMEM;
@@ -421,19 +477,23 @@ int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *d, mi_pk_sharded **out
     // ONE fixed-base plan for all parts (mode 1 exchanges buckets, so the parts must cut their scalars alike; and a part just
     // under the 2^20-point threshold next to one just over it would otherwise pick different paths): the rule of mi_pk_load
     // (prove.hip: tables for an MSM of >= 2^20 points while they fit in a third of the free memory, smallest group first),
-    // applied to the LARGEST part and the tightest device, then forced on every context through its knobs.  Knobs the caller
-    // set (mi_debug_set_prove_fixed_base) are kept.
+    // applied to the LARGEST part and the tightest device OF THE WHOLE GROUP (one rank per process: the budgets are all-gathered),
+    // then forced on every context through its knobs.  Knobs the caller set (mi_debug_set_prove_fixed_base) are kept.
     u32 plan[3] = {1, 1, 1};   // A+K, B, Z: 1 = no tables
+    auto fail = [&](int32_t rc) { for (size_t i = 0; i < spk->part.size(); i++) if (spk->part[i]) { (void)hipSetDevice(g->dev[i]); mi_pk_free(g->ctx[i], spk->part[i]); } delete spk; return rc; };
     {
-        size_t budget = ~(size_t)0;
+        std::vector<u64> budgets(nl, 0);
         for (int i = 0; i < nl; i++) {
             (void)hipSetDevice(g->dev[i]);
             size_t fr = 0, tot = 0, sharers = 0;
             if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = 0;
             for (int j = 0; j < nl; j++) sharers += g->dev[j] == g->dev[i] ? 1 : 0;
-            fr = fr / 3 / sharers;
-            if (fr < budget) budget = fr;
+            budgets[i] = fr / 3 / sharers;
         }
+        u64 bmin = 0, bmax = 0;
+        int32_t rc = group_min_max(g, budgets, &bmin, &bmax);
+        if (rc != MI_OK) return fail(rc);
+        size_t budget = (size_t)bmin;
         auto nwin_of = [](u32 c) { return (size_t)((256 + c - 1) / c); };
         auto choose = [&](u32 c_auto, u64 n_max, size_t bytes_per_point) -> u32 {
             const size_t need = nwin_of(c_auto) * n_max * bytes_per_point;
@@ -454,91 +514,122 @@ int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *d, mi_pk_sharded **out
         range_of(d->nb_wires, W, g->rank0 + i, sr.w_lo, sr.w_hi); range_of(N - 1, W, g->rank0 + i, sr.z_lo, sr.z_hi);
         u32 saved[3];
         for (int k = 0; k < 3; k++) { saved[k] = ctx->fixed_knob[k]; if (!saved[k]) ctx->fixed_knob[k] = plan[k]; }
-        rcs[i] = mi_pk_load_range(ctx, d, &spk->part[i], false, &sr);
+        rcs[i] = mi_pk_load_range(ctx, device_points ? &descs[i] : d, &spk->part[i], device_points, &sr);
         for (int k = 0; k < 3; k++) ctx->fixed_knob[k] = saved[k];
     });
     for (auto &t : th) t.join();
-    for (int i = 0; i < nl; i++) if (rcs[i] != MI_OK) { g->err = mi_last_error(g->ctx[i]); int32_t rc = rcs[i]; mi_pk_sharded_free(g, spk); return rc; }
-    spk->uniform = true;
+    // every process reaches the agreement below even when a local part failed (a collective that only some ranks enter would hang)
+    int32_t first_bad = MI_OK;
+    for (int i = 0; i < nl; i++) if (rcs[i] != MI_OK && first_bad == MI_OK) { g->err = mi_last_error(g->ctx[i]); first_bad = rcs[i]; }
+    // all parts on the same plan?  (a part whose tables could not be allocated after all fell back to the generic path by itself)
+    std::vector<u64> sig(nl, 0);
     for (int i = 0; i < nl; i++) {
-        mi_pk *p = spk->part[i], *q = spk->part[0];
-        p->gen_c_ak = mi_msm_auto_c(max_w); p->gen_c_b = mi_msm_auto_c(max_b); p->gen_c_z = mi_msm_auto_c(max_z);
-        if (p->c_ak != q->c_ak || p->c_b != q->c_b || p->c_z != q->c_z) spk->uniform = false;
+        mi_pk *p = spk->part[i];
+        if (p) { p->gen_c_ak = mi_msm_auto_c(max_w); p->gen_c_b = mi_msm_auto_c(max_b); p->gen_c_z = mi_msm_auto_c(max_z); }
+        sig[i] = p ? ((u64)1 << 32 | (u64)p->c_ak << 16 | (u64)p->c_b << 8 | (u64)p->c_z) : 0;   // 0 = this part failed to load
     }
+    u64 smin = 0, smax = 0;
+    int32_t rc = group_min_max(g, sig, &smin, &smax);
+    if (first_bad != MI_OK) return fail(first_bad);
+    if (rc != MI_OK) return fail(rc);
+    if (smin == 0) { g->err = "pk: another rank of the group failed to load its part"; return fail(MI_EHIP); }
+    spk->uniform = smin == smax;
     *out = spk;
     return MI_OK;
 }
 
-// groth16.Prove (mt.go:496) over the ranks of a single-process group; W, a, b, c, r, s, out as mi_groth16_prove.
+// One proof over the ranks of the group (groth16.Prove, mt.go:496).  Inputs either in host memory (host = true: W is the WHOLE wire
+// vector, a process reads only the ranges of its local ranks; a, b, c are read by the process that holds rank 0) or already on the
+// devices (W_dev[i] = the wire range of local rank i on its device; a, b, c on rank 0's device).
 // mode 0: per-rank partial sums (option i); mode 1: bucket reduce-scatter before the reduce (option ii).
-int32_t mi_groth16_prove_sharded(mi_group *g, mi_pk_sharded *spk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
-                                 size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, uint32_t mode, mi_proof_out *out, mi_stats *stats) {
-    if (!g || !spk || !W || !a || !b || !c || !r_m || !s_m || !out || mode > 1) return MI_EINVAL;
-    if (g->n_local() != g->world || (int)spk->part.size() != g->world) G_FAIL(g, MI_EINVAL, "group: the sharded prove needs all ranks in this process");
-    const int nl = g->n_local();
+static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, const mi_fr *W_host, const mi_fr *const *W_dev, size_t n_wires,
+                                  const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m,
+                                  uint32_t mode, mi_proof_out *out, mi_stats *stats) {
+    if (!g || !spk || !r_m || !s_m || !out || mode > 1 || (host ? !W_host : !W_dev)) return MI_EINVAL;
+    const int nl = g->n_local(), W = g->world;
+    if ((nl != W && nl != 1) || (int)spk->part.size() != nl) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
+    const bool lead_here = g->rank0 == 0;   // global rank 0 runs computeH and owns a, b, c
+    if (lead_here && (!a || !b || !c)) return MI_EINVAL;
     const size_t N = (size_t)1 << spk->log_n;
     if (n_wires != spk->nb_wires || n_constraints > N) G_FAIL(g, MI_EINVAL, "prove: witness size does not match the proving key");
     if (mode == 1 && !spk->uniform) G_FAIL(g, MI_EINVAL, "group: mode 1 needs every part to use the same MSM plan (table widths differ between devices)");
     const auto t_begin = std::chrono::steady_clock::now();
     const size_t cb = n_constraints * sizeof(mi_fr);
-    // workspaces first, each on its own device: W slice (+ a, b, c on the lead), h (whole on the lead, a slice elsewhere)
+    // workspaces first, each on its own device: W slice (+ a, b, c on the lead) for host inputs; h (whole on the lead, a slice elsewhere)
     for (int i = 0; i < nl; i++) {
         (void)hipSetDevice(g->dev[i]);
         mi_ctx *ctx = g->ctx[i];
         mi_pk *pk = spk->part[i];
+        const bool lead = g->rank0 + i == 0;
         std::memset(&ctx->stats, 0, sizeof(ctx->stats));
-        G_CTX(g, i, mi_reserve(ctx, ctx->ws[16], pk->nb_wires * sizeof(mi_fr) + (i == 0 ? 3 * cb : 0) + 128));
-        G_CTX(g, i, mi_reserve(ctx, ctx->ws[14], (i == 0 ? N : pk->n_z_msm + 1) * sizeof(Fr)));
+        if (host) G_CTX(g, i, mi_reserve(ctx, ctx->ws[16], pk->nb_wires * sizeof(mi_fr) + (lead ? 3 * cb : 0) + 128));
+        G_CTX(g, i, mi_reserve(ctx, ctx->ws[14], (lead ? N : pk->n_z_msm + 1) * sizeof(Fr)));
     }
     const bool defer = mode == 1;
     std::vector<int32_t> rcs(nl, MI_OK);
-    std::promise<bool> h_ready;
-    std::shared_future<bool> h_fut = h_ready.get_future().share();
+    // every local rank: its slice of W, its wire MSMs; the lead also a, b, c, computeH and its own Z MSM.  One host thread per rank:
+    // enqueueing the wire MSMs waits once for the count pass of their sorts (msm.hip, MI_MSM_EXACT_SIZE)
     auto rank_main = [&](int i) -> int32_t {
         (void)hipSetDevice(g->dev[i]);
         mi_ctx *ctx = g->ctx[i];
         mi_pk *pk = spk->part[i];
         hipEvent_t *ev = ctx->ev;
-        char *base = (char *)ctx->ws[16].p;
+        const bool lead = g->rank0 + i == 0;
         const size_t wb = pk->nb_wires * sizeof(mi_fr);
+        const mi_fr *Wd = host ? (const mi_fr *)ctx->ws[16].p : W_dev[i];
+        if (!Wd && wb) MI_FAIL(ctx, MI_EINVAL, "prove: null wire slice");
         MI_CHECK_HIP(ctx, hipEventRecord(ev[10], ctx->stream));
-        if (wb) MI_CHECK_HIP(ctx, hipMemcpyAsync(base, W + pk->wire_lo, wb, hipMemcpyHostToDevice, ctx->stream));
+        if (host && wb) MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)Wd, W_host + pk->wire_lo, wb, hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-        MI_TRY(mi_prove_enqueue_wire_msms(ctx, pk, (const mi_fr *)base, ev[2], defer));
-        if (i == 0) {
-            // lead: a, b, c arrive while the wire MSMs run; computeH; every other rank gets its slice of h device-to-device
-            mi_fr *da = (mi_fr *)(base + wb), *db = (mi_fr *)(base + wb + cb), *dc = (mi_fr *)(base + wb + 2 * cb);
+        MI_TRY(mi_prove_enqueue_wire_msms(ctx, pk, Wd, ev[2], defer));
+        if (!lead) return MI_OK;
+        // lead: a, b, c arrive while the wire MSMs run; computeH; its own slice of h feeds its Z MSM straight away
+        const mi_fr *da = a, *db = b, *dc = c;
+        if (host) {
+            char *base = (char *)ctx->ws[16].p;
+            da = (mi_fr *)(base + wb); db = (mi_fr *)(base + wb + cb); dc = (mi_fr *)(base + wb + 2 * cb);
             if (cb) {
-                MI_CHECK_HIP(ctx, hipMemcpyAsync(da, a, cb, hipMemcpyHostToDevice, ctx->stream));
-                MI_CHECK_HIP(ctx, hipMemcpyAsync(db, b, cb, hipMemcpyHostToDevice, ctx->stream));
-                MI_CHECK_HIP(ctx, hipMemcpyAsync(dc, c, cb, hipMemcpyHostToDevice, ctx->stream));
+                MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)da, a, cb, hipMemcpyHostToDevice, ctx->stream));
+                MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)db, b, cb, hipMemcpyHostToDevice, ctx->stream));
+                MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dc, c, cb, hipMemcpyHostToDevice, ctx->stream));
             }
-            MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
-            Fr *h = (Fr *)ctx->ws[14].p;
-            MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, da, db, dc, n_constraints, (mi_fr *)h));
-            MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
-            MI_TRY(mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)(h + pk->z_lo), ev[3], defer));
-            for (int j = 1; j < nl; j++) {
-                mi_pk *pj = spk->part[j];
-                const size_t bytes = pj->n_z_msm * sizeof(Fr);
-                if (bytes) {
-                    if (g->dev[j] == g->dev[0]) MI_CHECK_HIP(ctx, hipMemcpyAsync(g->ctx[j]->ws[14].p, h + pj->z_lo, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-                    else MI_CHECK_HIP(ctx, hipMemcpyPeerAsync(g->ctx[j]->ws[14].p, g->dev[j], h + pj->z_lo, g->dev[0], bytes, ctx->stream));
-                }
-                MI_CHECK_HIP(ctx, hipEventRecord(g->ev_h[j], ctx->stream));
-            }
-            return MI_OK;
         }
-        if (!h_fut.get()) return MI_OK;   // the lead failed: nothing to wait for (its error is reported)
-        return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)ctx->ws[14].p, g->ev_h[i], defer);
+        MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
+        Fr *h = (Fr *)ctx->ws[14].p;
+        MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, da, db, dc, n_constraints, (mi_fr *)h));
+        MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+        return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)(h + pk->z_lo), ev[3], defer);
     };
-    std::vector<std::thread> th;
-    for (int i = 1; i < nl; i++) th.emplace_back([&, i] { rcs[i] = rank_main(i); });
-    rcs[0] = rank_main(0);
-    h_ready.set_value(rcs[0] == MI_OK);
-    for (auto &t : th) t.join();
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < nl; i++) th.emplace_back([&, i] { rcs[i] = rank_main(i); });
+        rcs[0] = rank_main(0);
+        for (auto &t : th) t.join();
+    }
     (void)hipSetDevice(g->dev[0]);
     for (int i = 0; i < nl; i++) if (rcs[i] != MI_OK) { g->err = mi_last_error(g->ctx[i]); return rcs[i]; }
+    // h: rank 0 hands every other rank its slice device to device, as one batch of the group's transport (grouped ncclSend / ncclRecv,
+    // or same-process copies) on the exchange streams; the events that order the Z MSMs behind it are recorded by each RECEIVER on its
+    // own stream (an event is recorded only on a stream of the device it was created on)
+    if (W > 1) {
+        std::vector<Xfer> list;
+        for (int j = 1; j < W; j++) {
+            u64 zlo, zhi;
+            range_of(N - 1, W, j, zlo, zhi);
+            Xfer x{0, j, nullptr, nullptr, (size_t)(zhi - zlo) * sizeof(Fr)};
+            if (g->local(0)) x.sp = (const char *)g->ctx[0 - g->rank0]->ws[14].p + zlo * sizeof(Fr);
+            if (g->local(j)) x.dp = g->ctx[j - g->rank0]->ws[14].p;
+            list.push_back(x);
+        }
+        if (lead_here) { (void)hipSetDevice(g->dev[0]); G_HIP(g, hipStreamWaitEvent(g->xs[0], g->ctx[0]->ev[3], 0)); }
+        MI_TRY(run_xfers(g, list, g->xs));
+        for (int i = 0; i < nl; i++) {
+            if (g->rank0 + i == 0) continue;
+            (void)hipSetDevice(g->dev[i]);
+            G_HIP(g, hipEventRecord(g->ev_h[i], g->xs[i]));
+            G_CTX(g, i, mi_prove_enqueue_z_msm(g->ctx[i], spk->part[i], (const mi_fr *)g->ctx[i]->ws[14].p, g->ev_h[i], defer));
+        }
+    }
     if (defer) {
         // same order on every rank: A, B1, B2, K, Z
         static const int slots[5] = {0, 1, 2, 3, 4}, curves[5] = {1, 1, 2, 1, 1};
@@ -546,36 +637,62 @@ int32_t mi_groth16_prove_sharded(mi_group *g, mi_pk_sharded *spk, const mi_fr *W
     }
     ProofAssembler as;
     as.start(spk->part[0], r_m, s_m);
-    // collect: per MSM the sum of the ranks' partial results
-    G1X sum_a = G1X::inf(), sum_b1 = G1X::inf(), sum_k = G1X::inf(), sum_z = G1X::inf();
-    G2X sum_b2 = G2X::inf();
-    auto collect = [&](int slot, int curve, void *acc) -> int32_t {
-        for (int i = 0; i < nl; i++) {
-            (void)hipSetDevice(g->dev[i]);
-            if (curve == 1) { G1X p; G_CTX(g, i, mi_msm_finish(g->ctx[i], slot, 1, &p)); xyzz_add(*(G1X *)acc, p); }
-            else { G2X p; G_CTX(g, i, mi_msm_finish(g->ctx[i], slot, 2, &p)); xyzz_add(*(G2X *)acc, p); }
-        }
-        return MI_OK;
+    // collect: per MSM the sum of the ranks' partial results (every process ends with the same five sums)
+    G1X sum_a, sum_b1, sum_k, sum_z;
+    G2X sum_b2;
+    auto collect1 = [&](int slot, G1X *acc) -> int32_t {
+        std::vector<G1X> part((size_t)nl);
+        for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); G_CTX(g, i, mi_msm_finish(g->ctx[i], slot, 1, &part[i])); }
+        return combine_partials<Fp>(g, part, acc);
     };
-    MI_TRY(collect(0, 1, &sum_a));
-    MI_TRY(collect(1, 1, &sum_b1));
+    auto collect2 = [&](int slot, G2X *acc) -> int32_t {
+        std::vector<G2X> part((size_t)nl);
+        for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); G_CTX(g, i, mi_msm_finish(g->ctx[i], slot, 2, &part[i])); }
+        return combine_partials<Fp2>(g, part, acc);
+    };
+    MI_TRY(collect1(0, &sum_a));
+    MI_TRY(collect1(1, &sum_b1));
     as.have_a_b1(sum_a, sum_b1);
-    MI_TRY(collect(3, 1, &sum_k));
-    MI_TRY(collect(2, 2, &sum_b2));
-    MI_TRY(collect(4, 1, &sum_z));
-    for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); G_HIP(g, hipStreamSynchronize(g->ctx[i]->stream)); }
+    MI_TRY(collect1(3, &sum_k));
+    MI_TRY(collect2(2, &sum_b2));
+    MI_TRY(collect1(4, &sum_z));
+    for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); G_HIP(g, hipStreamSynchronize(g->ctx[i]->stream)); G_HIP(g, hipStreamSynchronize(g->xs[i])); }
     const auto t_gpu_done = std::chrono::steady_clock::now();
     as.finish(sum_k, sum_b2, sum_z, out);
     const auto t_end = std::chrono::steady_clock::now();
     (void)hipSetDevice(g->dev[0]);
     mi_stats &st = g->ctx[0]->stats;
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<float, std::milli>(y - x).count(); };
-    G_HIP(g, hipEventElapsedTime(&st.compute_h_ms, g->ctx[0]->ev[11], g->ctx[0]->ev[3]));
-    G_HIP(g, hipEventElapsedTime(&st.h2d_ms, g->ctx[0]->ev[10], g->ctx[0]->ev[11]));
+    if (lead_here) {
+        G_HIP(g, hipEventElapsedTime(&st.compute_h_ms, g->ctx[0]->ev[11], g->ctx[0]->ev[3]));
+        if (host) G_HIP(g, hipEventElapsedTime(&st.h2d_ms, g->ctx[0]->ev[10], g->ctx[0]->ev[11]));
+    }
     st.assemble_ms = ms(t_gpu_done, t_end);
     st.total_ms = ms(t_begin, t_end);
     if (stats) *stats = st;
     return MI_OK;
+}
+
+extern "C" {
+
+int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *d, mi_pk_sharded **out) {
+    G_ENTER(g);
+    return pk_load_sharded_impl(g, d, false, out);
+}
+int32_t mi_pk_load_sharded_dev(mi_group *g, const mi_pk_desc *slice_descs, mi_pk_sharded **out) {
+    G_ENTER(g);
+    return pk_load_sharded_impl(g, slice_descs, true, out);
+}
+int32_t mi_groth16_prove_sharded(mi_group *g, mi_pk_sharded *spk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                                 size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, uint32_t mode, mi_proof_out *out, mi_stats *stats) {
+    G_ENTER(g);
+    return prove_sharded_impl(g, spk, true, W, nullptr, n_wires, a, b, c, n_constraints, r_m, s_m, mode, out, stats);
+}
+int32_t mi_groth16_prove_sharded_dev(mi_group *g, mi_pk_sharded *spk, const mi_fr *const *W_dev, size_t n_wires, const mi_fr *a_dev, const mi_fr *b_dev,
+                                     const mi_fr *c_dev, size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, uint32_t mode, mi_proof_out *out,
+                                     mi_stats *stats) {
+    G_ENTER(g);
+    return prove_sharded_impl(g, spk, false, nullptr, W_dev, n_wires, a_dev, b_dev, c_dev, n_constraints, r_m, s_m, mode, out, stats);
 }
 
 }  // extern "C"

@@ -66,6 +66,19 @@ void mi_ntt_state_free(mi_ctx *ctx) {
     for (Fr **p : all) if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
+// bytes of device memory the context's NTT tables take (mi_get_mem_ledger)
+size_t mi_ntt_table_bytes(mi_ctx *ctx) {
+    const NttState *st = state_of(ctx);
+    size_t b = 0;
+    if (st->small_f) b += (size_t)(2 * 2048 + 2 * 65536) * sizeof(Fr);
+    if (st->log_n != 0xffffffffu) {
+        const size_t nlo = (size_t)1 << st->tw_h, nhi = (size_t)1 << (st->log_n - st->tw_h);
+        b += (4 * nlo + 6 * nhi + 2) * sizeof(Fr);
+    }
+    for (const Fr *p : {st->d_tw_inv, st->d_tw_fwd, st->d_sc_fwd, st->d_sc_inv}) if (p) b += sizeof(Fr) << st->d_log_n;
+    return b;
+}
+
 static NttKnobs knobs_for(const NttState *st, u32 log_n) {
     if (st->plan_set) return NttKnobs{st->log_e, st->max_contig, st->max_strided};
     if (log_n == 24) return NttKnobs{10, 8, 8};

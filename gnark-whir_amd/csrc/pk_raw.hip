@@ -6,7 +6,11 @@
 // backend/groth16/bn254/marshal.go and gnark-crypto ecc/bn254/marshal.go (Encoder with RawEncoding), fr/fft Domain.WriteTo,
 // fr/pedersen ProvingKey.WriteRawTo; spelled out field by field in oracle/pk_raw.py, which writes the same layout for the tests.
 // The parser is strict -- every count is cross-checked (points vs infinity masks, stream length, flag bits, the domain's
-// constants against log_n) -- so a layout difference shows up as MI_EINVAL on first contact, not as a wrong proof.
+// constants against log_n) -- so a SHIFTED or re-ordered layout shows up as MI_EINVAL on first contact.  ONE thing no check here can
+// see: the bit order inside the packed []bool masks (taken as MSB-first, `7 - j % 8`).  A population count is the same under
+// either order, so the other order would pass every check and pair the A / B points with the wrong wires: wrong proofs, silently.
+// The entry point is therefore EXPERIMENTAL until one real gnark v0.11.0 WriteRawTo fixture (go/mi355x/cmd/dumpfixture) has been
+// loaded and a proof from it verified; include/mi355x_groth16.h and INTEGRATION.md say the same.
 //
 // Raw points are big-endian CANONICAL coordinates; the device wants little-endian Montgomery limbs.  The conversion is the one
 // data-parallel piece (one point per thread: byte swap, flag bits, fe_to_mont) and runs on the GPU over the uploaded bytes;
@@ -190,8 +194,10 @@ int32_t mi_pk_load_raw(mi_ctx *ctx, const uint8_t *buf, size_t len, uint32_t nb_
         std::memcpy(&d.beta2, &small2[0], 128); std::memcpy(&d.delta2, &small2[1], 128);
         d.infinity_a = ia.data(); d.infinity_b = ib.data();
         d.committed_wires = committed_wires; d.n_committed = n_committed;
-        MI_TRY(mi_pk_load_range(ctx, &d, out, true, nullptr, /*adopt=*/true));
-        for (void *&a : arrays) a = nullptr;   // the key owns them now
+        bool took = false;
+        const int32_t lr = mi_pk_load_range(ctx, &d, out, true, nullptr, /*adopt=*/true, &took);
+        if (took) for (void *&a : arrays) a = nullptr;   // the key owns them now (it has released them itself if it failed after taking them)
+        MI_TRY(lr);
         // Pedersen commitment keys
         if (ped_out) {
             for (uint32_t k = 0; k < in.n_commitment_keys; k++) {

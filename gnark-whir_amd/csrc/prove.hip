@@ -26,13 +26,15 @@ static int32_t upload(mi_ctx *ctx, void **dst, const void *src, size_t bytes) {
     return MI_OK;
 }
 
-int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr, bool adopt) {
+int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr, bool adopt, bool *took_arrays) {
+    if (took_arrays) *took_arrays = false;
     if (!ctx || !d || !out) return MI_EINVAL;
     *out = nullptr;
-    if (sr && device_points) return MI_EINVAL;
+    // device_points with a range (mi_pk_load_sharded_dev): the arrays ARE this part's slices (counts = points of the slice)
     if (d->log_n > 28 || d->nb_public > d->nb_wires || !d->infinity_a || !d->infinity_b) MI_FAIL(ctx, MI_EINVAL, "pk: bad header");
     const u64 N = (u64)1 << d->log_n;
-    if (d->n_g1_z + 1 < N) MI_FAIL(ctx, MI_EINVAL, "pk: G1.Z needs at least 2^log_n - 1 points");
+    const bool slices = sr && device_points;
+    if (!slices && d->n_g1_z + 1 < N) MI_FAIL(ctx, MI_EINVAL, "pk: G1.Z needs at least 2^log_n - 1 points");
     if (d->nb_wires >= ((u64)1 << 31)) MI_FAIL(ctx, MI_EINVAL, "pk: too many wires");
     if (d->n_g2_b != d->n_g1_b) MI_FAIL(ctx, MI_EINVAL, "pk: G1.B and G2.B differ in length");
     // gather indices from the static masks (prove.go: wireValuesA/B filters; K drops public + committed)
@@ -56,7 +58,10 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
         }
     }
     if (w_lo >= d->nb_wires) { a0 = ca; b0 = cb; k0 = ck; }
-    if (ca != d->n_g1_a || cb != d->n_g1_b || ck != d->n_g1_k)
+    if (slices) {
+        if (ia.size() != d->n_g1_a || ib.size() != d->n_g1_b || ik.size() != d->n_g1_k || d->n_g1_z < z_hi - z_lo)
+            MI_FAIL(ctx, MI_EINVAL, "pk: slice point counts do not match the infinity masks / public / committed wire sets of this rank's wire range");
+    } else if (ca != d->n_g1_a || cb != d->n_g1_b || ck != d->n_g1_k)
         MI_FAIL(ctx, MI_EINVAL, "pk: point counts do not match the infinity masks / public / committed wire sets");
     mi_pk *pk = new (std::nothrow) mi_pk();
     if (!pk) return MI_ENOMEM;
@@ -69,7 +74,10 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
     int32_t rc = MI_OK;
     if (device_points) {
         pk->g1_a = (void *)d->g1_a; pk->g1_b = (void *)d->g1_b; pk->g1_k = (void *)d->g1_k; pk->g1_z = (void *)d->g1_z; pk->g2_b = (void *)d->g2_b;
-        pk->owns_points = adopt;   // mi_pk_load_raw hands its converted arrays over; on failure they stay the caller's (below)
+        // mi_pk_load_raw hands its converted arrays over (adopt): from here on they are the key's, on success AND on every failure
+        // path below (mi_pk_free releases what is still there); *took_arrays tells the caller so
+        pk->owns_points = adopt;
+        if (adopt && took_arrays) *took_arrays = true;
     } else {
         pk->owns_points = true;
         if (rc == MI_OK) rc = upload(ctx, &pk->g1_a, d->g1_a + a0, pk->n_a * 64);
@@ -138,7 +146,7 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
         if (rc == MI_OK) rc = group(pk->c_ak, &pk->pre_a, pk->a_full, 1, &pk->pre_k, pk->k_full, 1, pk->nb_wires);
     }
     if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pk upload sync failed"; rc = MI_EHIP; }
-    if (rc != MI_OK) { if (device_points) pk->owns_points = false; mi_pk_free(ctx, pk); return rc; }
+    if (rc != MI_OK) { if (device_points && !adopt) pk->owns_points = false; mi_pk_free(ctx, pk); return rc; }
     // the compact A and K copies are not needed any more when the library owns them; nor are plain bases that have tables
     if (pk->owns_points) { (void)hipFree(pk->g1_a); (void)hipFree(pk->g1_k); pk->g1_a = pk->g1_k = nullptr; }
     if (pk->c_ak) { (void)hipFree(pk->a_full); (void)hipFree(pk->k_full); pk->a_full = pk->k_full = nullptr; }
@@ -257,6 +265,28 @@ int32_t mi_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *chal
     }
     G1Aff a = xyzz_to_affine(acc);
     std::memcpy(out, &a, sizeof(a));
+    return MI_OK;
+}
+int32_t mi_get_mem_ledger(mi_ctx *ctx, const mi_pk *pk, mi_mem_ledger *out) {
+    if (!ctx || !out) return MI_EINVAL;
+    std::memset(out, 0, sizeof(*out));
+    auto nwin_of = [](u32 c) { return (size_t)((256 + c - 1) / c); };
+    if (pk) {
+        const size_t g1 = sizeof(G1Aff), g2 = sizeof(G2Aff);
+        if (pk->owns_points) out->key_bases += (pk->g1_a ? pk->n_a * g1 : 0) + (pk->g1_k ? pk->n_k * g1 : 0) + (pk->g1_b ? pk->n_b * g1 : 0) + (pk->g2_b ? pk->n_b * g2 : 0) + (pk->g1_z ? pk->n_z * g1 : 0);
+        out->key_bases += (pk->a_full ? pk->nb_wires * g1 : 0) + (pk->k_full ? pk->nb_wires * g1 : 0);
+        out->key_bases += (pk->b1_copy ? pk->n_b * g1 : 0) + (pk->b2_copy ? pk->n_b * g2 : 0) + (pk->z_copy ? pk->n_z_msm * g1 : 0);
+        if (pk->c_ak) out->key_tables += 2 * nwin_of(pk->c_ak) * pk->nb_wires * g1;
+        if (pk->c_b) out->key_tables += nwin_of(pk->c_b) * pk->n_b * (g1 + g2);
+        if (pk->c_z) out->key_tables += nwin_of(pk->c_z) * pk->n_z_msm * g1;
+        out->key_indices = (pk->n_a + pk->n_b + pk->n_k) * 4;
+    }
+    out->ctx_ntt_tables = mi_ntt_table_bytes(ctx);
+    for (int i = 0; i < 24; i++) {
+        const size_t cap = ctx->ws[i].cap;
+        if (i == 0 || i == 1 || i == 14) out->ctx_ntt_vectors += cap; else out->ctx_other += cap;
+    }
+    for (const auto &sl : ctx->msm) for (const auto &b : sl.buf) out->ctx_msm += b.cap;
     return MI_OK;
 }
 int32_t mi_pk_load(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out) {

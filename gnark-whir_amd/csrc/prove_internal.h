@@ -36,7 +36,10 @@ struct mi_pk {
 
 struct ShardRange { u64 w_lo, w_hi, z_lo, z_hi; };   // wires [w_lo, w_hi), Z pairs [z_lo, z_hi)
 // mi_pk_load / mi_pk_load_dev (sr == nullptr) or one part of a sharded key (host arrays only)
-int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr, bool adopt = false);
+// sr with device_points: the arrays are this part's slices on ctx's device (mi_pk_load_sharded_dev).
+// adopt (device_points only): the key takes ownership of the five arrays; *took_arrays = true once it has (then they are released by
+// the key on success and by this function on failure -- the caller must not free them again).
+int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr, bool adopt = false, bool *took_arrays = nullptr);
 // a Pedersen key over device arrays the key takes ownership of (mi_pk_load_raw)
 extern "C" int32_t mi_pedersen_pk_adopt(mi_ctx *ctx, void *basis_dev, void *basis_exp_sigma_dev, size_t n, mi_pedersen_pk **out);
 // The wire MSMs (A, B1, B2, K on slots 0..3) over W_dev = this key's wire range, ordered after ev_w; the Z MSM (slot 4) over

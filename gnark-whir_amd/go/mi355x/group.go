@@ -19,6 +19,7 @@ import (
 	"github.com/consensys/gnark-crypto/ecc/bn254"
 	"github.com/consensys/gnark-crypto/ecc/bn254/fr"
 	groth16_bn254 "github.com/consensys/gnark/backend/groth16/bn254"
+	cs "github.com/consensys/gnark/constraint/bn254"
 )
 
 // Group is a set of devices that prove together.
@@ -46,15 +47,21 @@ func (gr *Group) status(rc C.int32_t) error {
 	return fmt.Errorf("mi355x: rc=%d: %s", int(rc), C.GoString(C.mi_group_last_error(gr.g)))
 }
 
-// LoadKey shards pk over the group's devices; d is the descriptor ProvingKey.setup fills (mi355x.go).
-func (gr *Group) LoadKey(d *C.mi_pk_desc) error {
-	return gr.status(C.mi_pk_load_sharded(gr.g, d, &gr.spk))
+// LoadKey shards pk over the group's devices.  The descriptor is built in C memory over pinned Go arrays (ProvingKey.withKeyDesc,
+// mi355x.go: a Go struct holding Go pointers must not be passed to C by address).
+func (gr *Group) LoadKey(pk *ProvingKey, r1cs *cs.R1CS) error {
+	return pk.withKeyDesc(r1cs, func(d *C.mi_pk_desc) error {
+		return gr.status(C.mi_pk_load_sharded(gr.g, d, &gr.spk))
+	})
 }
 
 // ProveSolved runs the post-solve part of groth16.Prove over the group (W, a, b, c from r1cs.Solve; r, s sampled by the caller
 // in prove.go's order).
 func (gr *Group) ProveSolved(W, a, b, c []fr.Element, r, s *fr.Element, mode uint32) (*groth16_bn254.Proof, error) {
-	var out C.mi_proof_out
+	if len(W) == 0 || len(a) == 0 || len(b) != len(a) || len(c) != len(a) {
+		return nil, fmt.Errorf("mi355x: empty or ragged solution")
+	}
+	var out C.mi_proof_out // a Go value without pointers, written during the call only
 	rc := C.mi_groth16_prove_sharded(gr.g, gr.spk,
 		(*C.mi_fr)(unsafe.Pointer(&W[0])), C.size_t(len(W)),
 		(*C.mi_fr)(unsafe.Pointer(&a[0])), (*C.mi_fr)(unsafe.Pointer(&b[0])), (*C.mi_fr)(unsafe.Pointer(&c[0])), C.size_t(len(a)),

@@ -73,36 +73,76 @@ func (pk *ProvingKey) setup(r1cs *cs.R1CS, device int) error {
 			pk.err = fmt.Errorf("mi355x: mi_prover_create rc=%d", int(rc))
 			return
 		}
-		var d C.mi_pk_desc
-		d.log_n = C.uint32_t(log2(pk.Domain.Cardinality))
-		d.nb_public = C.uint32_t(r1cs.GetNbPublicVariables())
-		d.nb_wires = C.uint64_t(len(pk.InfinityA))
-		// &s[0] panics on an empty slice (all-public circuits have no K points, tiny ones may lack A or B): g1/g2 guard it
-		d.g1_a, d.n_g1_a = g1(pk.G1.A), C.uint64_t(len(pk.G1.A))
-		d.g1_b, d.n_g1_b = g1(pk.G1.B), C.uint64_t(len(pk.G1.B))
-		d.g1_k, d.n_g1_k = g1(pk.G1.K), C.uint64_t(len(pk.G1.K))
-		d.g1_z, d.n_g1_z = g1(pk.G1.Z), C.uint64_t(len(pk.G1.Z))
-		d.g2_b, d.n_g2_b = g2(pk.G2.B), C.uint64_t(len(pk.G2.B))
-		d.alpha1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Alpha))
-		d.beta1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Beta))
-		d.delta1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Delta))
-		d.beta2 = *(*C.mi_g2_affine)(unsafe.Pointer(&pk.G2.Beta))
-		d.delta2 = *(*C.mi_g2_affine)(unsafe.Pointer(&pk.G2.Delta))
-		// []bool is one byte per element in Go's memory model
-		d.infinity_a = (*C.uint8_t)(unsafe.Pointer(&pk.InfinityA[0]))
-		d.infinity_b = (*C.uint8_t)(unsafe.Pointer(&pk.InfinityB[0]))
-		// wires removed from the K MSM: private committed + commitment wires (prove.go "toRemove")
-		info := r1cs.CommitmentInfo.(constraint.Groth16Commitments)
-		removed := sortedUint32(append(flatten(info.GetPrivateCommitted()), info.CommitmentIndexes()...))
-		if len(removed) > 0 {
-			d.committed_wires, d.n_committed = (*C.uint32_t)(unsafe.Pointer(&removed[0])), C.uint64_t(len(removed))
-		}
-		pk.err = status(pk.ctx, C.mi_pk_load(pk.ctx, &d, &pk.dev))
-		runtime.KeepAlive(removed)
+		pk.err = pk.withKeyDesc(r1cs, func(d *C.mi_pk_desc) error {
+			return status(pk.ctx, C.mi_pk_load(pk.ctx, d, &pk.dev))
+		})
 	})
 	return pk.err
 }
 
+// withKeyDesc builds the mi_pk_desc of this key and hands it to fn (mi_pk_load, mi_pk_load_sharded).
+//
+// cgo pointer passing: the descriptor holds POINTERS to the key's Go slices, so it must not be a Go variable handed to C by
+// address -- cgocheck rejects "Go pointer to unpinned Go pointer".  The descriptor therefore lives in C memory (C.calloc) and every
+// Go array it points to is pinned with a runtime.Pinner for the duration of fn (Go >= 1.21: a Go pointer may be stored in C memory
+// while its target is pinned).  The library reads the arrays during the call only and keeps none of these pointers.
+func (pk *ProvingKey) withKeyDesc(r1cs *cs.R1CS, fn func(d *C.mi_pk_desc) error) error {
+	if len(pk.InfinityA) == 0 || len(pk.InfinityB) != len(pk.InfinityA) {
+		return errors.New("mi355x: proving key without wires")
+	}
+	d := (*C.mi_pk_desc)(C.calloc(1, C.size_t(unsafe.Sizeof(C.mi_pk_desc{}))))
+	if d == nil {
+		return errors.New("mi355x: out of memory")
+	}
+	defer C.free(unsafe.Pointer(d))
+	var pin runtime.Pinner
+	defer pin.Unpin()
+	d.log_n = C.uint32_t(log2(pk.Domain.Cardinality))
+	d.nb_public = C.uint32_t(r1cs.GetNbPublicVariables())
+	d.nb_wires = C.uint64_t(len(pk.InfinityA))
+	// &s[0] panics on an empty slice (all-public circuits have no K points, tiny ones may lack A or B): g1 / g2 guard it and pin
+	d.g1_a, d.n_g1_a = g1(&pin, pk.G1.A), C.uint64_t(len(pk.G1.A))
+	d.g1_b, d.n_g1_b = g1(&pin, pk.G1.B), C.uint64_t(len(pk.G1.B))
+	d.g1_k, d.n_g1_k = g1(&pin, pk.G1.K), C.uint64_t(len(pk.G1.K))
+	d.g1_z, d.n_g1_z = g1(&pin, pk.G1.Z), C.uint64_t(len(pk.G1.Z))
+	d.g2_b, d.n_g2_b = g2(&pin, pk.G2.B), C.uint64_t(len(pk.G2.B))
+	d.alpha1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Alpha)) // copied by value: no pointer kept
+	d.beta1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Beta))
+	d.delta1 = *(*C.mi_g1_affine)(unsafe.Pointer(&pk.G1.Delta))
+	d.beta2 = *(*C.mi_g2_affine)(unsafe.Pointer(&pk.G2.Beta))
+	d.delta2 = *(*C.mi_g2_affine)(unsafe.Pointer(&pk.G2.Delta))
+	// []bool is one byte per element in Go's memory model
+	pin.Pin(&pk.InfinityA[0])
+	pin.Pin(&pk.InfinityB[0])
+	d.infinity_a = (*C.uint8_t)(unsafe.Pointer(&pk.InfinityA[0]))
+	d.infinity_b = (*C.uint8_t)(unsafe.Pointer(&pk.InfinityB[0]))
+	// wires removed from the K MSM: private committed + commitment wires (prove.go "toRemove")
+	info := r1cs.CommitmentInfo.(constraint.Groth16Commitments)
+	removed := sortedUint32(append(flatten(info.GetPrivateCommitted()), info.CommitmentIndexes()...))
+	if len(removed) > 0 {
+		pin.Pin(&removed[0])
+		d.committed_wires, d.n_committed = (*C.uint32_t)(unsafe.Pointer(&removed[0])), C.uint64_t(len(removed))
+	}
+	return fn(d)
+}
+
+// Every C call of this package and the rule that makes its pointer arguments legal (cmd/cgo "Passing pointers"):
+//   mi_init(&pk.ctx), mi_prover_create(&pk.pool), mi_pk_load(.., &pk.dev), mi_pedersen_pk_load(.., &pk.ped[i]), mi_group_create(&g),
+//   mi_pk_load_sharded(.., &gr.spk)      pointer to ONE field / element that receives a C pointer: the memory passed is that field
+//                                        (or a slice backing array of C pointers) and holds no Go pointer
+//   mi_pk_load / mi_pk_load_sharded(d)   d is C memory; the Go arrays it points to are pinned (withKeyDesc)
+//   mi_prover_submit(W, a, b, c, &r, &s, out, &ticket)
+//                                        W, a, b, c: flat []fr.Element backing arrays (no pointers inside), pinned because a worker
+//                                        thread reads them after the call returns; r, s, ticket: Go values without pointers, used
+//                                        during the call only; out: C memory (written after the call returns)
+//   mi_groth16_prove_sharded(W, a, b, c, r, s, &out)
+//                                        flat arrays / values without pointers, used during the call only
+//   mi_pedersen_commit / _prove_knowledge / _fold
+//                                        flat []fr.Element / []bn254.G1Affine backing arrays and values, during the call only
+//   mi_group_create(&ids[0])             []C.int backing array
+//   mi_last_error / mi_prover_last_error / mi_group_last_error
+//                                        C strings owned by the library, copied at once with C.GoString
+//
 // Prove mirrors groth16_bn254.Prove: solve on the CPU (gnark's solver, incl. the reference's
 // utilities.IndexOf hint passed through opts), everything after it on the GPU.
 func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...backend.ProverOption) (*groth16_bn254.Proof, error) {
@@ -277,16 +317,19 @@ func (pk *ProvingKey) batchProve(values [][]fr.Element, challenge fr.Element) (b
 
 func log2(n uint64) int { k := 0; for (uint64(1) << k) < n { k++ }; return k }
 
-func g1(s []bn254.G1Affine) *C.mi_g1_affine {
+// g1 / g2: address of a point slice's backing array for a descriptor in C memory; the array is pinned until pin.Unpin
+func g1(pin *runtime.Pinner, s []bn254.G1Affine) *C.mi_g1_affine {
 	if len(s) == 0 {
 		return nil
 	}
+	pin.Pin(&s[0])
 	return (*C.mi_g1_affine)(unsafe.Pointer(&s[0]))
 }
-func g2(s []bn254.G2Affine) *C.mi_g2_affine {
+func g2(pin *runtime.Pinner, s []bn254.G2Affine) *C.mi_g2_affine {
 	if len(s) == 0 {
 		return nil
 	}
+	pin.Pin(&s[0])
 	return (*C.mi_g2_affine)(unsafe.Pointer(&s[0]))
 }
 

@@ -133,8 +133,10 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk);
 
 /* ---- proving key from gnark's own serialisation: the stream groth16 bn254 ProvingKey.WriteRawTo writes
  * (gnark v0.11.0, go.mod:6; the reference itself re-runs Setup on every run, mt.go:448, and never writes one).
- * LAYOUT RECALLED, UNVERIFIED -- spelled out in oracle/pk_raw.py and csrc/pk_raw.hip; the parser cross-checks every count and
- * refuses anything else with MI_EINVAL.  nb_public and the wires removed from the K MSM come from the constraint system, not
+ * EXPERIMENTAL: LAYOUT RECALLED, UNVERIFIED -- spelled out in oracle/pk_raw.py and csrc/pk_raw.hip; the parser cross-checks every count
+ * and refuses a shifted layout with MI_EINVAL, but the bit order inside the packed InfinityA/B masks (taken as MSB-first) is checked by
+ * nothing: until a real gnark fixture has been loaded and a proof from it verified, do not rely on this entry point (mi_pk_load is the
+ * supported one).  nb_public and the wires removed from the K MSM come from the constraint system, not
  * from the key file.  ped_out (room for MI_PK_RAW_MAX_COMMITMENTS handles, may be NULL) receives the key's Pedersen
  * commitment keys for mi_pedersen_*; free them with mi_pedersen_pk_free. ---- */
 #define MI_PK_RAW_MAX_COMMITMENTS 16
@@ -196,6 +198,18 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, size_t 
                              mi_proof_out *out, mi_stats *stats);
 /* Stats of the last mi_msm_* / mi_ntt* / mi_compute_h* / prove call on ctx. */
 int32_t mi_get_stats(mi_ctx *ctx, mi_stats *out);
+/* Device memory the library holds, in bytes: what a proving key keeps resident (pk may be NULL) and what a context has grown to
+ * (grow-only workspaces; a prover pool has one such set per context in flight).  For capacity planning at N = 2^26. */
+typedef struct mi_mem_ledger {
+    uint64_t key_bases;        /* pk.G1.{A,B,K,Z} / pk.G2.B arrays the key still holds (incl. per-wire expanded and converted copies) */
+    uint64_t key_tables;       /* fixed-base window tables */
+    uint64_t key_indices;      /* gather-index arrays from the infinity masks */
+    uint64_t ctx_ntt_tables;   /* computeH's twiddle / coset tables of this context */
+    uint64_t ctx_ntt_vectors;  /* the two N-element vectors computeH works in + h */
+    uint64_t ctx_msm;          /* workspaces of the context's MSM slots (digits, histograms, sorted entries, partial sums, buckets) */
+    uint64_t ctx_other;        /* staging areas for host inputs and the rest */
+} mi_mem_ledger;
+int32_t mi_get_mem_ledger(mi_ctx *ctx, const mi_pk *pk, mi_mem_ledger *out);
 
 /* ---- prover pool: several proofs in flight on one device.
  * The reference proves one circuit per groth16.Prove call (mt.go:496) and a prover service issues those calls from many
@@ -232,7 +246,11 @@ int32_t mi_prover_wait(mi_prover *p, uint64_t ticket);
  *   mode 1  "all-reduce of partial bucket sums": every rank stops at its bucket sums, rank r receives the keys it owns from
  *           every other rank (reduce-scatter as grouped ncclSend / ncclRecv, one hop on the xGMI mesh), adds them, reduces
  *           its slice; the per-rank results are combined as in mode 0.
- * Results are bit-identical to the unsharded entry points.  Calls on one group must not overlap. ---- */
+ * Results are bit-identical to the unsharded entry points.  A group serves ONE call at a time: an entry point called while another
+ * call on the same group is still running returns MI_EINVAL at once and touches nothing (the exchange streams and receive
+ * buffers belong to the running call).  A process holds either ALL ranks of a group (mi_group_create) or exactly ONE
+ * (mi_group_create_rank); with one rank per process every process makes the same calls in the same order (they are
+ * collectives), each with its own rank's data. ---- */
 typedef struct mi_group mi_group;
 typedef struct mi_pk_sharded mi_pk_sharded;
 /* all ranks in this process, one context per entry of dev_ids (SURVEY 8b proposed mi_init(dev_ids, n_dev, ...)).  Distinct
@@ -249,16 +267,32 @@ const char *mi_group_last_error(mi_group *g);
 int32_t mi_group_transport(const mi_group *g);             /* 1 = RCCL, 2 = peer copies */
 /* transport check: every rank sends `bytes` patterned bytes to every rank (itself included) and verifies what it received */
 int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes);
-/* desc: the same whole-key descriptor as mi_pk_load (host arrays) */
+/* desc: the same whole-key descriptor as mi_pk_load (host arrays); with one rank per process every process passes the whole
+ * descriptor and keeps its own rank's slice.  The fixed-base table plan is agreed over the whole group (tightest device). */
 int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *desc, mi_pk_sharded **out);
+/* slice_descs[i], i < mi_group_local(): header (log_n, nb_public, nb_wires) and masks of the WHOLE key in host memory; the five
+ * point arrays are DEVICE pointers on local rank i's device to that rank's slices (the points of wires [nb_wires r / world,
+ * nb_wires (r+1) / world) and the Z pairs [(N-1) r / world, (N-1)(r+1) / world), r = global rank), counts = points of the slice.
+ * Adopted by reference like mi_pk_load_dev (the caller keeps them alive). */
+int32_t mi_pk_load_sharded_dev(mi_group *g, const mi_pk_desc *slice_descs, mi_pk_sharded **out);
 int32_t mi_pk_sharded_free(mi_group *g, mi_pk_sharded *pk);
-/* single-process groups; arguments as mi_groth16_prove */
+/* groth16.Prove after the solve (mt.go:496) over the ranks of the group; arguments as mi_groth16_prove.  W is the WHOLE wire
+ * vector: a process reads only the wire ranges of its local ranks.  a, b, c are read by the process that holds rank 0 (which runs
+ * computeH and hands every rank its slice of h over the group's transport); other processes may pass NULL.  Every process
+ * receives the proof. */
 int32_t mi_groth16_prove_sharded(mi_group *g, mi_pk_sharded *pk, const mi_fr *W, size_t n_wires,
                                  const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
                                  const mi_fr *r, const mi_fr *s, uint32_t mode, mi_proof_out *out, mi_stats *stats_or_null);
+/* the same with the inputs already in HBM: W_dev[i] = the wire range of local rank i on its device (n_wires = the WHOLE count);
+ * a_dev, b_dev, c_dev on rank 0's device (NULL in the other processes) */
+int32_t mi_groth16_prove_sharded_dev(mi_group *g, mi_pk_sharded *pk, const mi_fr *const *W_dev, size_t n_wires,
+                                     const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev, size_t n_constraints,
+                                     const mi_fr *r, const mi_fr *s, uint32_t mode, mi_proof_out *out, mi_stats *stats_or_null);
 /* one MSM over host arrays cut into contiguous slices (single-process groups) */
 int32_t mi_msm_g1_sharded(mi_group *g, const mi_g1_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags,
                           uint32_t mode, mi_g1_jac *out);
+int32_t mi_msm_g2_sharded(mi_group *g, const mi_g2_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags,
+                          uint32_t mode, mi_g2_jac *out);
 /* one MSM whose pairs already sit on the ranks' devices: arrays of mi_group_local() device pointers / counts; n_total = pairs
  * over ALL ranks (every rank passes the same value: it fixes the common window width).  Every rank receives the result. */
 int32_t mi_msm_g1_sharded_dev(mi_group *g, const mi_g1_affine *const *pts_dev, const mi_fr *const *scalars_dev,

@@ -91,3 +91,20 @@ def test_full_length_msms_equal_oracle(ctx, case):
     assert np.array_equal(got2, cref.msm_g2(case["pk"]["g2_b"], wb))
     got1 = ctx.msm_g1(case["pk"]["g1_b"], wb)
     assert np.array_equal(got1, cref.msm_g1(case["pk"]["g1_b"], wb))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sharded_prove_two_ranks_at_baseline_size(case, mode):
+    """N = 2^23 over a 2-rank group on device 0 (same partitioning, per-rank Pippenger with the automatic fixed-base tables, h slices
+    and -- mode 1 -- bucket slices moved by the group's transport): proof bytes == the oracle's.  Ranks on
+    DISTINCT devices have never run (this box has one GPU)."""
+    B = load_binding()
+    g = B.Group([0, 0])
+    try:
+        spk = g.pk_load(case["pk"])
+        got, st = g.prove(spk, case["W"], case["a"], case["b"], case["c"], case["r"], case["s"], mode=mode)
+        g.pk_free(spk)
+        print(f"sharded prove N=2^{LOG_N}, 2 ranks on one device, mode {mode}, host inputs: {st['total_ms']:.1f} ms")
+        assert B.proof_write(got["raw"]) == cref.proof_write(case["want"]["raw"])
+    finally:
+        g.close()

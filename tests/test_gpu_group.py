@@ -62,6 +62,90 @@ def test_sharded_msm_dev_g1_g2_vs_oracle(B, grp, mode):
         d.free()
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sharded_msm_g2_host_arrays_vs_oracle(grp, mode):
+    """mi_msm_g2_sharded: the G2 twin of the host-array entry point"""
+    n = 3001
+    pts = cref.gen_g2(n, 77); sc = cref.gen_scalars(n, 78, 1)
+    pts[4] = 0; sc[2] = 0
+    assert np.array_equal(grp.msm_g2(pts, sc, mode=mode), cref.msm_g2(pts, sc))
+
+
+def _slices(B, grp, pk, keep):
+    """per local rank: device copies of that rank's slices of the five point arrays (what mi_pk_load_sharded_dev adopts)"""
+    N = 1 << pk["log_n"]
+    ia, ib = np.asarray(pk["infinity_a"]), np.asarray(pk["infinity_b"])
+    cw = set(int(x) for x in (pk.get("committed_wires") if pk.get("committed_wires") is not None else []))
+    in_k = np.array([j >= pk["nb_public"] and j not in cw for j in range(pk["nb_wires"])])
+    ca, cb, ck = np.concatenate([[0], np.cumsum(ia == 0)]), np.concatenate([[0], np.cumsum(ib == 0)]), np.concatenate([[0], np.cumsum(in_k)])
+    out = []
+    for r in range(grp.world):
+        c = grp.ctx(r)
+        lo, hi = B.shard_range(pk["nb_wires"], grp.world, r); zlo, zhi = B.shard_range(N - 1, grp.world, r)
+        sl = {}
+        for name, arr in (("g1_a", pk["g1_a"][ca[lo]:ca[hi]]), ("g1_b", pk["g1_b"][cb[lo]:cb[hi]]), ("g1_k", pk["g1_k"][ck[lo]:ck[hi]]),
+                          ("g1_z", pk["g1_z"][zlo:zhi]), ("g2_b", pk["g2_b"][cb[lo]:cb[hi]])):
+            d = c.to_dev(arr); keep.append(d); sl[name] = (d.ptr, arr.shape[0])
+        out.append(sl)
+    return out
+
+
+@pytest.mark.parametrize("log_n,nb_public,n_committed", [(13, 5, 0), (15, 4097, 23)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sharded_prove_device_slices_and_device_inputs(B, grp, log_n, nb_public, n_committed, mode):
+    """mi_pk_load_sharded_dev (every rank's slices already on its device) + mi_groth16_prove_sharded_dev (W ranges, a, b, c in HBM):
+    the shape bench.py times for BASELINE configs[4]; bytes == oracle"""
+    N = 1 << log_n
+    nb_wires, n_constraints = N - 50, N - 10
+    pk = synthetic_pk(log_n, nb_wires, nb_public, 8000 + log_n, n_committed=n_committed)
+    W = cref.gen_scalars(nb_wires, 11, 1)
+    a = cref.gen_scalars(n_constraints, 12, 1); b = cref.gen_scalars(n_constraints, 13, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 14, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    keep = []
+    spk = grp.pk_load_dev(pk, _slices(B, grp, pk, keep))
+    Wp = []
+    for rk in range(grp.world):
+        lo, hi = B.shard_range(nb_wires, grp.world, rk)
+        d = grp.ctx(rk).to_dev(W[lo:hi]); keep.append(d); Wp.append(d.ptr)
+    c0 = grp.ctx(0)
+    da, db, dc = c0.to_dev(a), c0.to_dev(b), c0.to_dev(c); keep += [da, db, dc]
+    got, st = grp.prove_dev(spk, Wp, nb_wires, da.ptr, db.ptr, dc.ptr, n_constraints, r, s, mode=mode)
+    got2, _ = grp.prove(spk, W, a, b, c, r, s, mode=mode)   # the same sharded key through the host-input entry point
+    grp.pk_free(spk)
+    for d in keep:
+        d.free()
+    assert B.proof_write(got["raw"]) == want and B.proof_write(got2["raw"]) == want
+    bad = dict(pk); bad["nb_public"] = nb_public + 1   # slice counts no longer match the masks / public set
+    keep2 = []
+    with pytest.raises(B.MiError):
+        grp.pk_load_dev(bad, _slices(B, grp, pk, keep2))
+    for d in keep2:
+        d.free()
+
+
+def test_group_refuses_overlapping_calls(B, grp):
+    """a group serves one call at a time: a call that arrives while another is running gets MI_EINVAL and disturbs nothing"""
+    import threading
+    n = 1 << 21
+    c0 = grp.ctx(0)
+    dp, ds = c0.gen_g1(n, 5150), c0.gen_scalars(n, 5151, 0)
+    pts, sc = dp.download((n, 8)), ds.download((n, 4)); dp.free(); ds.free()
+    want = grp.msm_g1(pts, sc)   # also sizes the workspaces
+    res = {}
+    th = threading.Thread(target=lambda: res.update(got=grp.msm_g1(pts, sc)))
+    th.start()
+    refused = ok = 0
+    while th.is_alive():
+        rc = grp.lib.mi_group_exchange_selftest(grp.h, 4096)
+        assert rc in (0, -1)
+        refused += rc == -1; ok += rc == 0
+    th.join()
+    assert np.array_equal(res["got"], want)
+    assert refused >= 1, (refused, ok)
+    grp.exchange_selftest(4096)   # and the group still works
+
+
 def _toy():
     z = np.load(os.path.join(GOLD, "prove_toy1000.npz"))
     pk = {k: z[k] for k in ("g1_a", "g1_b", "g1_k", "g1_z", "g2_b", "alpha1", "beta1", "delta1", "beta2", "delta2", "infinity_a", "infinity_b")}
