@@ -1,6 +1,7 @@
 // Library-internal context shared by the HIP translation units (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -33,6 +34,7 @@ struct mi_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
+    std::mutex err_m;          // a prove enqueues its MSM groups from helper threads (prove.hip): failures there report through mi_set_err
     mi_stats stats{};
     hipEvent_t ev[24]{};
     // scratch
@@ -53,17 +55,18 @@ static inline bool mi_fault_hit() {
     if (mi_fault_countdown.load(std::memory_order_relaxed) <= 0) return false;
     return mi_fault_countdown.fetch_sub(1, std::memory_order_relaxed) == 1;
 }
+static inline void mi_set_err(struct mi_ctx *ctx, const std::string &msg);
 #define MI_CHECK_HIP(ctx, call)                                                                       \
     do {                                                                                              \
         hipError_t e__ = mi_fault_hit() ? hipErrorUnknown : (call);                                   \
         if (e__ != hipSuccess) {                                                                      \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                          \
+            mi_set_err((ctx), std::string(#call) + ": " + hipGetErrorString(e__));                    \
             return e__ == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP;                                  \
         }                                                                                             \
     } while (0)
 #define MI_FAIL(ctx, code, msg)                                                                       \
     do {                                                                                              \
-        (ctx)->err = (msg);                                                                           \
+        mi_set_err((ctx), (msg));                                                                     \
         return (code);                                                                                \
     } while (0)
 #define MI_TRY(expr)                                                                                  \
@@ -71,6 +74,11 @@ static inline bool mi_fault_hit() {
         int32_t rc__ = (expr);                                                                        \
         if (rc__ != MI_OK) return rc__;                                                               \
     } while (0)
+
+static inline void mi_set_err(struct mi_ctx *ctx, const std::string &msg) {
+    std::lock_guard<std::mutex> lk(ctx->err_m);
+    ctx->err = msg;
+}
 
 // grow-only scratch
 static inline int32_t mi_reserve(mi_ctx *ctx, DevBuf &b, size_t bytes) {

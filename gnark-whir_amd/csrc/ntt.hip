@@ -37,6 +37,7 @@ struct NttState {
     u32 plan_set = 0;      // the knobs above were set by the caller: no per-size defaults
     u32 wave_stages = 1;   // passes of radix >= 2^7 run their last / first seven stages in registers (k_ntt_pass_wave); 0 = all through LDS
     u32 fuse_pair = 1;     // computeH: inverse last pass + coset first pass of a and b as one launch (k_ntt_contig_pair)
+    u32 fuse_triple = 1;   // computeH: coset last pass of a and of b + the product a b + the last transform's first pass as one launch (k_ntt_strided_triple)
 };
 // Tile / radix knobs for a transform of 2^log_n: the caller's (mi_debug_set_ntt_plan) or, untouched, the measured best per size
 // (tools/ntt_probe.py sweep, profiles/r02_tune_ntt_sweep.json): 2^9 tiles and radices 2^7 2^7 2^9 up to 2^23; 2^10 tiles and
@@ -51,6 +52,7 @@ static NttState *state_of(mi_ctx *ctx) {
 __global__ void k_ntt_pass(Fr *dst, const Fr *src, NttPass p, NttTables t);
 __global__ void k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t);
 __global__ void k_ntt_contig_pair(Fr *data, NttPass pi, NttTables ti, NttPass pf, NttTables tf);
+__global__ void k_ntt_strided_triple(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl);
 void mi_ntt_state_init(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= sizeof(ctx->ntt_state), "NttState lives in ctx->ntt_state");
     new (ctx->ntt_state) NttState();
@@ -58,6 +60,7 @@ void mi_ntt_state_init(mi_ctx *ctx) {
     (void)hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_pass_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_contig_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
@@ -189,6 +192,39 @@ __global__ void __launch_bounds__(256) k_ntt_contig_pair(Fr *data, NttPass pi, N
         __syncthreads();
     }
     ntt_tile_store(pf, tf, data, tile, threadIdx.x, blockDim.x, lds);
+}
+
+// computeH's OTHER seam: the LAST pass of the coset FFT of a and of b (DIT, the strided M = N pass), the pointwise product a b, and the
+// FIRST pass of the last transform (DIF, inverse on the coset, the same strided tiles) as one launch.  A workgroup loads a's tile
+// (DIT pre-twiddle on the way in), runs the seven register stages and keeps the result in registers (a lane ends DIT holding rows L,
+// L + 64 -- exactly what the DIF stages start from), loads b's tile into the same LDS, does the same, multiplies, runs the DIF stages
+// and stores through LDS with the DIF post-twiddle.  Per element: the same products; four passes of a vector through HBM (store a,
+// store b, load a, load b: 1.07 GB at N = 2^23) and two launches less.  pc / tc: the coset FFT's last pass as ntt_run would have
+// launched it (for a and for b alike), pl / tl: the last transform's first pass (without load_mul).  Radix 2^7 exactly (no stage
+// through LDS) and one 128-row sub-block per wave (blockDim = 64 x sub-blocks of the tile).
+__global__ void __launch_bounds__(512) k_ntt_strided_triple(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl) {
+    extern __shared__ U4 lds[];
+    const u64 tile = blockIdx.x;
+    const u32 PL = ntt_plane_slots(pc);
+    const u32 lane = threadIdx.x & 63, sb = threadIdx.x >> 6;
+    const u32 col = sb & ((1u << pc.log_c) - 1), base = (sb >> pc.log_c) << 7;
+    const u32 s0 = ntt_lds_slot(pc, base + 2 * lane, col), s1 = ntt_lds_slot(pc, base + 2 * lane + 1, col);
+    ntt_tile_load(pc, tc, a, tile, threadIdx.x, blockDim.x, lds);
+    __syncthreads();
+    Fr a0 = lds_get(lds, PL, s0), a1 = lds_get(lds, PL, s1);
+    wave_ntt128(a0, a1, lane, true, tc.small);     // -> rows L, L + 64
+    __syncthreads();                               // every wave has read a's tile
+    ntt_tile_load(pc, tc, b, tile, threadIdx.x, blockDim.x, lds);
+    __syncthreads();
+    Fr x0 = lds_get(lds, PL, s0), x1 = lds_get(lds, PL, s1);
+    wave_ntt128(x0, x1, lane, true, tc.small);
+    x0 = x0 * a0; x1 = x1 * a1;
+    wave_ntt128(x0, x1, lane, false, tl.small);    // rows L, L + 64 -> positions 2L, 2L + 1
+    __syncthreads();                               // every wave has read b's tile
+    lds_put(lds, PL, ntt_lds_slot(pl, base + 2 * lane, col), x0);
+    lds_put(lds, PL, ntt_lds_slot(pl, base + 2 * lane + 1, col), x1);
+    __syncthreads();
+    ntt_tile_store(pl, tl, a, tile, threadIdx.x, blockDim.x, lds);
 }
 
 // direct factor tables (NttPass::tw_direct / sc_direct), one thread per entry, square-and-multiply
@@ -427,11 +463,34 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
     }
     MI_TRY(ntt_run(ctx, C, (const Fr *)c, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4));
     // 2. a, b <- FFT(., DIT, OnCoset)  (the rest of it when the first pass ran in the pair)
-    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, pair ? 1u : 0u));
-    MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, pair ? 1u : 0u));
     // 3. h <- den FFTInverse(a b, DIF, OnCoset) - c, left bit-reversed like gnark: the product a b is taken on the way into the
-    //    first pass, the subtraction on the way out of the last (no pointwise kernel, no extra round trip through HBM)
-    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C));
+    //    first pass, the subtraction on the way out of the last (no pointwise kernel, no extra round trip through HBM).
+    //    The coset FFT's LAST pass (of a and of b), the product and the last transform's FIRST pass share their strided tiles: one
+    //    launch (k_ntt_strided_triple) when that pass has radix 2^7 and a tile is one sub-block per wave
+    const u32 first_skip = pair ? 1u : 0u;
+    bool triple = st->fuse_triple && st->wave_stages && pl.n_pass >= 2 && pl.log_r[0] == 7;
+    NttPass pc{}, pc2{}, plast{};
+    NttTables tc{}, tc2{}, tlast{};
+    if (triple) {   // capture the two passes without launching anything, and check the tile shape before committing to the fused form
+        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, 2 | 4, &pc, &tc));
+        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, nullptr, 1 | 4, &plast, &tlast));
+        triple = pc.log_r == 7 && plast.log_r == 7 && pc.log_s == plast.log_s && pc.log_c == plast.log_c && pc.log_s != 0 && pc.log_r + pc.log_c >= 7 && pc.log_r + pc.log_c <= 10 &&
+                 pc.lds_pad == plast.lds_pad && !pc.scale && !plast.scale;
+    }
+    if (!triple) {
+        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip));
+        MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip));
+        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C));
+        return MI_OK;
+    }
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | 2, &pc2, &tc2));   // the passes between the seams
+    MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | 2, &pc2, &tc2));
+    // one wave per 128-row sub-block of the tile: 64 * 2^(log_r + log_c - 7) threads (256 at the default 2^9-element tiles)
+    hipLaunchKernelGGL(k_ntt_strided_triple, dim3(1u << (log_n - pc.log_r - pc.log_c)), dim3(64u << (pc.log_r + pc.log_c - 7)), (size_t)32 * ntt_plane_slots(pc), ctx->stream,
+                       A, (const Fr *)B, pc, tc, plast, tlast);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    ctx->stats.ntt_launches++;
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, C, 1));
     return MI_OK;
 }
 
@@ -453,8 +512,9 @@ int32_t mi_debug_set_ntt_wave_stages(mi_ctx *ctx, uint32_t on, uint32_t direct_m
     return MI_OK;
 }
 int32_t mi_debug_set_ntt_fuse_pair(mi_ctx *ctx, uint32_t on) {
-    if (!ctx || on > 1) return MI_EINVAL;
-    state_of(ctx)->fuse_pair = on;
+    if (!ctx || on > 3) return MI_EINVAL;
+    state_of(ctx)->fuse_pair = on & 1u;          // bit 0: the contiguous pair (k_ntt_contig_pair)
+    state_of(ctx)->fuse_triple = (on >> 1) & 1u;  // bit 1: the strided triple (k_ntt_strided_triple)
     return MI_OK;
 }
 int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads) {

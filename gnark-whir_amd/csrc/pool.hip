@@ -16,7 +16,7 @@
 // (20 ms per 1.07 GB proof at N = 2^23): done by the worker itself (round 1) it lengthened every context's cycle and cost
 // 13 % of the throughput; on the uploader it overlaps the previous proofs' kernels.
 #include <hip/hip_runtime.h>
-#include "ctx.h"
+#include "prove_internal.h"
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -38,6 +38,7 @@ struct Job {
     int32_t rc = MI_OK;
     bool done = false, waited = false;
     int set = -1;          // device input set a host job was staged into (released when the proof is done)
+    bool gated = false;    // handed to a worker as soon as W had arrived: a, b, c follow behind the set's ev_abc
     float h2d_ms = 0;      // wall-clock of the staging copies
     std::string err;
 };
@@ -45,6 +46,9 @@ struct InputSet {          // W | a | b | c of one staged host job
     void *p = nullptr;
     size_t cap = 0;
     bool busy = false;
+    hipEvent_t ev_w = nullptr, ev_abc = nullptr;   // on the copy stream: W complete / a, b, c complete
+    int abc_state = 0;     // under the pool mutex: 0 = a, b, c still being enqueued, 1 = ev_abc recorded, -1 = their upload failed
+    std::string abc_err;
 };
 }  // namespace
 
@@ -56,7 +60,7 @@ struct mi_prover {
     hipStream_t copy_stream = nullptr;
     std::vector<InputSet> sets;                 // in_flight + 1: one being filled while in_flight are being consumed
     std::mutex m;
-    std::condition_variable cv_work, cv_done, cv_up;
+    std::condition_variable cv_work, cv_done, cv_up, cv_abc;
     std::deque<Job *> upq;                      // host jobs waiting for the upload stage
     std::deque<Job *> queue;                    // jobs whose inputs are in HBM
     std::unordered_map<uint64_t, Job *> jobs;   // submitted, not yet collected by mi_prover_wait
@@ -89,7 +93,18 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
             j = p->queue.front();
             p->queue.pop_front();
         }
-        int32_t rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
+        int32_t rc;
+        if (j->gated) {
+            InputSet &set = p->sets[j->set];
+            const std::function<hipEvent_t()> abc = [&]() -> hipEvent_t {   // blocks until the uploader has RECORDED ev_abc (or given up)
+                std::unique_lock<std::mutex> lk(p->m);
+                p->cv_abc.wait(lk, [&] { return set.abc_state != 0; });
+                return set.abc_state > 0 ? set.ev_abc : nullptr;
+            };
+            rc = mi_groth16_prove_dev_gated(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats, set.ev_w, abc);
+        } else {
+            rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
+        }
         if (rc == MI_OK && j->host && j->stats) j->stats->h2d_ms = j->h2d_ms;
         finish_job(p, j, rc, rc != MI_OK ? mi_last_error(ctx) : nullptr);
     }
@@ -128,15 +143,14 @@ static void uploader_main(mi_prover *p) {
         }
         char *base = (char *)set.p;
         const auto t0 = std::chrono::steady_clock::now();
+        // W first; the job goes to a worker as soon as W is on its way (its wire MSMs wait for ev_w), a, b, c -- 3/4 of the bytes --
+        // follow while those MSMs run and computeH waits for ev_abc.  In steady state the uploader is a whole job ahead and none of
+        // this shows; it is the FIRST job of a burst (nothing to hide its upload behind) that gains.
         if (e == hipSuccess) {
-            what = "prover: upload of W, a, b, c";
+            what = "prover: upload of W";
             if (wb) e = hipMemcpyAsync(base, j->W, wb, hipMemcpyHostToDevice, p->copy_stream);
-            if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb, j->a, cb, hipMemcpyHostToDevice, p->copy_stream);
-            if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + cb, j->b, cb, hipMemcpyHostToDevice, p->copy_stream);
-            if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + 2 * cb, j->c, cb, hipMemcpyHostToDevice, p->copy_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(p->copy_stream);   // the job is handed over with its inputs resident
+            if (e == hipSuccess) e = hipEventRecord(set.ev_w, p->copy_stream);
         }
-        j->h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (e != hipSuccess) {
             (void)hipGetLastError();
             std::string msg = std::string(what) + ": " + hipGetErrorString(e);
@@ -148,12 +162,27 @@ static void uploader_main(mi_prover *p) {
             p->cv_work.notify_all();
             continue;
         }
+        const mi_fr *ha = j->a, *hb = j->b, *hc = j->c;
         {
             std::lock_guard<std::mutex> lk(p->m);
             j->W = (const mi_fr *)base; j->a = (const mi_fr *)(base + wb); j->b = (const mi_fr *)(base + wb + cb); j->c = (const mi_fr *)(base + wb + 2 * cb);
+            j->gated = true;
+            set.abc_state = 0;
             p->queue.push_back(j);
+        }
+        p->cv_work.notify_all();
+        if (cb) e = hipMemcpyAsync(base + wb, ha, cb, hipMemcpyHostToDevice, p->copy_stream);
+        if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + cb, hb, cb, hipMemcpyHostToDevice, p->copy_stream);
+        if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + 2 * cb, hc, cb, hipMemcpyHostToDevice, p->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(set.ev_abc, p->copy_stream);
+        if (e != hipSuccess) (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(p->m);
+            j->h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            set.abc_state = e == hipSuccess ? 1 : -1;
             p->uploading = false;
         }
+        p->cv_abc.notify_all();
         p->cv_work.notify_all();
     }
 }
@@ -184,6 +213,15 @@ int32_t mi_prover_create(int device_id, uint32_t in_flight, mi_prover **out) {
         return MI_EHIP;
     }
     p->sets.resize(in_flight + 1);
+    for (InputSet &st : p->sets)
+        if (hipEventCreateWithFlags(&st.ev_w, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&st.ev_abc, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            for (InputSet &q : p->sets) { if (q.ev_w) (void)hipEventDestroy(q.ev_w); if (q.ev_abc) (void)hipEventDestroy(q.ev_abc); }
+            (void)hipStreamDestroy(p->copy_stream);
+            for (mi_ctx *q : p->ctx) mi_shutdown(q);
+            delete p;
+            return MI_EHIP;
+        }
     for (mi_ctx *c : p->ctx) p->workers.emplace_back(worker_main, p, c);
     p->uploader = std::thread(uploader_main, p);
     *out = p;
@@ -203,7 +241,7 @@ int32_t mi_prover_destroy(mi_prover *p) {
     // every job has run by now and nothing references a caller's W/a/b/c/out/stats any more; tickets nobody waited on
     // are dropped here (waiting on a destroyed pool is the caller's bug, like any use after free)
     (void)hipSetDevice(p->dev);
-    for (InputSet &s : p->sets) if (s.p) (void)hipFree(s.p);
+    for (InputSet &s : p->sets) { if (s.p) (void)hipFree(s.p); if (s.ev_w) (void)hipEventDestroy(s.ev_w); if (s.ev_abc) (void)hipEventDestroy(s.ev_abc); }
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     for (mi_ctx *c : p->ctx) mi_shutdown(c);
     for (auto &kv : p->jobs) delete kv.second;
@@ -223,7 +261,7 @@ const char *mi_prover_last_error(mi_prover *p) {
 
 static int32_t submit(mi_prover *p, bool host, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                       size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket) {
-    if (!p || !pk || !r || !s || !out || !ticket || !W || !a || !b || !c) return MI_EINVAL;
+    if (!p || !pk || !r || !s || !out || !ticket || (!W && n_wires) || ((!a || !b || !c) && n_constraints)) return MI_EINVAL;
     Job *j = new (std::nothrow) Job();
     if (!j) return MI_ENOMEM;
     j->host = host; j->pk = pk; j->W = W; j->a = a; j->b = b; j->c = c;

@@ -307,8 +307,13 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
 }  // extern "C"
 
 // ---------------------------------------------------------------- the pieces of a proof (shared with group.hip)
-// step 5 + the wire MSMs: they depend on W only (ev_w = "W is on the device")
-int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
+// step 5 + the wire MSMs: they depend on W only (ev_w = "W is on the device").  Two independent groups, each with ONE sort:
+// B1 + B2 (slots 1, 2) and A + K (slots 0, 3).  Enqueueing a group waits once, on the host, for the count pass of its sort (msm.hip,
+// MI_MSM_EXACT_SIZE), so a proof enqueues the two groups from two helper threads while its own thread enqueues computeH and the Z MSM
+// (prove_common): measured on one proof alone, the A + K sort used to start 10 ms into the proof because the host was still busy
+// enqueueing Z's and B's ~130 launches, and the memory-bound sorts then ran beside the bucket accumulations instead of beside the NTT.
+int32_t mi_prove_enqueue_b_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
+    (void)hipSetDevice(ctx->dev);   // the current device is per host thread
     // wire values are skewed (45 % of them 0 or 1): their sorts are sized by the counted entries, not by windows * n (msm.hip)
     const uint32_t df = (defer ? MI_MSM_DEFER_REDUCE : 0) | MI_MSM_EXACT_SIZE;
     const uint32_t rp = pk->rprime ? MI_MSM_PTS_RPRIME : 0;
@@ -320,11 +325,15 @@ int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEv
     MI_CHECK_HIP(ctx, hipGetLastError());
     if (pk->pre_b1) {
         MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, pk->c_b));
-        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, df | rp, nullptr, false, pk->c_b));
-    } else {
-        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, 0, 0, pk->gen_c_b));
-        MI_TRY(mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, df | rp, nullptr, false));
+        return mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, df | rp, nullptr, false, pk->c_b);
     }
+    MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, 0, 0, pk->gen_c_b));
+    return mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, df | rp, nullptr, false);
+}
+int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
+    (void)hipSetDevice(ctx->dev);
+    const uint32_t df = (defer ? MI_MSM_DEFER_REDUCE : 0) | MI_MSM_EXACT_SIZE;
+    const uint32_t rp = pk->rprime ? MI_MSM_PTS_RPRIME : 0;
     // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
     // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
     if (pk->pre_a) {
@@ -333,6 +342,13 @@ int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEv
     }
     MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, df | rp, ev_w, true, 0, pk->n_a, pk->gen_c_ak));
     return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, df | rp, nullptr, true, 0, pk->n_k);
+}
+// both groups from two helper threads; returns when everything is enqueued
+int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
+    std::future<int32_t> fb = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer); });
+    const int32_t ra = mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, defer);
+    const int32_t rb = fb.get();
+    return ra != MI_OK ? ra : rb;
 }
 // the Z MSM over this key's h coefficients against the bit-reversed pk.G1.Z (ev_h = "h is ready")
 int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h, hipEvent_t ev_h, bool defer) {
@@ -381,10 +397,15 @@ void ProofAssembler::finish(const G1X &msm_k, const G2X &msm_b2, const G1X &msm_
 
 // Host-pointer inputs of mi_groth16_prove (null for the device-pointer entry point).
 struct HostInputs { const mi_fr *W, *a, *b, *c; };
+// Device inputs that are still ARRIVING (the prover pool's upload stage, pool.hip): W is complete once w_ready has fired; abc() blocks
+// the host until the producer has RECORDED the event that marks a, b, c complete and returns it (null: their upload failed) -- an
+// event must be recorded before a stream is told to wait for it.
+struct AbcGate { hipEvent_t w_ready; const std::function<hipEvent_t()> *abc; };
 
 // W, a, b, c: device buffers (for host inputs: staging areas the uploads below fill).
 static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
-                            size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, mi_proof_out *out, mi_stats *stats, const HostInputs *host) {
+                            size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, mi_proof_out *out, mi_stats *stats, const HostInputs *host,
+                            const AbcGate *gate = nullptr) {
     if (!ctx || !pk || !W || !a || !b || !c || !r_m || !s_m || !out) return MI_EINVAL;
     const size_t N = (size_t)1 << pk->log_n;
     if (pk->wire_lo || pk->n_z_msm != N - 1) MI_FAIL(ctx, MI_EINVAL, "prove: this key is one part of a sharded key (use mi_groth16_prove_sharded)");
@@ -403,24 +424,60 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
         return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);
     };
-    if (!host) {
-        // inputs already in HBM: computeH heads the longest chain (h -> Z MSM), so it is enqueued first
-        MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-        MI_TRY(enqueue_h_and_z());
-        MI_TRY(mi_prove_enqueue_wire_msms(ctx, pk, W, ev[2]));
-    } else {
+    // The two wire-MSM groups are enqueued by two helper threads (each waits once for its sort's count pass) while this thread
+    // enqueues computeH and the Z MSM -- or is held by the uploads of a, b, c: all sorts start at the head of the proof, beside the NTT.
+    // Whatever fails, the helpers are joined and every slot is collected before the error is returned (nothing of this proof may stay
+    // queued on the slots).
+    std::future<int32_t> f_b, f_ak;
+    auto start_wires = [&] {
+        f_b = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false); });
+        f_ak = std::async(std::launch::async, [=] { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false); });
+    };
+    auto main_part = [&]() -> int32_t {
+        if (gate) {
+            // inputs on their way into HBM (pool upload stage): the wire MSMs start as soon as W is there; a, b, c (3/4 of the bytes)
+            // finish arriving behind them, and computeH waits for exactly that
+            MI_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, gate->w_ready, 0));
+            MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+            start_wires();
+            hipEvent_t abc = (*gate->abc)();
+            if (!abc) MI_FAIL(ctx, MI_EHIP, "prove: the upload of a, b, c failed");
+            MI_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, abc, 0));
+            MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
+            return enqueue_h_and_z();
+        }
+        if (!host) {
+            // inputs already in HBM
+            MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+            start_wires();
+            return enqueue_h_and_z();
+        }
         // inputs in host memory (the cgo path): upload W, start the wire MSMs, and upload a, b, c WHILE they run; the
         // PCIe time of a, b, c (3/4 of the bytes) disappears behind the MSMs instead of preceding the whole proof
         const size_t wb = n_wires * sizeof(mi_fr), cb = n_constraints * sizeof(mi_fr);
         MI_CHECK_HIP(ctx, hipEventRecord(ev[10], ctx->stream));
         MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)W, host->W, wb, hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-        MI_TRY(mi_prove_enqueue_wire_msms(ctx, pk, W, ev[2]));
+        start_wires();
         MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)a, host->a, cb, hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)b, host->b, cb, hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)c, host->c, cb, hipMemcpyHostToDevice, ctx->stream));
         MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
-        MI_TRY(enqueue_h_and_z());
+        return enqueue_h_and_z();
+    };
+    {
+        int32_t rc = main_part();
+        if (f_b.valid()) { const int32_t r = f_b.get(); if (rc == MI_OK) rc = r; }
+        if (f_ak.valid()) { const int32_t r = f_ak.get(); if (rc == MI_OK) rc = r; }
+        if (rc != MI_OK) {
+            const std::string keep = ctx->err;   // the collection below may overwrite it
+            G1X t1; G2X t2;
+            for (int sl : {0, 1, 3, 4}) (void)mi_msm_finish(ctx, sl, 1, &t1);
+            (void)mi_msm_finish(ctx, 2, 2, &t2);
+            (void)hipStreamSynchronize(ctx->stream);
+            mi_set_err(ctx, keep);
+            return rc;
+        }
     }
     // step 6 while the GPU works: blinding multiples of delta on the host (O(1) points)
     ProofAssembler as;
@@ -448,7 +505,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         return MI_OK;
     };
     // per-phase spans overlap (five streams): they do not add up to total_ms
-    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.compute_h_ms, host ? ev[11] : ev[2], ev[3]));
+    MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.compute_h_ms, (host || gate) ? ev[11] : ev[2], ev[3]));
     if (host) MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.h2d_ms, ev[10], ev[11]));   // span of the uploads (overlaps the wire MSMs)
     if (pk->nb_wires) MI_TRY(slot_ms(0, &st.msm_a_ms));
     if (pk->n_b) { MI_TRY(slot_ms(1, &st.msm_b1_ms)); MI_TRY(slot_ms(2, &st.msm_b2_ms)); }
@@ -459,6 +516,12 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     st.total_ms = ms(t_begin, t_end);
     if (stats) *stats = st;
     return MI_OK;
+}
+
+int32_t mi_groth16_prove_dev_gated(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
+                                   const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, hipEvent_t w_ready, const std::function<hipEvent_t()> &abc_ready) {
+    const AbcGate gate{w_ready, &abc_ready};
+    return prove_common(ctx, pk, W, n_wires, a, b, c, n_constraints, r, s, out, stats, nullptr, &gate);
 }
 
 extern "C" {

@@ -9,12 +9,12 @@ N = 1 << log_n
 ctx = B.Context(0)
 a = ctx.gen_scalars(N - 100, 1, 1); b = ctx.gen_scalars(N - 100, 2, 0); c = ctx.gen_scalars(N - 100, 3, 0)
 h = ctx.alloc(32 * N)
-for on in (1, 0, 1, 0):
+for on in (3, 1, 3, 1, 2, 0):   # bit 0 = contiguous pair, bit 1 = strided triple
     assert ctx.lib.mi_debug_set_ntt_fuse_pair(ctx.h, on) == 0
     ctx.compute_h_dev(log_n, a.ptr, b.ptr, c.ptr, N - 100, h.ptr)
     ms = []
     for _ in range(reps):
         ctx.compute_h_dev(log_n, a.ptr, b.ptr, c.ptr, N - 100, h.ptr)
         ms.append(ctx.stats()["compute_h_ms"])
-    print("fused pair", on, "computeH ms: min %.3f  all %s  launches %d" % (min(ms), " ".join("%.3f" % x for x in ms), ctx.stats()["ntt_launches"]), flush=True)
+    print("fuse mask", on, "computeH ms: min %.3f  all %s  launches %d" % (min(ms), " ".join("%.3f" % x for x in ms), ctx.stats()["ntt_launches"]), flush=True)
 ctx.close()
