@@ -338,6 +338,7 @@ def main():
     ap.add_argument("--msm-group-bits", type=int, default=0, help="tuning: mi_debug_set_msm_group_bits on every context")
     ap.add_argument("--no-limb29", action="store_true", help="tuning: G1 level-1 accumulation in 8 x 32-bit limbs (mi_debug_set_msm_limb29(0)) instead of 9 x 29-bit")
     ap.add_argument("--g1-waves", type=int, default=3, choices=(2, 3), help="tuning: build of the G1 level-1 kernel (mi_debug_set_msm_l1_waves): 3 waves per SIMD (default) or 2")
+    ap.add_argument("--hold-accum", action="store_true", help="tuning: mi_debug_set_prove_schedule(1): the wire MSMs' bucket accumulations wait for computeH (measured: no gain)")
     ap.add_argument("--msm-chunk", type=int, default=0, help="tuning: mi_debug_set_msm_chunk on every context")
     ap.add_argument("--sharded-msm-log-n", type=int, default=26, help="configs[4]: size of the point-sharded G1 MSM run after the proofs (0 = skip)")
     ap.add_argument("--sharded-prove-log-n", type=int, default=26, help="configs[4]: FFT domain of the ONE proof point-sharded over the ranks, run after the proofs (0 = skip)")
@@ -379,6 +380,7 @@ def main():
         assert pool.lib.mi_debug_set_msm_l1_waves(pool.ctx(i).h, args.g1_waves) == 0
         assert pool.lib.mi_debug_set_msm_group_bits(pool.ctx(i).h, args.msm_group_bits) == 0
         assert pool.lib.mi_debug_set_msm_chunk(pool.ctx(i).h, args.msm_chunk) == 0
+        assert pool.lib.mi_debug_set_prove_schedule(pool.ctx(i).h, 1 if args.hold_accum else 0) == 0
     if args.ntt_plan:
         np_ = [int(x) for x in args.ntt_plan.split(",")]
         for i in range(pool.in_flight):
@@ -471,14 +473,16 @@ def main():
 
     # second timed region: the same K proofs with W, a, b, c in HOST memory (mi_prover_submit, what the cgo drop-in passes:
     # Go slices, mt.go:494-496) -- the PCIe-inclusive rate.  Reported next to `value`, never as `value`.
-    host_rate = host_ms = None
+    host_rate = host_ms = host_h2d_ms = None
     if not args.no_host_inputs:
         Wh, ah, bh, ch = W.download((nb_wires, 4)), a.download((n_constraints, 4)), b.download((n_constraints, 4)), c.download((n_constraints, 4))
         for t in [pool.submit(pkh, Wh, ah, bh, ch, rs[0], rs[1]) for _ in range(max(args.warmup, pool.in_flight + 1))]:
             pool.wait(t)
         fence()
         t0h = time.perf_counter()
-        host_proofs = [pool.wait(t)[0]["raw"] for t in [pool.submit(pkh, Wh, ah, bh, ch, rs[0], rs[1]) for _ in range(args.steps)]]
+        host_done = [pool.wait(t) for t in [pool.submit(pkh, Wh, ah, bh, ch, rs[0], rs[1]) for _ in range(args.steps)]]
+        host_proofs = [x[0]["raw"] for x in host_done]
+        host_h2d_ms = sorted(x[1]["h2d_ms"] for x in host_done)
         fence()
         dth = time.perf_counter() - t0h
         if dist is not None:
@@ -590,6 +594,9 @@ def main():
             "single_proof_latency_ms": serial_ms,
             # PCIe-inclusive: the same K steps with W, a, b, c handed over as host pointers (the cgo path); proofs byte-equal
             "value_host_inputs": host_rate, "ms_per_step_host_inputs": host_ms,
+            # the upload stage's wall time per job (W, a, b, c = 1.07 GB at N = 2^23 from pageable host memory): when its median nears
+            # ms_per_step the host-input rate is bound by the PCIe / host-memory side of the box, not by the GPU
+            "host_inputs_upload_ms": None if host_rate is None else {"median": host_h2d_ms[len(host_h2d_ms) // 2], "max": host_h2d_ms[-1]},
             # BASELINE configs[4] (one MSM point-sharded over the ranks, strong scaling); n_gpus = 1: the same code path with one rank
             "sharded_msm": sharded,
             # BASELINE configs[4] as north_star states it: ONE proof point-sharded over the ranks (strong scaling)

@@ -1,6 +1,7 @@
 // Library-internal context shared by the HIP translation units (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -27,6 +28,10 @@ struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, 
     bool deferred = false;      // accumulate stage done up to the bucket sums, reduce not yet enqueued (MI_MSM_DEFER_REDUCE)
     uint32_t tail_seg = 0;      // buckets per bucket-reduce thread
     const uint32_t *entries_src = nullptr;   // device word holding the number of sorted entries (stats)
+    // Set by the caller before mi_msm_enqueue, consumed by it: called on the enqueueing thread right before the bucket accumulation is
+    // enqueued (after the sort); blocks until the event it returns HAS BEEN RECORDED and the slot's stream then waits for that event
+    // (null result = no wait).  prove.hip holds the wire MSMs' accumulations back until computeH is done this way.
+    const std::function<hipEvent_t()> *accum_gate = nullptr;
 };
 
 struct mi_ctx {
@@ -45,6 +50,7 @@ struct mi_ctx {
     int cu_count = 256;
     int prio_scheme = 0;      // MI_PRIO_*: how the context's streams rank (api.hip, msm.hip)
     uint32_t fixed_knob[3] = {0, 0, 0};  // prove's fixed-base tables for A+K / B / Z: 0 = automatic, 1 = never, 17..22 = forced (prove.hip)
+    uint32_t hold_accum = 0;             // prove: 1 = the wire MSMs' bucket accumulations wait for computeH (mi_debug_set_prove_schedule; measured: no gain)
 };
 
 // Fault injection for the error-path tests (mi_debug_inject_hip_failure, api.hip): the n-th MI_CHECK_HIP from now reports

@@ -531,6 +531,11 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * ops.xyzz_bytes, st));
     hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, S, L1, A.start, A.cnt, A.items);
     MI_CHECK_HIP(ctx, hipGetLastError());
+    if (acc.accum_gate) {   // the caller's condition for the heavy part (prove.hip: computeH first)
+        const hipEvent_t g = (*acc.accum_gate)();
+        acc.accum_gate = nullptr;
+        if (g) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, g, 0));
+    }
     // largest possible bucket: one entry per scalar and window of the key space it collects
     const u64 max_count = (u64)(srt.nwin_digits / srt.nwin_keys) * n;
     MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed, rprime));
@@ -619,6 +624,8 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     if (slot < 0 || slot >= MI_MSM_SLOTS || sort_slot >= MI_MSM_SLOTS) return MI_EINVAL;
     if (n > ((size_t)1 << 27)) MI_FAIL(ctx, MI_EINVAL, "msm: n > 2^27 pairs per device not supported (shard the points)");
     MsmSlot &sl = ctx->msm[slot];
+    const std::function<hipEvent_t()> *gate_once = sl.accum_gate;   // valid for this call only, whatever path it takes
+    sl.accum_gate = nullptr;
     sl.active = false;
     sl.deferred = false;
     sl.stat_pairs = stat_pairs ? stat_pairs : n;
@@ -631,6 +638,7 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     if (sort_slot < 0 && precomp_c) MI_TRY(msm2_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, precomp_c, false, exact));
     else if (sort_slot < 0) MI_TRY(msm_sort_enqueue(ctx, sl, (const Fr *)scalars_dev, (u32)n, flags, generic_c, exact));
     else if (srt.n != n) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
+    sl.accum_gate = gate_once;
     return msm_accum_enqueue(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), srt, sl, pts_dev, timed, defer, rprime);
 }
 bool mi_msm_limb29_enabled(mi_ctx *ctx) { return !knobs_of(ctx)->no_rprime; }
@@ -768,6 +776,11 @@ int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2,
     if (!ctx || c == 1 || c > 16 || G > 1024 || L1 == 1 || L2 == 1) return MI_EINVAL;   // items of one entry would never shrink a level
     MsmKnobs *k = knobs_of(ctx);
     k->c = c; k->L1 = L1; k->L2 = L2; k->seg = seg; k->G = G;
+    return MI_OK;
+}
+int32_t mi_debug_set_prove_schedule(mi_ctx *ctx, uint32_t hold_accum) {
+    if (!ctx || hold_accum > 1) return MI_EINVAL;
+    ctx->hold_accum = hold_accum;
     return MI_OK;
 }
 int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, uint32_t c_z) {

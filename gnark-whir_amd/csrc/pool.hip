@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include "prove_internal.h"
 #include <chrono>
+#include <cstdlib>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -66,6 +67,7 @@ struct mi_prover {
     std::unordered_map<uint64_t, Job *> jobs;   // submitted, not yet collected by mi_prover_wait
     uint64_t next_id = 1;
     bool stop = false, uploading = false;
+    bool early_handover = true;   // a host job goes to a worker once W has arrived (MI_POOL_EARLY_HANDOVER=0: only when W, a, b, c all have)
     std::string err;
 };
 
@@ -101,7 +103,12 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
                 p->cv_abc.wait(lk, [&] { return set.abc_state != 0; });
                 return set.abc_state > 0 ? set.ev_abc : nullptr;
             };
-            rc = mi_groth16_prove_dev_gated(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats, set.ev_w, abc);
+            bool arrived;
+            {
+                std::lock_guard<std::mutex> lk(p->m);
+                arrived = set.abc_state == 1;   // the steady state: the uploader is a job ahead
+            }
+            rc = mi_groth16_prove_dev_gated(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats, set.ev_w, abc, arrived);
         } else {
             rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
         }
@@ -163,25 +170,33 @@ static void uploader_main(mi_prover *p) {
             continue;
         }
         const mi_fr *ha = j->a, *hb = j->b, *hc = j->c;
+        auto hand_over = [&] {
+            {
+                std::lock_guard<std::mutex> lk(p->m);
+                j->W = (const mi_fr *)base; j->a = (const mi_fr *)(base + wb); j->b = (const mi_fr *)(base + wb + cb); j->c = (const mi_fr *)(base + wb + 2 * cb);
+                j->gated = true;
+                p->queue.push_back(j);
+            }
+            p->cv_work.notify_all();
+        };
         {
             std::lock_guard<std::mutex> lk(p->m);
-            j->W = (const mi_fr *)base; j->a = (const mi_fr *)(base + wb); j->b = (const mi_fr *)(base + wb + cb); j->c = (const mi_fr *)(base + wb + 2 * cb);
-            j->gated = true;
             set.abc_state = 0;
-            p->queue.push_back(j);
         }
-        p->cv_work.notify_all();
+        if (p->early_handover) hand_over();
         if (cb) e = hipMemcpyAsync(base + wb, ha, cb, hipMemcpyHostToDevice, p->copy_stream);
         if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + cb, hb, cb, hipMemcpyHostToDevice, p->copy_stream);
         if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + 2 * cb, hc, cb, hipMemcpyHostToDevice, p->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(set.ev_abc, p->copy_stream);
         if (e != hipSuccess) (void)hipGetLastError();
+        if (!p->early_handover && e == hipSuccess) e = hipStreamSynchronize(p->copy_stream);
         {
             std::lock_guard<std::mutex> lk(p->m);
             j->h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
             set.abc_state = e == hipSuccess ? 1 : -1;
             p->uploading = false;
         }
+        if (!p->early_handover) hand_over();   // (a failed upload is reported by the worker through the gate, like the early form)
         p->cv_abc.notify_all();
         p->cv_work.notify_all();
     }
@@ -213,6 +228,7 @@ int32_t mi_prover_create(int device_id, uint32_t in_flight, mi_prover **out) {
         return MI_EHIP;
     }
     p->sets.resize(in_flight + 1);
+    if (const char *e = getenv("MI_POOL_EARLY_HANDOVER")) p->early_handover = atoi(e) != 0;
     for (InputSet &st : p->sets)
         if (hipEventCreateWithFlags(&st.ev_w, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&st.ev_abc, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();

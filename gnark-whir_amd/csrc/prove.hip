@@ -10,6 +10,7 @@
 #include <cstring>
 #include <vector>
 #include <chrono>
+#include <cstdlib>
 
 __global__ void k_expand_points(G1Aff *full, const G1Aff *compact, const u32 *idx, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,8 +313,9 @@ int32_t mi_pk_free(mi_ctx *ctx, mi_pk *pk) {
 // MI_MSM_EXACT_SIZE), so a proof enqueues the two groups from two helper threads while its own thread enqueues computeH and the Z MSM
 // (prove_common): measured on one proof alone, the A + K sort used to start 10 ms into the proof because the host was still busy
 // enqueueing Z's and B's ~130 launches, and the memory-bound sorts then ran beside the bucket accumulations instead of beside the NTT.
-int32_t mi_prove_enqueue_b_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
+int32_t mi_prove_enqueue_b_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer, const std::function<hipEvent_t()> *accum_gate) {
     (void)hipSetDevice(ctx->dev);   // the current device is per host thread
+    struct Gates { mi_ctx *c; const std::function<hipEvent_t()> *g; void arm(int slot) const { c->msm[slot].accum_gate = g; } } gates{ctx, accum_gate};
     // wire values are skewed (45 % of them 0 or 1): their sorts are sized by the counted entries, not by windows * n (msm.hip)
     const uint32_t df = (defer ? MI_MSM_DEFER_REDUCE : 0) | MI_MSM_EXACT_SIZE;
     const uint32_t rp = pk->rprime ? MI_MSM_PTS_RPRIME : 0;
@@ -324,29 +326,38 @@ int32_t mi_prove_enqueue_b_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent
     if (pk->n_b) hipLaunchKernelGGL(k_gather_fr, dim3((unsigned)((pk->n_b + 255) / 256)), dim3(256), 0, st, (Fr *)ctx->ws[17].p, (const Fr *)W, pk->idx_b, pk->n_b);
     MI_CHECK_HIP(ctx, hipGetLastError());
     if (pk->pre_b1) {
+        gates.arm(1);
         MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, pk->c_b));
+        gates.arm(2);
         return mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, df | rp, nullptr, false, pk->c_b);
     }
+    gates.arm(1);
     MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, 0, 0, pk->gen_c_b));
+    gates.arm(2);
     return mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, df | rp, nullptr, false);
 }
-int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
+int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer, const std::function<hipEvent_t()> *accum_gate) {
     (void)hipSetDevice(ctx->dev);
+    struct Gates { mi_ctx *c; const std::function<hipEvent_t()> *g; void arm(int slot) const { c->msm[slot].accum_gate = g; } } gates{ctx, accum_gate};
     const uint32_t df = (defer ? MI_MSM_DEFER_REDUCE : 0) | MI_MSM_EXACT_SIZE;
     const uint32_t rp = pk->rprime ? MI_MSM_PTS_RPRIME : 0;
     // A and K are both multiplied by W itself: one sort of all wires (slot 0) serves both, against the per-wire expanded
     // point arrays (a wire without a point reads (0,0) = infinity and is skipped); no gather, one sort less
     if (pk->pre_a) {
+        gates.arm(0);
         MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->pre_a, W, pk->nb_wires, df | rp, ev_w, true, pk->c_ak, pk->n_a));
+        gates.arm(3);
         return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, df | rp, nullptr, true, pk->c_ak, pk->n_k);
     }
+    gates.arm(0);
     MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, df | rp, ev_w, true, 0, pk->n_a, pk->gen_c_ak));
+    gates.arm(3);
     return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, df | rp, nullptr, true, 0, pk->n_k);
 }
 // both groups from two helper threads; returns when everything is enqueued
 int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
-    std::future<int32_t> fb = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer); });
-    const int32_t ra = mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, defer);
+    std::future<int32_t> fb = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer, nullptr); });
+    const int32_t ra = mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, defer, nullptr);
     const int32_t rb = fb.get();
     return ra != MI_OK ? ra : rb;
 }
@@ -400,7 +411,7 @@ struct HostInputs { const mi_fr *W, *a, *b, *c; };
 // Device inputs that are still ARRIVING (the prover pool's upload stage, pool.hip): W is complete once w_ready has fired; abc() blocks
 // the host until the producer has RECORDED the event that marks a, b, c complete and returns it (null: their upload failed) -- an
 // event must be recorded before a stream is told to wait for it.
-struct AbcGate { hipEvent_t w_ready; const std::function<hipEvent_t()> *abc; };
+struct AbcGate { hipEvent_t w_ready; const std::function<hipEvent_t()> *abc; bool abc_arrived; /* a, b, c were complete already when the job was picked up */ };
 
 // W, a, b, c: device buffers (for host inputs: staging areas the uploads below fill).
 static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
@@ -419,19 +430,40 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     MI_TRY(mi_reserve(ctx, ctx->ws[14], N * sizeof(Fr)));
     Fr *h = (Fr *)ctx->ws[14].p;
     // step 4: h = computeH(a, b, c)  (bit-reversed, like gnark leaves it), then the Z MSM over h[:N-1] against the bit-reversed pk.G1.Z
+    // "computeH is enqueued and its end event recorded": what the wire MSMs' accumulations wait for (hold, below).  Always fulfilled
+    // before the helper threads are joined -- with a null event on a failure path, which releases them without a wait.
+    std::promise<hipEvent_t> h_recorded;
+    bool h_promised = false;
+    const std::shared_future<hipEvent_t> h_fut = h_recorded.get_future().share();
+    const std::function<hipEvent_t()> h_gate = [h_fut] { return h_fut.get(); };
     auto enqueue_h_and_z = [&]() -> int32_t {
         MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, c, n_constraints, (mi_fr *)h));
         MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+        h_recorded.set_value(ev[3]); h_promised = true;
         return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);
     };
     // The two wire-MSM groups are enqueued by two helper threads (each waits once for its sort's count pass) while this thread
     // enqueues computeH and the Z MSM -- or is held by the uploads of a, b, c: all sorts start at the head of the proof, beside the NTT.
     // Whatever fails, the helpers are joined and every slot is collected before the error is returned (nothing of this proof may stay
     // queued on the slots).
+    // hold: the wire MSMs SORT at once (memory-bound, beside the NTT) but their bucket accumulations wait for computeH.  Measured on
+    // one proof alone: let loose, the accumulations' resident waves starved the NTT passes (stream priorities order dispatch, they do
+    // not preempt), computeH ended at 18 instead of 9 ms, the Z MSM's sort -- which needs h -- could no longer hide beside the other
+    // accumulations and the GPU idled for 3 ms before the Z accumulation.  Not for host inputs whose a, b, c are still on the PCIe
+    // bus: there the accumulations are what fills the GPU meanwhile.
+    const bool hold = ctx->hold_accum && !host && (!gate || gate->abc_arrived);
     std::future<int32_t> f_b, f_ak;
+    static const bool helper_threads = !(getenv("MI_PROVE_HELPER_THREADS") && atoi(getenv("MI_PROVE_HELPER_THREADS")) == 0);   // A/B switch
+    int32_t rc_inline = MI_OK;
     auto start_wires = [&] {
-        f_b = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false); });
-        f_ak = std::async(std::launch::async, [=] { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false); });
+        const std::function<hipEvent_t()> *g = hold ? &h_gate : nullptr;
+        if (!helper_threads) {   // the round-2 form: both groups enqueued by this thread, one after the other (no hold: it would wait for itself)
+            rc_inline = mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, nullptr);
+            if (rc_inline == MI_OK) rc_inline = mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, nullptr);
+            return;
+        }
+        f_b = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, g); });
+        f_ak = std::async(std::launch::async, [=] { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, g); });
     };
     auto main_part = [&]() -> int32_t {
         if (gate) {
@@ -467,6 +499,8 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     };
     {
         int32_t rc = main_part();
+        if (rc == MI_OK) rc = rc_inline;
+        if (!h_promised) h_recorded.set_value(nullptr);   // a failure before computeH's event: release the helpers
         if (f_b.valid()) { const int32_t r = f_b.get(); if (rc == MI_OK) rc = r; }
         if (f_ak.valid()) { const int32_t r = f_ak.get(); if (rc == MI_OK) rc = r; }
         if (rc != MI_OK) {
@@ -519,8 +553,9 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
 }
 
 int32_t mi_groth16_prove_dev_gated(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
-                                   const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, hipEvent_t w_ready, const std::function<hipEvent_t()> &abc_ready) {
-    const AbcGate gate{w_ready, &abc_ready};
+                                   const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, hipEvent_t w_ready, const std::function<hipEvent_t()> &abc_ready,
+                                   bool abc_arrived) {
+    const AbcGate gate{w_ready, &abc_ready, abc_arrived};
     return prove_common(ctx, pk, W, n_wires, a, b, c, n_constraints, r, s, out, stats, nullptr, &gate);
 }
 

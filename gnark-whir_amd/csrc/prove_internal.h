@@ -49,8 +49,10 @@ extern "C" int32_t mi_pedersen_pk_adopt(mi_ctx *ctx, void *basis_dev, void *basi
 int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hipEvent_t ev_w, bool defer_reduce = false);
 // its two halves, each with one sort and one host-side wait for that sort's count pass: B1 + B2 (slots 1, 2), A + K (slots 0, 3).
 // Independent of each other (own slots, own buffers): safe to call from two threads at once.
-int32_t mi_prove_enqueue_b_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hipEvent_t ev_w, bool defer_reduce = false);
-int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hipEvent_t ev_w, bool defer_reduce = false);
+// accum_gate (may be null): MsmSlot::accum_gate for the group's two slots -- the sorts are enqueued at once, the bucket accumulations
+// behind the event it returns.
+int32_t mi_prove_enqueue_b_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hipEvent_t ev_w, bool defer_reduce = false, const std::function<hipEvent_t()> *accum_gate = nullptr);
+int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hipEvent_t ev_w, bool defer_reduce = false, const std::function<hipEvent_t()> *accum_gate = nullptr);
 int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h_dev, hipEvent_t ev_h, bool defer_reduce = false);
 
 // mi_groth16_prove_dev over inputs that are still arriving in HBM (the prover pool's upload stage): the wire MSMs are ordered after
@@ -58,7 +60,7 @@ int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h_dev, hipEv
 // failed); computeH is ordered after it.  Same proof bytes.
 int32_t mi_groth16_prove_dev_gated(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, size_t n_wires, const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev,
                                    size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, hipEvent_t w_ready,
-                                   const std::function<hipEvent_t()> &abc_ready);
+                                   const std::function<hipEvent_t()> &abc_ready, bool abc_arrived);
 
 // Blinding and assembly of Ar, Bs, Krs from the five MSM sums, exactly as gnark's prove.go composes them (row a9); host
 // code over O(1) points.  start() launches the multiples of delta on host threads while the GPU works; have_a_b1() needs

@@ -384,6 +384,10 @@ int32_t mi_debug_set_msm_group_bits(mi_ctx *ctx, uint32_t gbits);   /* fixed-bas
  * 0 = automatic (tables when the MSM has >= 2^20 points and they fit in a third of the free device memory),
  * 1 = never, 17..22 = that width whatever the size */
 int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, uint32_t c_z);
+/* hold_accum = 1: inside a prove whose inputs are in HBM the wire MSMs (A, B1, B2, K) sort at once but start their bucket
+ * accumulations only when computeH is done; 0 (default): everything as soon as its inputs exist.  Same proofs.  Measured neutral on
+ * throughput and 0.4 ms worse on the single-proof latency (a proof alone is work-bound, not schedule-bound: DESIGN.md 7b). */
+int32_t mi_debug_set_prove_schedule(mi_ctx *ctx, uint32_t hold_accum);
 /* 1: generic MSMs of >= 2^18 pairs keep the one-pass counting sort instead of the LDS-staged two-pass one (parity tests run both) */
 int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on);
 /* on = 1 (default): the G1 level-1 bucket accumulation runs in nine 29-bit limbs (keys loaded afterwards keep their G1 points in

@@ -3,7 +3,7 @@
 rounds=$1; shift
 for r in $(seq 1 $rounds); do
   for setting in "" "$@"; do
-    env $setting timeout -k 10 200 python bench.py --no-cpu-baseline --no-host-inputs --sharded-msm-log-n 0 --steps 20 > gpurun_out/abe.log 2>&1 || exit 1
+    env $setting timeout -k 10 200 python bench.py --no-cpu-baseline --no-host-inputs --sharded-msm-log-n 0 --sharded-prove-log-n 0 --steps 20 > gpurun_out/abe.log 2>&1 || exit 1
     python - <<PY
 import json
 l = json.loads(open("gpurun_out/abe.log").read().strip().splitlines()[-1])

@@ -4,7 +4,7 @@ rounds=$1; flag=$2; shift 2
 for r in $(seq 1 $rounds); do
   for v in A B; do
     extra=""; [ $v = B ] && extra=$flag
-    timeout -k 10 200 python bench.py --no-cpu-baseline --no-host-inputs --sharded-msm-log-n 0 --steps 20 $extra "$@" > gpurun_out/abf_$v$r.log 2>&1 || exit 1
+    timeout -k 10 200 python bench.py --no-cpu-baseline --no-host-inputs --sharded-msm-log-n 0 --sharded-prove-log-n 0 --steps 20 $extra "$@" > gpurun_out/abf_$v$r.log 2>&1 || exit 1
     python - <<PY
 import json
 l = json.loads(open("gpurun_out/abf_$v$r.log").read().strip().splitlines()[-1])
