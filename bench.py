@@ -416,6 +416,16 @@ def main():
     t_load = time.perf_counter()
     pkh = ctx.pk_load(pk, device_points=True)   # includes building the fixed-base window tables (once per key)
     t_load = time.perf_counter() - t_load
+    # The key took its own copies of every base it gathers from (per-wire expanded A / K, window tables, R'-form copies): the generated
+    # source arrays of A, B, K, G2.B are dead weight from here on (16 GB at N = 2^26).  They leave the device -- to the host first when
+    # the CPU baseline will want them; pk.G1.Z stays for the solo-MSM leg.  (With --no-limb29 the key references B / G2.B / Z in place.)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    key_host = {}
+    if not args.no_limb29:
+        for name, d, cnt, k in (("g1_a", g1a, na, 8), ("g1_b", g1b, nb, 8), ("g1_k", g1k, nk, 8), ("g2_b", g2b, nb, 16)):
+            if want_cpu:
+                key_host[name] = d.download((cnt, k))
+            d.free()
     W = ctx.gen_scalars(nb_wires, seed + 8, dist_id)
     a = ctx.gen_scalars(n_constraints, seed + 9, dist_id); b = ctx.gen_scalars(n_constraints, seed + 10, 0)
     c = ctx.alloc(32 * n_constraints)
@@ -494,6 +504,21 @@ def main():
                 raise SystemExit("bench.py: a host-input proof differs from the device-input proof of the same inputs")
         host_rate, host_ms = args.steps * world / dth, dth / args.steps * 1e3
 
+    # HBM ledger of the PROVE path, taken right after the timed regions: key + tables, every context's workspaces, the pool's input sets,
+    # bench.py's own inputs -- before the solo-MSM / solo-computeH / probe legs below grow the (grow-only) workspaces of context 0 for
+    # their own shapes (a generic 2^26-pair MSM alone adds ~22 GB at N = 2^26)
+    hbm_in_use_gb = (lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info())
+    hbm_ledger = None
+    if rank == 0:
+        hbm_ledger = ctx.mem_ledger(pkh)   # the key + context 0; the other contexts of the pool add their own workspaces
+        for i in range(1, pool.in_flight):
+            for k, v in pool.ctx(i).mem_ledger().items():
+                if k.startswith("ctx_"):
+                    hbm_ledger[k] += v
+        hbm_ledger["pool_contexts"] = pool.in_flight
+        hbm_ledger["pool_input_sets_gb"] = (pool.in_flight + 1) * (nb_wires + 3 * n_constraints) * 32 / 1e9 if not args.no_host_inputs else 0.0
+        hbm_ledger["bench_inputs_gb"] = (nb_wires + 3 * n_constraints) * 32 / 1e9
+        hbm_ledger["bench_key_source_arrays_gb"] = (N * 64 if not args.no_limb29 else (na + nb + nk + N) * 64 + nb * 128) / 1e9   # what bench.py itself still holds of the generated bases
     # the same kernel measured alone (no other stream competing for the CUs): one uniform-scalar G1 MSM over pk.G1.Z
     solo = None
     if rank == 0:
@@ -521,25 +546,13 @@ def main():
         gtab = ctx.alloc(64 << 27)
         gather_ms = min(ctx.bench_gather(gtab.ptr, 1 << 27, 256 * 4 * 64 * 4, 128) for _ in range(3))
         gtab.free()
-    # HBM ledger while everything of the proofs/s run is still resident (key + tables, every context's workspaces, inputs)
-    hbm_in_use_gb = (lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info())
-    hbm_ledger = None
-    if rank == 0:
-        hbm_ledger = ctx.mem_ledger(pkh)   # the key + context 0; the other contexts of the pool add their own workspaces
-        for i in range(1, pool.in_flight):
-            for k, v in pool.ctx(i).mem_ledger().items():
-                if k.startswith("ctx_"):
-                    hbm_ledger[k] += v
-        hbm_ledger["pool_contexts"] = pool.in_flight
-        hbm_ledger["pool_input_sets_gb"] = (pool.in_flight + 1) * (nb_wires + 3 * n_constraints) * 32 / 1e9 if not args.no_host_inputs else 0.0
-        hbm_ledger["bench_inputs_gb"] = (nb_wires + 3 * n_constraints) * 32 / 1e9
-        hbm_ledger["bench_key_source_arrays_gb"] = ((na + nb + nk + N) * 64 + nb * 128) / 1e9   # the caller's bases (mi_pk_load_dev adopts by reference)
     # inputs of the CPU baseline leave the device before it is emptied for the sharded legs
     cpu_inputs = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if want_cpu:
         dl = lambda d, n, k: d.download((n, k))
-        pk_host = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": dl(g1a, na, 8), "g1_b": dl(g1b, nb, 8),
-                   "g1_k": dl(g1k, nk, 8), "g1_z": dl(g1z, N, 8), "g2_b": dl(g2b, nb, 16), "alpha1": small[0], "beta1": small[1],
+        kh = lambda name, d, n, k: key_host[name] if name in key_host else dl(d, n, k)
+        pk_host = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": kh("g1_a", g1a, na, 8), "g1_b": kh("g1_b", g1b, nb, 8),
+                   "g1_k": kh("g1_k", g1k, nk, 8), "g1_z": dl(g1z, N, 8), "g2_b": kh("g2_b", g2b, nb, 16), "alpha1": small[0], "beta1": small[1],
                    "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b}
         cpu_inputs = (pk_host, dl(W, nb_wires, 4), dl(a, n_constraints, 4), dl(b, n_constraints, 4), dl(c, n_constraints, 4))
     # configs[4]: this process gives its GPU memory back first (an N = 2^26 proof wants most of a GPU), then the helper runs the
@@ -547,7 +560,7 @@ def main():
     in_flight = pool.in_flight
     ctx.pk_free(pkh)
     for d in (g1a, g1b, g1k, g1z, g2b, W, a, b, c):
-        d.free()
+        d.free()   # (DevArray.free is idempotent)
     pool.close()
     sharded, sharded_prove = {"done": False}, {"done": False}
     if helper is not None:
@@ -573,11 +586,13 @@ def main():
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
                 kname = "k_msm_accum_affine29"
                 traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
-                # per pass launch (the fused contiguous pair counted with its own figures, two launches per computeH); one transform =
-                # a sixth of computeH's launches
+                # per pass launch (the fused contiguous pair -- two launches per computeH -- and the fused strided triple -- one -- counted with
+                # their own figures); one transform = a sixth of computeH's traffic
                 per = lambda kn: (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0
                 n_pair = 2 if "k_ntt_contig_pair" in pmc["FETCH_SIZE"] else 0
-                traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0)) / 6.0
+                n_triple = 1 if "k_ntt_strided_triple" in pmc["FETCH_SIZE"] else 0
+                traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair - n_triple) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0) +
+                               (per("k_ntt_strided_triple") if n_triple else 0.0)) / 6.0
             except Exception:
                 traffic = traffic_ntt = None
         line = {
@@ -614,7 +629,7 @@ def main():
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
             # time = computeH alone on the GPU / its 6 transforms (gnark's 7th, the coset FFT of c, is never needed: DESIGN.md 4)
-            "roofline_ntt": {"kernel": "k_ntt_pass_wave (all passes of one size-N transform)", "bound": "hbm",
+            "roofline_ntt": {"kernel": "k_ntt_pass_wave + k_ntt_contig_pair + k_ntt_strided_triple (all passes of one size-N transform)", "bound": "hbm",
                              "achieved": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9 / 8000.0, "traffic": traffic_ntt,
                              "traffic_source": pmc_src + ": (2 x FETCH_SIZE + WRITE_SIZE) per pass launch x pass launches per transform",
