@@ -465,7 +465,11 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
     if (!spk) return MI_ENOMEM;
     spk->part.assign(nl, nullptr); spk->log_n = d->log_n; spk->nb_wires = d->nb_wires;
     // window widths of the generic path that all parts share (mode 1 needs equal bucket layouts): from the LARGEST part of each MSM
+    // ... and whether EVERY rank holds at least one pair of every MSM: mode 1 exchanges bucket slices rank to rank and a rank without
+    // buckets would leave its peers waiting in the collective -- decided here from the masks every process holds, so that every
+    // process refuses mode 1 alike (spk->uniform) instead of one rank failing while the others hang
     u64 max_w = 0, max_b = 0, max_z = 0;
+    bool all_nonempty = true;
     for (int r = 0; r < W; r++) {
         u64 lo, hi, zlo, zhi, nb = 0;
         range_of(d->nb_wires, W, r, lo, hi); range_of(N - 1, W, r, zlo, zhi);
@@ -473,6 +477,7 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
         if (hi - lo > max_w) max_w = hi - lo;
         if (nb > max_b) max_b = nb;
         if (zhi - zlo > max_z) max_z = zhi - zlo;
+        if (hi == lo || nb == 0 || zhi == zlo) all_nonempty = false;
     }
     // ONE fixed-base plan for all parts (mode 1 exchanges buckets, so the parts must cut their scalars alike; and a part just
     // under the 2^20-point threshold next to one just over it would otherwise pick different paths): the rule of mi_pk_load
@@ -533,7 +538,7 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
     if (first_bad != MI_OK) return fail(first_bad);
     if (rc != MI_OK) return fail(rc);
     if (smin == 0) { g->err = "pk: another rank of the group failed to load its part"; return fail(MI_EHIP); }
-    spk->uniform = smin == smax;
+    spk->uniform = smin == smax && all_nonempty;
     *out = spk;
     return MI_OK;
 }
@@ -552,7 +557,7 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
     if (lead_here && (!a || !b || !c)) return MI_EINVAL;
     const size_t N = (size_t)1 << spk->log_n;
     if (n_wires != spk->nb_wires || n_constraints > N) G_FAIL(g, MI_EINVAL, "prove: witness size does not match the proving key");
-    if (mode == 1 && !spk->uniform) G_FAIL(g, MI_EINVAL, "group: mode 1 needs every part to use the same MSM plan (table widths differ between devices)");
+    if (mode == 1 && !spk->uniform) G_FAIL(g, MI_EINVAL, "group: mode 1 needs every part to use the same MSM plan and every rank to hold pairs of every MSM");
     const auto t_begin = std::chrono::steady_clock::now();
     const size_t cb = n_constraints * sizeof(mi_fr);
     // workspaces first, each on its own device: W slice (+ a, b, c on the lead) for host inputs; h (whole on the lead, a slice elsewhere)
