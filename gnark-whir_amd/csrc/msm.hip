@@ -374,10 +374,14 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         }
         if (grid > grid_cap) grid = grid_cap;
         if (grid == 0) grid = 1;
-        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
-        if (level == 0 && pts && rprime && ops.accum_affine_rp) {
+        // the timed span (mi_stats.g1_accum_kernel_ms) brackets the accumulate kernel alone: on the 29-bit path the launcher records the
+        // opening event AFTER its item-table kernel (0.1 ms alone, up to 0.5 ms waiting for CUs with three proofs in flight)
+        const bool rp_path = level == 0 && pts && rprime && ops.accum_affine_rp;
+        if (time_first && level == 0 && !rp_path) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
+        if (rp_path) {
             MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
-            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p, (rp_partials ? 1u : 0u) | (knobs_of(ctx)->l1_waves == 2 ? 2u : 0u));
+            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p,
+                                (rp_partials ? 1u : 0u) | (knobs_of(ctx)->l1_waves == 2 ? 2u : 0u), time_first ? sl.ev[1] : nullptr);
         } else if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else if (rp_partials) ops.accum_xyzz_rp(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);

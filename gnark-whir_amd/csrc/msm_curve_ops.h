@@ -28,7 +28,8 @@ struct MsmCurveOps {
     // same arguments and results as accum_affine.  Null where no such kernel exists (G2).
     void (*accum_affine_rp)(hipStream_t st, unsigned grid, const void *pts_rp, const uint32_t *sorted, const uint32_t *start, const uint32_t *cnt,
                             const uint32_t *items, const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out,
-                            void *item_table /* 16 B per item of scratch */, uint32_t rp_partials /* bit 0; bit 1: the G1 kernel's two-wave build */);
+                            void *item_table /* 16 B per item of scratch */, uint32_t rp_partials /* bit 0; bit 1: the G1 kernel's two-wave build */,
+                            hipEvent_t ev_before /* recorded on st between the item-table kernel and the accumulate kernel when non-null (stats) */);
     // Levels >= 2 over partial sums the level before left in the packed R' form (accum_affine_rp with rp_partials = 1, or this
     // kernel): same arguments as accum_xyzz; bucket sums leave in the standard form, partial sums in the R' form.  Null = the
     // curve keeps its partial sums in the standard form (G2), and rp_partials must be 0.

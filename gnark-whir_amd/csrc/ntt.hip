@@ -53,6 +53,7 @@ __global__ void k_ntt_pass(Fr *dst, const Fr *src, NttPass p, NttTables t);
 __global__ void k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t);
 __global__ void k_ntt_contig_pair(Fr *data, NttPass pi, NttTables ti, NttPass pf, NttTables tf);
 __global__ void k_ntt_strided_triple(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl);
+__global__ void k_ntt_strided_triple8(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl);
 void mi_ntt_state_init(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= sizeof(ctx->ntt_state), "NttState lives in ctx->ntt_state");
     new (ctx->ntt_state) NttState();
@@ -61,6 +62,7 @@ void mi_ntt_state_init(mi_ctx *ctx) {
     (void)hipFuncSetAttribute((const void *)k_ntt_pass_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_contig_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
@@ -223,6 +225,68 @@ __global__ void __launch_bounds__(512) k_ntt_strided_triple(Fr *a, const Fr *b, 
     __syncthreads();                               // every wave has read b's tile
     lds_put(lds, PL, ntt_lds_slot(pl, base + 2 * lane, col), x0);
     lds_put(lds, PL, ntt_lds_slot(pl, base + 2 * lane + 1, col), x1);
+    __syncthreads();
+    ntt_tile_store(pl, tl, a, tile, threadIdx.x, blockDim.x, lds);
+}
+// The same seam for a first radix of 2^8 (the plans of N = 2^24 and 2^26): the DIT pass ends, and the DIF pass begins, with the stage at
+// distance 128 -- on the SAME pairs (r, r + 128).  Each 128-row half of a column goes through the register stages of one wave and back
+// to LDS; a thread then takes its pairs, does the DIT butterfly and keeps the two results in registers (for a), does the same for b,
+// multiplies, does the DIF butterfly on the products and writes them to LDS for the DIF register stages.  256 threads per 256-row x
+// 2^log_c-column tile: 2^log_c butterflies per thread at distance 128 (2^(log_c + 1) elements of a held in registers: log_c <= 2).
+__global__ void __launch_bounds__(256) k_ntt_strided_triple8(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl) {
+    extern __shared__ U4 lds[];
+    const u64 tile = blockIdx.x;
+    const u32 PL = ntt_plane_slots(pc);
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const u32 C = 1u << pc.log_c, nsub = 2u << pc.log_c;   // 128-row sub-blocks of the tile
+    const u32 nb = C >> 1;                                  // butterflies at distance 128 per thread: 128 * C over 256 threads
+    Fr keep[4];                                             // a's results of this thread's pairs (nb <= 2 pairs)
+    auto reg_stages = [&](const NttPass &p, bool dit, const Fr *small) {
+        for (u32 sbk = wave; sbk < nsub; sbk += nwaves) {
+            const u32 col = sbk & (C - 1), base = (sbk >> p.log_c) << 7;
+            u32 ra, rb, wa, wb;
+            if (!dit) { ra = base + lane; rb = ra + 64; wa = base + 2 * lane; wb = wa + 1; }
+            else { ra = base + 2 * lane; rb = ra + 1; wa = base + lane; wb = wa + 64; }
+            Fr x0 = lds_get(lds, PL, ntt_lds_slot(p, ra, col)), x1 = lds_get(lds, PL, ntt_lds_slot(p, rb, col));
+            wave_ntt128(x0, x1, lane, dit, small);
+            lds_put(lds, PL, ntt_lds_slot(p, wa, col), x0);
+            lds_put(lds, PL, ntt_lds_slot(p, wb, col), x1);
+        }
+    };
+    // pair k of this thread: butterfly index bf = threadIdx.x + 256 k over (column, row j < 128), rows j and j + 128
+    ntt_tile_load(pc, tc, a, tile, threadIdx.x, blockDim.x, lds);
+    __syncthreads();
+    reg_stages(pc, true, tc.small);
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 2; k++) {   // (constant trip count: keep[] stays in registers)
+        if (k >= nb) break;
+        const u32 bf = threadIdx.x + 256 * k, col = bf & (C - 1), j = bf >> pc.log_c;
+        const Fr x = lds_get(lds, PL, ntt_lds_slot(pc, j, col));
+        Fr y = lds_get(lds, PL, ntt_lds_slot(pc, j + 128, col));
+        if (j) y = y * tc.small[j << 4];           // w_256^j = w_4096^(16 j)
+        keep[2 * k] = x + y; keep[2 * k + 1] = x - y;
+    }
+    __syncthreads();
+    ntt_tile_load(pc, tc, b, tile, threadIdx.x, blockDim.x, lds);
+    __syncthreads();
+    reg_stages(pc, true, tc.small);
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < 2; k++) {
+        if (k >= nb) break;
+        const u32 bf = threadIdx.x + 256 * k, col = bf & (C - 1), j = bf >> pc.log_c;
+        const Fr x = lds_get(lds, PL, ntt_lds_slot(pc, j, col));
+        Fr y = lds_get(lds, PL, ntt_lds_slot(pc, j + 128, col));
+        if (j) y = y * tc.small[j << 4];
+        const Fr p0 = (x + y) * keep[2 * k], p1 = (x - y) * keep[2 * k + 1];   // the products at rows j, j + 128
+        Fr d = p0 - p1;                                                         // DIF butterfly at distance 128
+        if (j) d = d * tl.small[j << 4];
+        lds_put(lds, PL, ntt_lds_slot(pl, j, col), p0 + p1);
+        lds_put(lds, PL, ntt_lds_slot(pl, j + 128, col), d);
+    }
+    __syncthreads();
+    reg_stages(pl, false, tl.small);
     __syncthreads();
     ntt_tile_store(pl, tl, a, tile, threadIdx.x, blockDim.x, lds);
 }
@@ -468,14 +532,15 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
     //    The coset FFT's LAST pass (of a and of b), the product and the last transform's FIRST pass share their strided tiles: one
     //    launch (k_ntt_strided_triple) when that pass has radix 2^7 and a tile is one sub-block per wave
     const u32 first_skip = pair ? 1u : 0u;
-    bool triple = st->fuse_triple && st->wave_stages && pl.n_pass >= 2 && pl.log_r[0] == 7;
+    bool triple = st->fuse_triple && st->wave_stages && pl.n_pass >= 2 && (pl.log_r[0] == 7 || pl.log_r[0] == 8);
     NttPass pc{}, pc2{}, plast{};
     NttTables tc{}, tc2{}, tlast{};
     if (triple) {   // capture the two passes without launching anything, and check the tile shape before committing to the fused form
         MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, 2 | 4, &pc, &tc));
         MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, nullptr, 1 | 4, &plast, &tlast));
-        triple = pc.log_r == 7 && plast.log_r == 7 && pc.log_s == plast.log_s && pc.log_c == plast.log_c && pc.log_s != 0 && pc.log_r + pc.log_c >= 7 && pc.log_r + pc.log_c <= 10 &&
-                 pc.lds_pad == plast.lds_pad && !pc.scale && !plast.scale;
+        triple = pc.log_r == plast.log_r && pc.log_s == plast.log_s && pc.log_c == plast.log_c && pc.log_s != 0 && pc.lds_pad == plast.lds_pad && !pc.scale && !plast.scale &&
+                 ((pc.log_r == 7 && pc.log_c <= 3) ||                      // one wave per 128-row sub-block, up to 512 threads
+                  (pc.log_r == 8 && pc.log_c >= 1 && pc.log_c <= 2));      // k_ntt_strided_triple8: 256 threads, 1 or 2 pairs at distance 128 each
     }
     if (!triple) {
         MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip));
@@ -485,9 +550,13 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
     }
     MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | 2, &pc2, &tc2));   // the passes between the seams
     MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | 2, &pc2, &tc2));
-    // one wave per 128-row sub-block of the tile: 64 * 2^(log_r + log_c - 7) threads (256 at the default 2^9-element tiles)
-    hipLaunchKernelGGL(k_ntt_strided_triple, dim3(1u << (log_n - pc.log_r - pc.log_c)), dim3(64u << (pc.log_r + pc.log_c - 7)), (size_t)32 * ntt_plane_slots(pc), ctx->stream,
-                       A, (const Fr *)B, pc, tc, plast, tlast);
+    // radix 2^7: one wave per 128-row sub-block of the tile, 64 * 2^log_c threads (256 at the default 2^9-element tiles); radix 2^8: 256 threads
+    if (pc.log_r == 7)
+        hipLaunchKernelGGL(k_ntt_strided_triple, dim3(1u << (log_n - pc.log_r - pc.log_c)), dim3(64u << pc.log_c), (size_t)32 * ntt_plane_slots(pc), ctx->stream,
+                           A, (const Fr *)B, pc, tc, plast, tlast);
+    else
+        hipLaunchKernelGGL(k_ntt_strided_triple8, dim3(1u << (log_n - pc.log_r - pc.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pc), ctx->stream,
+                           A, (const Fr *)B, pc, tc, plast, tlast);
     MI_CHECK_HIP(ctx, hipGetLastError());
     ctx->stats.ntt_launches++;
     MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, C, 1));

@@ -193,12 +193,13 @@ def test_ntt_register_and_lds_stage_paths_agree_with_oracle(ctx, log_n):
         assert ctx.lib.mi_debug_set_ntt_wave_stages(ctx.h, 1, 12) == 0
 
 
-@pytest.mark.parametrize("log_n,plan", [(10, None), (14, (8, 7, 7)), (16, None), (17, (10, 10, 7)), (20, None), (21, (9, 7, 7))])
+@pytest.mark.parametrize("log_n,plan", [(10, None), (14, (8, 7, 7)), (16, None), (17, (10, 10, 7)), (20, None), (21, (9, 7, 7)), (16, (10, 8, 8)),
+                                         (17, (9, 9, 8)), (19, (10, 3, 8))])
 def test_compute_h_with_and_without_the_fused_launches(ctx, log_n, plan):
     """computeH with its two fused launches -- the inverse transform's last pass + the coset transform's first pass of a and b
     (bit 0; wherever the plan's contiguous radix is >= 2^7), and the coset transform's last pass of a and of b + the product + the last
-    transform's first pass (bit 1; wherever the plan's first radix is 2^7: tiles of 2, 4 and 8 sub-blocks, two- and three-pass plans
-    here) -- in every combination, against the oracle: all of h, with zero padding, c unrelated to a b"""
+    transform's first pass (bit 1; wherever the plan's first radix is 2^7 -- tiles of 2, 4 and 8 sub-blocks, two- and three-pass plans
+    here -- or 2^8 -- the plans of N = 2^24 and 2^26: tiles of 4 and 2 columns, with and without a contiguous pair) -- in every combination, against the oracle: all of h, with zero padding, c unrelated to a b"""
     n = 1 << log_n
     nc = n - 11
     a = cref.gen_scalars(nc, 600 + log_n, 1); b = cref.gen_scalars(nc, 601 + log_n, 0); c = cref.gen_scalars(nc, 602 + log_n, 0)

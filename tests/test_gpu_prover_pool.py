@@ -139,3 +139,53 @@ def test_pool_at_2p20_overlapping_witnesses_match_single_context():
     for d in (g1a, g1b, g1k, g1z, g2b) + tuple(x for w in wit for x in w):
         d.free()
     pool.close()
+
+
+def test_pool_host_inputs_at_2p20_early_handover_and_ledger():
+    """N = 2^20 with HOST inputs (the cgo path): the upload stage hands a job to a worker as soon as W has arrived and a, b, c follow
+    behind an event (csrc/pool.hip) -- eight jobs over two witnesses through a pool of three, bursts included (all submitted at once:
+    the first jobs are picked up while their a, b, c are still on the PCIe bus); every proof equals the one a plain context computes
+    alone.  Also: mi_get_mem_ledger accounts for what the key and the contexts hold."""
+    B = load_binding()
+    log_n = 20
+    N = 1 << log_n
+    nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
+    pool = B.Prover(0, 3)
+    c0 = pool.ctx(0)
+    rng = np.random.default_rng(21)
+    inf_a = (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8); inf_b = (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
+    na, nb, nk = int((inf_a == 0).sum()), int((inf_b == 0).sum()), nb_wires - nb_public
+    g1a, g1b, g1k, g1z, g2b = c0.gen_g1(na, 1), c0.gen_g1(nb, 2), c0.gen_g1(nk, 3), c0.gen_g1(N, 4), c0.gen_g2(nb, 5)
+    small = c0.gen_g1(3, 6).download((3, 8)); small2 = c0.gen_g2(2, 7).download((2, 16))
+    pk = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk),
+          "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb), "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0],
+          "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b}
+    pkh = c0.pk_load(pk, device_points=True)
+    wit = []
+    for w in range(2):
+        W = c0.gen_scalars(nb_wires, 500 + w, 1); a = c0.gen_scalars(n_constraints, 600 + w, 1); b = c0.gen_scalars(n_constraints, 700 + w, 0)
+        c = c0.alloc(32 * n_constraints); c0.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)
+        host = (W.download((nb_wires, 4)), a.download((n_constraints, 4)), b.download((n_constraints, 4)), c.download((n_constraints, 4)))
+        wit.append(((W, a, b, c), host))
+    rs = c0.gen_scalars(16, 800, 0).download((16, 4))
+    c0.sync()
+    single = B.Context(0)
+    want = [single.prove(pkh, *(x.ptr for x in wit[j % 2][0]), rs[2 * j], rs[2 * j + 1], device=True, n_wires=nb_wires, n_constraints=n_constraints)[0]["raw"].copy()
+            for j in range(8)]
+    single.close()
+    for burst in range(2):   # two bursts: the second finds the pool idle again
+        tickets = [pool.submit(pkh, *wit[j % 2][1], rs[2 * j], rs[2 * j + 1]) for j in range(8)]
+        for j, t in enumerate(tickets):
+            proof, st = pool.wait(t)
+            assert np.array_equal(proof["raw"], want[j]), (burst, j)
+            assert st["h2d_ms"] > 0
+    led = c0.mem_ledger(pkh)
+    assert led["key_bases"] + led["key_tables"] > 0 and led["ctx_msm"] > 0 and led["ctx_ntt_vectors"] >= 2 * 32 * N / 1e9 and led["key_indices"] > 0
+    assert pool.ctx(1).mem_ledger()["key_bases"] == 0 and pool.ctx(1).mem_ledger()["ctx_msm"] > 0
+    for (dev, _) in wit:
+        for x in dev:
+            x.free()
+    for d in (g1a, g1b, g1k, g1z, g2b):
+        d.free()
+    c0.pk_free(pkh)
+    pool.close()
