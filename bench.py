@@ -298,6 +298,8 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
                         "mode0_partial_sums_pts_per_s": n_msm * steps_msm / v[1], "mode0_ms": v[1] / steps_msm * 1e3,
                         "mode1_bucket_exchange_pts_per_s": n_msm * steps_msm / v[2], "mode1_ms": v[2] / steps_msm * 1e3,
                         "modes_agree": v[3] == 1.0, "done": True})
+    elif not args.sharded_msm_log_n:
+        sharded["skipped"] = "--sharded-msm-log-n 0"
     else:
         sharded["error"] = res.get("error", "a rank's helper failed")
     if w[0] == 1.0 and w[1] > 0 and w[2] > 0:
@@ -311,6 +313,8 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
                               "pk_load_sharded_s": pv.get("pk_load_sharded_s"),
                               "note": "ranks on distinct devices have only ever run if n_gpus > 1 in this line; with n_gpus = 1 this is the same code path over a world-1 RCCL communicator",
                               "done": True})
+    elif not args.sharded_prove_log_n:
+        sharded_prove["skipped"] = "--sharded-prove-log-n 0"
     else:
         sharded_prove["error"] = pv.get("error") or res.get("error", "a rank's helper failed")
     try:

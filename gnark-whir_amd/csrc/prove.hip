@@ -356,9 +356,15 @@ int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEven
 }
 // both groups from two helper threads; returns when everything is enqueued
 int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {
-    std::future<int32_t> fb = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer, nullptr); });
+    std::future<int32_t> fb;
+    int32_t rb = MI_OK;
+    try {
+        fb = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer, nullptr); });
+    } catch (...) {
+        rb = mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer, nullptr);
+    }
     const int32_t ra = mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, defer, nullptr);
-    const int32_t rb = fb.get();
+    if (fb.valid()) rb = fb.get();
     return ra != MI_OK ? ra : rb;
 }
 // the Z MSM over this key's h coefficients against the bit-reversed pk.G1.Z (ev_h = "h is ready")
@@ -462,8 +468,17 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
             if (rc_inline == MI_OK) rc_inline = mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, nullptr);
             return;
         }
-        f_b = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, g); });
-        f_ak = std::async(std::launch::async, [=] { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, g); });
+        try {
+            f_b = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, g); });
+        } catch (...) {   // no thread to be had: this thread does it (without the hold: it would wait for itself); no exception crosses the C-ABI
+            rc_inline = mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, nullptr);
+        }
+        try {
+            f_ak = std::async(std::launch::async, [=] { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, g); });
+        } catch (...) {
+            const int32_t r = mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, nullptr);
+            if (rc_inline == MI_OK) rc_inline = r;
+        }
     };
     auto main_part = [&]() -> int32_t {
         if (gate) {
