@@ -384,7 +384,8 @@ def main():
         assert pool.lib.mi_debug_set_msm_l1_waves(pool.ctx(i).h, args.g1_waves) == 0
         assert pool.lib.mi_debug_set_msm_group_bits(pool.ctx(i).h, args.msm_group_bits) == 0
         assert pool.lib.mi_debug_set_msm_chunk(pool.ctx(i).h, args.msm_chunk) == 0
-        assert pool.lib.mi_debug_set_prove_schedule(pool.ctx(i).h, 1 if args.hold_accum else 0) == 0
+        if hasattr(pool.lib, "mi_debug_set_prove_schedule"):   # (absent from older builds compared through MI355X_GROTH16_LIB)
+            assert pool.lib.mi_debug_set_prove_schedule(pool.ctx(i).h, 1 if args.hold_accum else 0) == 0
     if args.ntt_plan:
         np_ = [int(x) for x in args.ntt_plan.split(",")]
         for i in range(pool.in_flight):

@@ -414,10 +414,10 @@ void ProofAssembler::finish(const G1X &msm_k, const G2X &msm_b2, const G1X &msm_
 
 // Host-pointer inputs of mi_groth16_prove (null for the device-pointer entry point).
 struct HostInputs { const mi_fr *W, *a, *b, *c; };
-// Device inputs that are still ARRIVING (the prover pool's upload stage, pool.hip): W is complete once w_ready has fired; abc() blocks
-// the host until the producer has RECORDED the event that marks a, b, c complete and returns it (null: their upload failed) -- an
-// event must be recorded before a stream is told to wait for it.
-struct AbcGate { hipEvent_t w_ready; const std::function<hipEvent_t()> *abc; bool abc_arrived; /* a, b, c were complete already when the job was picked up */ };
+// Device inputs that are still ARRIVING (the prover pool's upload stage, pool.hip): W is resident when the call is made; abc() blocks
+// the host until a, b, c are resident too and returns true (false: their upload failed).  Host-side waits on purpose: events recorded
+// on the pool's copy stream between its pageable copies slowed those copies down (round 3: uploads of 50-70 ms instead of 19).
+struct AbcGate { const std::function<bool()> *abc; bool abc_arrived; /* a, b, c were complete already when the job was picked up */ };
 
 // W, a, b, c: device buffers (for host inputs: staging areas the uploads below fill).
 static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
@@ -484,18 +484,21 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         if (gate) {
             // inputs on their way into HBM (pool upload stage): the wire MSMs start as soon as W is there; a, b, c (3/4 of the bytes)
             // finish arriving behind them, and computeH waits for exactly that
-            MI_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, gate->w_ready, 0));
             MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
             start_wires();
-            hipEvent_t abc = (*gate->abc)();
-            if (!abc) MI_FAIL(ctx, MI_EHIP, "prove: the upload of a, b, c failed");
-            MI_CHECK_HIP(ctx, hipStreamWaitEvent(ctx->stream, abc, 0));
+            if (!(*gate->abc)()) MI_FAIL(ctx, MI_EHIP, "prove: the upload of a, b, c failed");
             MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
             return enqueue_h_and_z();
         }
         if (!host) {
             // inputs already in HBM
             MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
+            static const bool old_order = getenv("MI_PROVE_OLD_ORDER") && atoi(getenv("MI_PROVE_OLD_ORDER")) != 0;   // A/B switch: round 2's flow
+            if (old_order) {
+                MI_TRY(enqueue_h_and_z());
+                MI_TRY(mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, nullptr));
+                return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, nullptr);
+            }
             start_wires();
             return enqueue_h_and_z();
         }
@@ -568,9 +571,8 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
 }
 
 int32_t mi_groth16_prove_dev_gated(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
-                                   const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, hipEvent_t w_ready, const std::function<hipEvent_t()> &abc_ready,
-                                   bool abc_arrived) {
-    const AbcGate gate{w_ready, &abc_ready, abc_arrived};
+                                   const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, const std::function<bool()> &abc_ready, bool abc_arrived) {
+    const AbcGate gate{&abc_ready, abc_arrived};
     return prove_common(ctx, pk, W, n_wires, a, b, c, n_constraints, r, s, out, stats, nullptr, &gate);
 }
 

@@ -55,12 +55,12 @@ int32_t mi_prove_enqueue_b_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hipE
 int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hipEvent_t ev_w, bool defer_reduce = false, const std::function<hipEvent_t()> *accum_gate = nullptr);
 int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h_dev, hipEvent_t ev_h, bool defer_reduce = false);
 
-// mi_groth16_prove_dev over inputs that are still arriving in HBM (the prover pool's upload stage): the wire MSMs are ordered after
-// w_ready; abc_ready() must block until the event that marks a, b, c complete HAS BEEN RECORDED and return it (null = their upload
-// failed); computeH is ordered after it.  Same proof bytes.
+// mi_groth16_prove_dev over inputs that are still arriving in HBM (the prover pool's upload stage): W is resident; the wire MSMs are
+// enqueued at once; abc_ready() must block until a, b, c are resident too (false = their upload failed); computeH is enqueued after it.
+// abc_arrived: they already were when the job was picked up (the steady state).  Same proof bytes.
 int32_t mi_groth16_prove_dev_gated(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, size_t n_wires, const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev,
-                                   size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, hipEvent_t w_ready,
-                                   const std::function<hipEvent_t()> &abc_ready, bool abc_arrived);
+                                   size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats,
+                                   const std::function<bool()> &abc_ready, bool abc_arrived);
 
 // Blinding and assembly of Ar, Bs, Krs from the five MSM sums, exactly as gnark's prove.go composes them (row a9); host
 // code over O(1) points.  start() launches the multiples of delta on host threads while the GPU works; have_a_b1() needs

@@ -220,8 +220,8 @@ int32_t mi_get_mem_ledger(mi_ctx *ctx, const mi_pk *pk, mi_mem_ledger *out);
  * submit returns at once with a ticket; W/a/b/c (host or device memory as the variant says), out and stats must stay
  * valid until mi_prover_wait(ticket) returns the job's status (r and s are copied).  Each ticket is waited on exactly
  * once, from any thread.  Proofs are bit-identical to mi_groth16_prove[_dev] on the same inputs.
- * Host inputs (mi_prover_submit) pass through an upload stage with in_flight + 1 device input sets; a job goes to a worker as soon as W
- * has arrived (its A, B1, B2, K MSMs start) and a, b, c follow behind an event.  Null W / a / b / c are accepted where the matching
+ * Host inputs (mi_prover_submit) pass through an upload stage with in_flight + 1 device input sets; a job goes to an IDLE worker as soon
+ * as W is resident (its A, B1, B2, K MSMs start) and a, b, c follow; otherwise when all four are.  Null W / a / b / c are accepted where the matching
  * count is 0.  The input sets are grow-only: the first job of a LARGER size than any before frees and reallocates its set (hipFree
  * synchronises the device -- a one-off stall of every proof in flight, like any other workspace growth).
  * mi_prover_destroy runs the jobs still queued, then frees every context. ---- */
