@@ -488,9 +488,17 @@ def main():
 
     # second timed region: the same K proofs with W, a, b, c in HOST memory (mi_prover_submit, what the cgo drop-in passes:
     # Go slices, mt.go:494-496) -- the PCIe-inclusive rate.  Reported next to `value`, never as `value`.
-    host_rate = host_ms = host_h2d_ms = None
+    host_rate = host_ms = host_h2d_ms = serial_host_ms = None
     if not args.no_host_inputs:
         Wh, ah, bh, ch = W.download((nb_wires, 4)), a.download((n_constraints, 4)), b.download((n_constraints, 4)), c.download((n_constraints, 4))
+        # one proof alone through the host-pointer entry point (mi_groth16_prove, what a caller that proves strictly one circuit at a time
+        # binds -- the reference's own shape, mt.go:494-496): PCIe-inclusive single-proof latency
+        for k in range(3):
+            t1 = time.perf_counter()
+            pr, _ = ctx.prove(pkh, Wh, ah, bh, ch, rs[0], rs[1])
+            serial_host_ms = (time.perf_counter() - t1) * 1e3
+            if B.proof_write(pr["raw"]) != serial_bytes:
+                raise SystemExit("bench.py: the host-pointer proof differs from the device-pointer proof of the same inputs")
         for t in [pool.submit(pkh, Wh, ah, bh, ch, rs[0], rs[1]) for _ in range(max(args.warmup, pool.in_flight + 1))]:
             pool.wait(t)
         fence()
@@ -612,6 +620,9 @@ def main():
             # latency of ONE proof with nothing else on the GPU (untimed region, context 0); value above is throughput with
             # proofs_in_flight_per_gpu proofs overlapping, every one of the K steps submitted and completed inside the timed region
             "single_proof_latency_ms": serial_ms,
+            # the same with W, a, b, c handed over as host pointers (mi_groth16_prove: 1.07 GB cross PCIe inside the call; W first, the wire
+            # MSMs start behind it, a's and b's transforms behind a and b, the rest behind c)
+            "single_proof_latency_host_inputs_ms": serial_host_ms,
             # PCIe-inclusive: the same K steps with W, a, b, c handed over as host pointers (the cgo path); proofs byte-equal
             "value_host_inputs": host_rate, "ms_per_step_host_inputs": host_ms,
             # the upload stage's wall time per job (W, a, b, c = 1.07 GB at N = 2^23 from pageable host memory): when its median nears

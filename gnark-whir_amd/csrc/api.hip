@@ -33,6 +33,7 @@ int32_t mi_init_prio(int device_id, int prio_scheme, mi_ctx **out) {
         if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ph) != hipSuccess) { (void)hipGetLastError(); delete ctx; return MI_EHIP; }
     }
     ctx->own_stream = true;
+    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(ctx->stream); delete ctx; return MI_EHIP; }
     mi_ntt_state_init(ctx);
     // from here on a failure unwinds through mi_shutdown: it frees exactly what exists (null handles are skipped)
     int32_t rc = mi_msm_state_init(ctx);
@@ -51,6 +52,7 @@ int32_t mi_shutdown(mi_ctx *ctx) {
     mi_msm_state_free(ctx);
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     delete ctx;
     return MI_OK;
 }

@@ -38,6 +38,8 @@ struct mi_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t copy_stream = nullptr;   // host-pointer inputs of mi_groth16_prove: pageable copies run on a stream that carries nothing else
+                                         // (no event between two of them: a marker takes the copies behind it off the runtime's fast path)
     std::string err;
     std::mutex err_m;          // a prove enqueues its MSM groups from helper threads (prove.hip): failures there report through mi_set_err
     mi_stats stats{};
@@ -100,6 +102,8 @@ static inline int32_t mi_reserve(mi_ctx *ctx, DevBuf &b, size_t bytes) {
 int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t flags);
 int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                               size_t n_constraints, mi_fr *h_out);
+// computeH one input vector at a time (ntt.hip): part 0 = a, 1 = b, 2 = c (src = that vector), 3 = the rest (src unused)
+int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *src, size_t n_constraints, mi_fr *h_out);
 void mi_ntt_state_init(mi_ctx *ctx);
 size_t mi_ntt_table_bytes(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);

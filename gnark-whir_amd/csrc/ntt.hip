@@ -489,78 +489,96 @@ int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t 
     return ntt_run(ctx, (Fr *)inout_dev, (const Fr *)inout_dev, 1u << log_n, log_n, flags);
 }
 
-int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
-                              size_t n_constraints, mi_fr *h_out) {
+// computeH in four parts on ctx->stream, so that a caller whose inputs arrive one vector at a time (the host-pointer prove: a, b, c cross
+// PCIe one after the other) can start a's transforms while b is still on the bus:
+//   part 0 (src = a), part 1 (src = b)   N FFTInverse(., DIF) and the coset FFT up to (not including) its last pass when that pass runs in
+//                                        the strided triple, else all of it; a lives in h_out, b in ws[0]
+//   part 2 (src = c)                     den FFTInverse(c, DIF) into ws[1]
+//   part 3                               the strided triple (or the coset FFTs' last passes) and the last transform -> h_out
+// The same launches as the one-call form, in an order that differs only between independent vectors: identical h.
+struct ComputeHPlan {
+    bool pair, triple;
+    NttPass pc, plast;
+    NttTables tc, tlast;
+};
+static int32_t compute_h_plan(mi_ctx *ctx, uint32_t log_n, Fr *A, ComputeHPlan &cp) {
     const size_t n = (size_t)1 << log_n;
-    MI_TRY(ensure_direct(ctx, log_n));
-    MI_TRY(mi_reserve(ctx, ctx->ws[0], n * sizeof(Fr)));
-    MI_TRY(mi_reserve(ctx, ctx->ws[1], n * sizeof(Fr)));
-    Fr *A = (Fr *)h_out, *B = (Fr *)ctx->ws[0].p, *C = (Fr *)ctx->ws[1].p;
+    NttState *st = state_of(ctx);
+    const NttKnobs kn = knobs_for(st, log_n);
+    const NttPlan pl = ntt_make_plan(log_n, kn.max_contig, kn.max_strided);
+    // a and b: the contiguous last pass of the inverse transform and the contiguous first pass of the coset transform run as ONE
+    // launch on the same tiles (k_ntt_contig_pair) when the plan has such a pair of radix >= 2^7
+    cp.pair = st->fuse_pair && st->wave_stages && pl.n_pass >= 2 && pl.log_r[pl.n_pass - 1] >= 7;
+    // The coset FFT's LAST pass (of a and of b), the product and the last transform's FIRST pass share their strided tiles: one
+    // launch (k_ntt_strided_triple / k_ntt_strided_triple8) when that pass has radix 2^7 or 2^8 and the tile shape fits
+    cp.triple = st->fuse_triple && st->wave_stages && pl.n_pass >= 2 && (pl.log_r[0] == 7 || pl.log_r[0] == 8);
+    cp.pc = NttPass{}; cp.plast = NttPass{}; cp.tc = NttTables{}; cp.tlast = NttTables{};
+    if (cp.triple) {   // capture the two passes without launching anything, and check the tile shape before committing to the fused form
+        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, 2 | 4, &cp.pc, &cp.tc));
+        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, nullptr, 1 | 4, &cp.plast, &cp.tlast));
+        const NttPass &pc = cp.pc, &plast = cp.plast;
+        cp.triple = pc.log_r == plast.log_r && pc.log_s == plast.log_s && pc.log_c == plast.log_c && pc.log_s != 0 && pc.lds_pad == plast.lds_pad && !pc.scale && !plast.scale &&
+                    ((pc.log_r == 7 && pc.log_c <= 3) ||                      // one wave per 128-row sub-block, up to 512 threads
+                     (pc.log_r == 8 && pc.log_c >= 1 && pc.log_c <= 2));      // k_ntt_strided_triple8: 256 threads, 1 or 2 pairs at distance 128 each
+    }
+    return MI_OK;
+}
+int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *src, size_t n_constraints, mi_fr *h_out) {
+    const size_t n = (size_t)1 << log_n;
     // gnark's computeH (7 transforms): a, b, c <- FFTInverse; a, b, c <- FFT on the coset; a <- (a b - c) den; h <- FFTInverse on
     // the coset.  The last transform is linear and undoes the coset FFT of c exactly:
     //     h = cosetFFTInverse((ca cb - cc) den) = den cosetFFTInverse(ca cb) - den FFTInverse(c),
     // so the coset FFT of c is never computed -- SIX transforms, the same field elements (exact arithmetic), for ANY a, b, c.
-    // 1. a, b <- N FFTInverse(., DIF) (zero padding fused into the first pass's load; the 1/N rides in step 2's coset shift);
-    //    c <- den FFTInverse(c, DIF) (one constant den / N on the way out), bit-reversed like h
-    //    a and b: the contiguous last pass of the inverse transform and the contiguous first pass of the coset transform run as ONE
-    //    launch on the same tiles (k_ntt_contig_pair) when the plan has such a pair of radix >= 2^7
-    NttState *st = state_of(ctx);
-    const NttKnobs kn = knobs_for(st, log_n);
-    const NttPlan pl = ntt_make_plan(log_n, kn.max_contig, kn.max_strided);
-    const bool pair = st->fuse_pair && st->wave_stages && pl.n_pass >= 2 && pl.log_r[pl.n_pass - 1] >= 7;
-    Fr *vec[2] = {A, B};
-    const Fr *in[2] = {(const Fr *)a, (const Fr *)b};
-    for (int k = 0; k < 2; k++) {
-        if (!pair) {
-            MI_TRY(ntt_run(ctx, vec[k], in[k], (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
-            continue;
+    MI_TRY(ensure_direct(ctx, log_n));
+    MI_TRY(mi_reserve(ctx, ctx->ws[0], n * sizeof(Fr)));
+    MI_TRY(mi_reserve(ctx, ctx->ws[1], n * sizeof(Fr)));
+    Fr *A = (Fr *)h_out, *B = (Fr *)ctx->ws[0].p, *C = (Fr *)ctx->ws[1].p;
+    ComputeHPlan cp;
+    MI_TRY(compute_h_plan(ctx, log_n, A, cp));
+    const u32 first_skip = cp.pair ? 1u : 0u;
+    if (part == 0 || part == 1) {
+        // 1. v <- N FFTInverse(v, DIF) (zero padding fused into the first pass's load; the 1/N rides in the coset shift)
+        Fr *v = part == 0 ? A : B;
+        if (!cp.pair) {
+            MI_TRY(ntt_run(ctx, v, (const Fr *)src, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1));
+        } else {
+            NttPass pi{}, pf{};
+            NttTables ti{}, tf{};
+            MI_TRY(ntt_run(ctx, v, (const Fr *)src, (u32)n_constraints, log_n, MI_NTT_INVERSE, 1, nullptr, nullptr, 2, &pi, &ti));
+            MI_TRY(ntt_run(ctx, v, v, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, 1 | 4, &pf, &tf));
+            if (pi.log_r != pf.log_r || pi.log_c != pf.log_c || pi.log_s || pf.log_s) MI_FAIL(ctx, MI_EINVAL, "internal: contiguous pass pair does not match");
+            hipLaunchKernelGGL(k_ntt_contig_pair, dim3(1u << (log_n - pi.log_r - pi.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pi), ctx->stream, v, pi, ti, pf, tf);
+            MI_CHECK_HIP(ctx, hipGetLastError());
+            ctx->stats.ntt_launches++;
         }
-        NttPass pi{}, pf{};
-        NttTables ti{}, tf{};
-        MI_TRY(ntt_run(ctx, vec[k], in[k], (u32)n_constraints, log_n, MI_NTT_INVERSE, 1, nullptr, nullptr, 2, &pi, &ti));
-        MI_TRY(ntt_run(ctx, vec[k], vec[k], (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, 1 | 4, &pf, &tf));
-        if (pi.log_r != pf.log_r || pi.log_c != pf.log_c || pi.log_s || pf.log_s) MI_FAIL(ctx, MI_EINVAL, "internal: contiguous pass pair does not match");
-        hipLaunchKernelGGL(k_ntt_contig_pair, dim3(1u << (log_n - pi.log_r - pi.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pi), ctx->stream,
-                           vec[k], pi, ti, pf, tf);
-        MI_CHECK_HIP(ctx, hipGetLastError());
-        ctx->stats.ntt_launches++;
+        // 2. v <- FFT(v, DIT, OnCoset): the rest of it after the pair, without its last pass when that one runs in the triple
+        NttPass px{};
+        NttTables tx{};
+        return ntt_run(ctx, v, v, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | (cp.triple ? 2u : 0u), &px, &tx);
     }
-    MI_TRY(ntt_run(ctx, C, (const Fr *)c, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4));
-    // 2. a, b <- FFT(., DIT, OnCoset)  (the rest of it when the first pass ran in the pair)
+    if (part == 2)   // c <- den FFTInverse(c, DIF) (one constant den / N on the way out), bit-reversed like h
+        return ntt_run(ctx, C, (const Fr *)src, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4);
     // 3. h <- den FFTInverse(a b, DIF, OnCoset) - c, left bit-reversed like gnark: the product a b is taken on the way into the
-    //    first pass, the subtraction on the way out of the last (no pointwise kernel, no extra round trip through HBM).
-    //    The coset FFT's LAST pass (of a and of b), the product and the last transform's FIRST pass share their strided tiles: one
-    //    launch (k_ntt_strided_triple) when that pass has radix 2^7 and a tile is one sub-block per wave
-    const u32 first_skip = pair ? 1u : 0u;
-    bool triple = st->fuse_triple && st->wave_stages && pl.n_pass >= 2 && (pl.log_r[0] == 7 || pl.log_r[0] == 8);
-    NttPass pc{}, pc2{}, plast{};
-    NttTables tc{}, tc2{}, tlast{};
-    if (triple) {   // capture the two passes without launching anything, and check the tile shape before committing to the fused form
-        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, 2 | 4, &pc, &tc));
-        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, nullptr, 1 | 4, &plast, &tlast));
-        triple = pc.log_r == plast.log_r && pc.log_s == plast.log_s && pc.log_c == plast.log_c && pc.log_s != 0 && pc.lds_pad == plast.lds_pad && !pc.scale && !plast.scale &&
-                 ((pc.log_r == 7 && pc.log_c <= 3) ||                      // one wave per 128-row sub-block, up to 512 threads
-                  (pc.log_r == 8 && pc.log_c >= 1 && pc.log_c <= 2));      // k_ntt_strided_triple8: 256 threads, 1 or 2 pairs at distance 128 each
-    }
-    if (!triple) {
-        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip));
-        MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip));
-        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C));
-        return MI_OK;
-    }
-    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | 2, &pc2, &tc2));   // the passes between the seams
-    MI_TRY(ntt_run(ctx, B, B, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | 2, &pc2, &tc2));
+    //    first pass, the subtraction on the way out of the last (no pointwise kernel, no extra round trip through HBM)
+    if (!cp.triple) return ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C);
     // radix 2^7: one wave per 128-row sub-block of the tile, 64 * 2^log_c threads (256 at the default 2^9-element tiles); radix 2^8: 256 threads
+    const NttPass &pc = cp.pc;
     if (pc.log_r == 7)
         hipLaunchKernelGGL(k_ntt_strided_triple, dim3(1u << (log_n - pc.log_r - pc.log_c)), dim3(64u << pc.log_c), (size_t)32 * ntt_plane_slots(pc), ctx->stream,
-                           A, (const Fr *)B, pc, tc, plast, tlast);
+                           A, (const Fr *)B, pc, cp.tc, cp.plast, cp.tlast);
     else
         hipLaunchKernelGGL(k_ntt_strided_triple8, dim3(1u << (log_n - pc.log_r - pc.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pc), ctx->stream,
-                           A, (const Fr *)B, pc, tc, plast, tlast);
+                           A, (const Fr *)B, pc, cp.tc, cp.plast, cp.tlast);
     MI_CHECK_HIP(ctx, hipGetLastError());
     ctx->stats.ntt_launches++;
-    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, C, 1));
-    return MI_OK;
+    return ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, C, 1);
+}
+int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                              size_t n_constraints, mi_fr *h_out) {
+    MI_TRY(mi_compute_h_part(ctx, log_n, 0, a, n_constraints, h_out));
+    MI_TRY(mi_compute_h_part(ctx, log_n, 1, b, n_constraints, h_out));
+    MI_TRY(mi_compute_h_part(ctx, log_n, 2, c, n_constraints, h_out));
+    return mi_compute_h_part(ctx, log_n, 3, nullptr, n_constraints, h_out);
 }
 
 static void stats_begin(mi_ctx *ctx) { std::memset(&ctx->stats, 0, sizeof(ctx->stats)); }

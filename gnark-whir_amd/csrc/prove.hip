@@ -461,22 +461,22 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     std::future<int32_t> f_b, f_ak;
     static const bool helper_threads = !(getenv("MI_PROVE_HELPER_THREADS") && atoi(getenv("MI_PROVE_HELPER_THREADS")) == 0);   // A/B switch
     int32_t rc_inline = MI_OK;
-    auto start_wires = [&] {
+    auto start_wires = [&](hipEvent_t ev_w) {   // ev_w: "W is resident" on some stream, or null when the host already knows it is
         const std::function<hipEvent_t()> *g = hold ? &h_gate : nullptr;
         if (!helper_threads) {   // the round-2 form: both groups enqueued by this thread, one after the other (no hold: it would wait for itself)
-            rc_inline = mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, nullptr);
-            if (rc_inline == MI_OK) rc_inline = mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, nullptr);
+            rc_inline = mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, false, nullptr);
+            if (rc_inline == MI_OK) rc_inline = mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, false, nullptr);
             return;
         }
         try {
-            f_b = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, g); });
+            f_b = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, false, g); });
         } catch (...) {   // no thread to be had: this thread does it (without the hold: it would wait for itself); no exception crosses the C-ABI
-            rc_inline = mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, nullptr);
+            rc_inline = mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, false, nullptr);
         }
         try {
-            f_ak = std::async(std::launch::async, [=] { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, g); });
+            f_ak = std::async(std::launch::async, [=] { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, false, g); });
         } catch (...) {
-            const int32_t r = mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, nullptr);
+            const int32_t r = mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, false, nullptr);
             if (rc_inline == MI_OK) rc_inline = r;
         }
     };
@@ -484,8 +484,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         if (gate) {
             // inputs on their way into HBM (pool upload stage): the wire MSMs start as soon as W is there; a, b, c (3/4 of the bytes)
             // finish arriving behind them, and computeH waits for exactly that
-            MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-            start_wires();
+            start_wires(nullptr);   // W is resident (the pool synchronised its copy stream before handing the job over)
             if (!(*gate->abc)()) MI_FAIL(ctx, MI_EHIP, "prove: the upload of a, b, c failed");
             MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
             return enqueue_h_and_z();
@@ -499,21 +498,39 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
                 MI_TRY(mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, nullptr));
                 return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, nullptr);
             }
-            start_wires();
+            start_wires(ev[2]);
             return enqueue_h_and_z();
         }
         // inputs in host memory (the cgo path): upload W, start the wire MSMs, and upload a, b, c WHILE they run; the
-        // PCIe time of a, b, c (3/4 of the bytes) disappears behind the MSMs instead of preceding the whole proof
+        // PCIe time of a, b, c (3/4 of the bytes) disappears behind the MSMs instead of preceding the whole proof.  The copies run on
+        // the context's copy stream, which carries nothing else, and are ordered by synchronising it on this thread (a pageable copy
+        // holds the calling thread anyway): events between them cost 2-3.5x on every later copy (the pool's lesson).
+        // Order on the bus: W, a, b, c.  The wire MSMs start as soon as W is resident; computeH heads the proof's longest chain (h -> Z
+        // MSM), so a's inverse and coset transforms start as soon as a is resident (mi_compute_h_part), b's behind b, and what needs
+        // all three behind c: h is ready ~2.5 ms after c has crossed instead of a whole computeH later.  (a first: measured 2 ms worse
+        // -- the wire MSMs' 14 ms of work then start 5 ms later and nothing else can fill the bus time.)
         const size_t wb = n_wires * sizeof(mi_fr), cb = n_constraints * sizeof(mi_fr);
-        MI_CHECK_HIP(ctx, hipEventRecord(ev[10], ctx->stream));
-        MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)W, host->W, wb, hipMemcpyHostToDevice, ctx->stream));
-        MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-        start_wires();
-        MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)a, host->a, cb, hipMemcpyHostToDevice, ctx->stream));
-        MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)b, host->b, cb, hipMemcpyHostToDevice, ctx->stream));
-        MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)c, host->c, cb, hipMemcpyHostToDevice, ctx->stream));
+        const auto t_up = std::chrono::steady_clock::now();
+        auto upload = [&](const mi_fr *dst, const mi_fr *src, size_t bytes) -> int32_t {
+            if (bytes) MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+            MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+            return MI_OK;
+        };
+        MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging area may still be read by an earlier call's kernels
         MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
-        return enqueue_h_and_z();
+        MI_TRY(upload(W, host->W, wb));
+        start_wires(nullptr);   // W is resident: nothing to wait for
+        MI_TRY(upload(a, host->a, cb));
+        MI_TRY(mi_compute_h_part(ctx, pk->log_n, 0, a, n_constraints, (mi_fr *)h));
+        MI_TRY(upload(b, host->b, cb));
+        MI_TRY(mi_compute_h_part(ctx, pk->log_n, 1, b, n_constraints, (mi_fr *)h));
+        MI_TRY(upload(c, host->c, cb));
+        ctx->stats.h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_up).count();
+        MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, c, n_constraints, (mi_fr *)h));
+        MI_TRY(mi_compute_h_part(ctx, pk->log_n, 3, nullptr, n_constraints, (mi_fr *)h));
+        MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+        h_recorded.set_value(ev[3]); h_promised = true;
+        return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);
     };
     {
         int32_t rc = main_part();
@@ -558,7 +575,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     };
     // per-phase spans overlap (five streams): they do not add up to total_ms
     MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.compute_h_ms, (host || gate) ? ev[11] : ev[2], ev[3]));
-    if (host) MI_CHECK_HIP(ctx, hipEventElapsedTime(&st.h2d_ms, ev[10], ev[11]));   // span of the uploads (overlaps the wire MSMs)
+    // (h2d_ms of the host-pointer path: wall clock of the uploads, set above -- they overlap the wire MSMs)
     if (pk->nb_wires) MI_TRY(slot_ms(0, &st.msm_a_ms));
     if (pk->n_b) { MI_TRY(slot_ms(1, &st.msm_b1_ms)); MI_TRY(slot_ms(2, &st.msm_b2_ms)); }
     if (pk->nb_wires) MI_TRY(slot_ms(3, &st.msm_k_ms));
