@@ -663,7 +663,12 @@ def main():
             "valu": {"modmul_ceiling_per_s": 256 * 4096 * 256 * 2 / (modmul_ms * 1e-3),
                      "kernel_mixed_adds_per_s": accum_entries / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,
                      "kernel_modmul_per_s": 10.0 * accum_entries / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,
-                     "note": "one XYZZ mixed addition = 8M + 2S Fp products (+ ~7 add/sub); frac = kernel_modmul_per_s / modmul_ceiling_per_s"},
+                     "note": "one XYZZ mixed addition = 8M + 2S Fp products (+ ~7 add/sub); frac = kernel_modmul_per_s / modmul_ceiling_per_s",
+                     # the kernel's OWN instruction mix (ISA of k_msm_accum_affine29: 1467 v_mad_u64_u32 of ~2450 vector instructions per addition, at
+                     # the per-instruction costs of profiles/r02_probe_instr_rate.txt ~ 10 800 cycles per wave-addition) allows a
+                     # SIMD 2.4e9 / 10800 wave-additions/s: the kernel alone on the GPU against that floor
+                     "issue_floor_adds_per_s": 2.4e9 / 10800.0 * 64 * 1024,
+                     "kernel_alone_frac_of_issue_floor": solo["mixed_adds_per_s"] / (2.4e9 / 10800.0 * 64 * 1024)},
         }
         if cpu_inputs is not None:
             line["cpu_baseline"] = cpu_baseline(*cpu_inputs, rs[0], rs[1], log_n, serial_bytes)
