@@ -342,6 +342,7 @@ def main():
     ap.add_argument("--msm-group-bits", type=int, default=0, help="tuning: mi_debug_set_msm_group_bits on every context")
     ap.add_argument("--no-limb29", action="store_true", help="tuning: G1 level-1 accumulation in 8 x 32-bit limbs (mi_debug_set_msm_limb29(0)) instead of 9 x 29-bit")
     ap.add_argument("--g1-waves", type=int, default=3, choices=(2, 3), help="tuning: build of the G1 level-1 kernel (mi_debug_set_msm_l1_waves): 3 waves per SIMD (default) or 2")
+    ap.add_argument("--bound-levels", action="store_true", help="tuning: mi_debug_set_msm_bound_levels(1): worst-case number of item levels per MSM instead of what the fullest bucket needs")
     ap.add_argument("--hold-accum", action="store_true", help="tuning: mi_debug_set_prove_schedule(1): the wire MSMs' bucket accumulations wait for computeH (measured: no gain)")
     ap.add_argument("--msm-chunk", type=int, default=0, help="tuning: mi_debug_set_msm_chunk on every context")
     ap.add_argument("--sharded-msm-log-n", type=int, default=26, help="configs[4]: size of the point-sharded G1 MSM run after the proofs (0 = skip)")
@@ -384,6 +385,8 @@ def main():
         assert pool.lib.mi_debug_set_msm_l1_waves(pool.ctx(i).h, args.g1_waves) == 0
         assert pool.lib.mi_debug_set_msm_group_bits(pool.ctx(i).h, args.msm_group_bits) == 0
         assert pool.lib.mi_debug_set_msm_chunk(pool.ctx(i).h, args.msm_chunk) == 0
+        if hasattr(pool.lib, "mi_debug_set_msm_bound_levels"):
+            assert pool.lib.mi_debug_set_msm_bound_levels(pool.ctx(i).h, 1 if args.bound_levels else 0) == 0
         if hasattr(pool.lib, "mi_debug_set_prove_schedule"):   # (absent from older builds compared through MI355X_GROTH16_LIB)
             assert pool.lib.mi_debug_set_prove_schedule(pool.ctx(i).h, 1 if args.hold_accum else 0) == 0
     if args.ntt_plan:

@@ -16,7 +16,10 @@ struct DevBuf {             // growable device scratch owned by the ctx (no hipM
 #define MI_MSM_SLOTS 6
 struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, workspaces, pinned result
     hipStream_t stream = nullptr;
-    hipEvent_t ev[6]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job, 5: bucket sums ready (deferred reduce)
+    hipEvent_t ev[7]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job, 5: bucket sums ready (deferred reduce),
+                            // 6: the largest bucket's size has landed in host memory (exact level count, msm.hip)
+    bool max_pending = false;       // this slot's sort has a "largest bucket" word on its way to the host (ev[6])
+    uint32_t max_key_count = 0;     // entries of the fullest bucket of this slot's sort, once fetched
     DevBuf buf[15];
     void *host_wsum = nullptr;
     uint32_t n = 0, c = 0, G = 0;

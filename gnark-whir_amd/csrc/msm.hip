@@ -29,6 +29,8 @@ struct MsmKnobs {
     u32 one_pass_sort = 0;                      // 1: large generic MSMs keep the one-pass counting sort (tests compare both)
     u32 chunk = 0;                              // fixed-base sort: entries per pass-2 chunk (tests shrink it)
     u32 gbits = 0;                              // fixed-base sort: log2 buckets per pass-1 group (0 = automatic)
+    u32 bound_levels = 0;                       // 1: as many item levels as the worst case needs (windows * n entries in one bucket) instead of
+                                                // as many as the fullest bucket of THIS sort needs (tests compare both)
 };
 static MsmKnobs *knobs_of(mi_ctx *ctx) { return reinterpret_cast<MsmKnobs *>(ctx->msm_knobs); }
 __global__ void k_msm_hist(MsmShape s, const int16_t *digits, u32 *H);
@@ -339,7 +341,33 @@ void mi_msm_state_free(mi_ctx *ctx) {
 }
 
 // slot buffers
-enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_PVAL, B_C1, B_CHUNKS, B_ITEMTAB, B_COUNT_ };
+enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_PVAL, B_C1, B_CHUNKS, B_ITEMTAB, B_MAX, B_COUNT_ };
+static_assert(B_COUNT_ <= sizeof(MsmSlot::buf) / sizeof(DevBuf), "MsmSlot::buf is too small");
+
+// The fullest bucket of a sort: per-key totals -> one word (atomicMax), copied to pinned host memory behind the slot's ev[6].  The item
+// machinery needs ceil(log_L(fullest bucket)) levels; the worst case (every entry in one bucket) says 9 at N = 2^23 where uniform
+// scalars need 3 and the WHIR mix 7, and every unneeded level is three launches of empty kernels on the MSM's tail.  The host waits for
+// the word on the thread that enqueues the accumulation (a helper thread for the wire MSMs) while the rest of the sort still runs.
+__global__ void __launch_bounds__(256) k_max_u32(const u32 *v, u32 n, u32 *out) {
+    u32 m = 0;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = v[i] > m ? v[i] : m;
+    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+static int32_t fetch_max_enqueue(mi_ctx *ctx, MsmSlot &sl, const u32 *totals, u32 nkeys) {
+    MI_TRY(mi_reserve(ctx, sl.buf[B_MAX], 64));
+    u32 *dmax = (u32 *)sl.buf[B_MAX].p;
+    hipStream_t st = sl.stream;
+    MI_CHECK_HIP(ctx, hipMemsetAsync(dmax, 0, 4, st));
+    unsigned grid = (nkeys + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_max_u32, dim3(grid), dim3(256), 0, st, totals, nkeys, dmax);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)sl.host_wsum + 128 * 256 + 32, dmax, 4, hipMemcpyDeviceToHost, st));
+    MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[6], st));
+    sl.max_pending = true;
+    return MI_OK;
+}
 
 // Runs levels of the item machinery over `nkeys` keys whose level-0 decomposition (start/cnt/items) is
 // already in cur.  Level 0 reads (pts, sorted) when pts != null, else partial_first.
@@ -442,6 +470,7 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
     MI_CHECK_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_msm_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, H, total);
     MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(fetch_max_enqueue(ctx, sl, total, s.nkeys));
     MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
     hipLaunchKernelGGL(k_msm_scatter, dim3(s.nslices, s.nwin), dim3(1024), lds_bytes, st, s, digits, keystart, H, sorted);
     MI_CHECK_HIP(ctx, hipGetLastError());
@@ -506,6 +535,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     hipLaunchKernelGGL(k_msm2_hist2, dim3(chunks_bound), dim3(1024), s.gsize * 4, st, s, gstart, cstart, part_lo, H2);
     hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, cstart, H2, total);
     MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_TRY(fetch_max_enqueue(ctx, sl, total, s.nkeys));
     MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
     hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound + 8), dim3(1024), s.gsize * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
     MI_CHECK_HIP(ctx, hipGetLastError());
@@ -540,8 +570,15 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
         acc.accum_gate = nullptr;
         if (g) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, g, 0));
     }
-    // largest possible bucket: one entry per scalar and window of the key space it collects
-    const u64 max_count = (u64)(srt.nwin_digits / srt.nwin_keys) * n;
+    // largest possible bucket: one entry per scalar and window of the key space it collects -- or, fetched from this very sort, the
+    // fullest bucket there is (k_max_u32 above: the wait is on the enqueueing thread and ends before the sort does)
+    u64 max_count = (u64)(srt.nwin_digits / srt.nwin_keys) * n;
+    if (srt.max_pending) {
+        MI_CHECK_HIP(ctx, hipEventSynchronize(srt.ev[6]));
+        srt.max_key_count = *(const u32 *)((const char *)srt.host_wsum + 128 * 256 + 32);
+        srt.max_pending = false;
+    }
+    if (!kn->bound_levels && srt.max_key_count && srt.max_key_count < max_count) max_count = srt.max_key_count;
     MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed, rprime));
     // everything below reads the bucket sums only: a point-sharded MSM (group.hip, SURVEY 8e option ii) stops here, exchanges
     // bucket slices between the devices and calls mi_msm_reduce_enqueue afterwards
@@ -759,6 +796,11 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on) {
 int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves) {
     if (!ctx || (waves != 2 && waves != 3)) return MI_EINVAL;
     knobs_of(ctx)->l1_waves = waves;
+    return MI_OK;
+}
+int32_t mi_debug_set_msm_bound_levels(mi_ctx *ctx, uint32_t on) {
+    if (!ctx || on > 1) return MI_EINVAL;
+    knobs_of(ctx)->bound_levels = on;
     return MI_OK;
 }
 int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on) {

@@ -392,6 +392,9 @@ int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, 
  * accumulations only when computeH is done; 0 (default): everything as soon as its inputs exist.  Same proofs.  Measured neutral on
  * throughput and 0.4 ms worse on the single-proof latency (a proof alone is work-bound, not schedule-bound: DESIGN.md 7b). */
 int32_t mi_debug_set_prove_schedule(mi_ctx *ctx, uint32_t hold_accum);
+/* on = 0 (default): an MSM runs as many item levels as the fullest bucket of its sort needs (one 4-byte read-back per sort, waited for on the
+ * thread that enqueues the accumulation); 1: as many as the worst case would (every entry in one bucket).  Same sums; parity tests run both. */
+int32_t mi_debug_set_msm_bound_levels(mi_ctx *ctx, uint32_t on);
 /* 1: generic MSMs of >= 2^18 pairs keep the one-pass counting sort instead of the LDS-staged two-pass one (parity tests run both) */
 int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on);
 /* on = 1 (default): the G1 level-1 bucket accumulation runs in nine 29-bit limbs (keys loaded afterwards keep their G1 points in

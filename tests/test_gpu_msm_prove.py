@@ -474,3 +474,23 @@ def test_window_tables_batched_and_per_point_conversions_are_identical(ctx, g2, 
         i = min(3, n - 1)
         assert np.array_equal(tabs[0][(nwin - 1) * n + i], cref.g1_scalar_mul(pts[i], 1 << (c * (nwin - 1))))
     dp.free()
+
+
+@pytest.mark.parametrize("n,dist", [(60000, 1), (300000, 0), (1 << 20, 1)])
+def test_msm_exact_and_worst_case_level_counts_agree_with_oracle(ctx, n, dist):
+    """the item levels of an MSM are counted from the fullest bucket of its own sort (one 4-byte read-back, default) or from the worst
+    case (every entry in one bucket): same sums, G1 and G2, small (one-pass sort) and large (two-pass sort) MSMs, skewed and uniform
+    scalars -- with a giant bucket (a third of the scalars equal 1) in the skewed ones"""
+    pts = cref.gen_g1(n, 7100 + n); sc = cref.gen_scalars(n, 7101 + n, dist)
+    if dist:
+        sc[::3] = fr_arr([1])[0]
+    n2 = min(n, 40000)
+    p2 = cref.gen_g2(n2, 7102); s2 = sc[:n2]
+    want1, want2 = cref.msm_g1(pts, sc), cref.msm_g2(p2, s2)
+    try:
+        for on in (0, 1, 0):
+            assert ctx.lib.mi_debug_set_msm_bound_levels(ctx.h, on) == 0
+            assert np.array_equal(ctx.msm_g1(pts, sc), want1), on
+            assert np.array_equal(ctx.msm_g2(p2, s2), want2), on
+    finally:
+        assert ctx.lib.mi_debug_set_msm_bound_levels(ctx.h, 0) == 0
