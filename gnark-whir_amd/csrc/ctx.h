@@ -20,7 +20,7 @@ struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, 
                             // 6: the largest bucket's size has landed in host memory (exact level count, msm.hip)
     bool max_pending = false;       // this slot's sort has a "largest bucket" word on its way to the host (ev[6])
     uint32_t max_key_count = 0;     // entries of the fullest bucket of this slot's sort, once fetched
-    DevBuf buf[15];
+    DevBuf buf[18];
     void *host_wsum = nullptr;
     uint32_t n = 0, c = 0, G = 0;
     uint64_t entries_cap = 0;   // entries the sort of this slot is sized for: windows * n, or the counted number (MI_MSM_EXACT_SIZE)
@@ -99,6 +99,16 @@ static inline int32_t mi_reserve(mi_ctx *ctx, DevBuf &b, size_t bytes) {
     MI_CHECK_HIP(ctx, hipMalloc(&b.p, want));
     b.cap = want;
     return MI_OK;
+}
+
+// the same for scratch a faster path would like but the slower one does without: false (and no error) when the memory is not there
+static inline bool mi_try_reserve(DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return true;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&b.p, want) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return false; }
+    b.cap = want;
+    return true;
 }
 
 // internal entry points implemented across translation units

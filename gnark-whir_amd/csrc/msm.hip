@@ -23,6 +23,7 @@
 struct MsmKnobs {
     u32 c = 0, L1 = 0, L2 = 0, seg = 0, G = 0;  // 0 = automatic
     u32 no_rprime = 0;                          // 1: G1 level 1 stays on the 8 x 32-bit kernel everywhere (tests compare both)
+    u32 ba_rounds = 0;                          // G1 level 1 by batch-affine rounds (msm_ba_g1.cuh): 0 = off, 1..4 rounds (MI_MSM_BA_ROUNDS)
     u32 l1_waves = 3;                           // G1 level-1 29-bit kernel: the build for 3 (default) or 2 waves per SIMD (msm_g1.hip)
     u32 precompute_unbatched = 0;               // 1: window tables by the one-kernel form (one inversion per point per window)
     u32 std_partials = 0;                       // 1: partial sums between the levels in the standard form even after a 29-bit level 1
@@ -303,6 +304,7 @@ static MsmShape key_shape(const MsmSlot &sl) {
 
 int32_t mi_msm_state_init(mi_ctx *ctx) {
     new (ctx->msm_knobs) MsmKnobs();
+    if (const char *e = getenv("MI_MSM_BA_ROUNDS")) { const int r = atoi(e); if (r >= 0 && r <= 4) knobs_of(ctx)->ba_rounds = (u32)r; }   // A/B switch
     // the c = 16 histogram / cursor image is 128 KiB of LDS (gfx950 allows 160 KiB per workgroup)
     (void)hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -341,7 +343,7 @@ void mi_msm_state_free(mi_ctx *ctx) {
 }
 
 // slot buffers
-enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_PVAL, B_C1, B_CHUNKS, B_ITEMTAB, B_MAX, B_COUNT_ };
+enum { B_DIGITS, B_H, B_S, B_SORTED, B_LEVELS, B_PART0, B_PART1, B_BUCKET, B_SCAN, B_WIN, B_PVAL, B_C1, B_CHUNKS, B_ITEMTAB, B_MAX, B_BA_NODES, B_BA_PREFIX, B_BA_TOT, B_COUNT_ };
 static_assert(B_COUNT_ <= sizeof(MsmSlot::buf) / sizeof(DevBuf), "MsmSlot::buf is too small");
 
 // The fullest bucket of a sort: per-key totals -> one word (atomicMax), copied to pinned host memory behind the slot's ev[6].  The item
@@ -406,7 +408,21 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         // opening event AFTER its item-table kernel (0.1 ms alone, up to 0.5 ms waiting for CUs with three proofs in flight)
         const bool rp_path = level == 0 && pts && rprime && ops.accum_affine_rp;
         if (time_first && level == 0 && !rp_path) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
-        if (rp_path) {
+        const u32 ba_rounds = knobs_of(ctx)->ba_rounds;
+        // batch-affine rounds (msm_ba_g1.cuh) where the buckets hold a few items each (>= 32 entries on average) and the scratch fits
+        const u32 ba_waves = (u32)ctx->cu_count * 16;
+        const size_t ba_tot = msm_ba_scratch_bytes(items_bound + 1, ba_waves);
+        const bool use_ba = rp_path && ba_rounds && ops.accum_affine_ba && L == 16 && first_items_bound >= (u64)nkeys * 3 &&
+                            mi_try_reserve(sl.buf[B_BA_NODES], (items_bound + 1) * 512) && mi_try_reserve(sl.buf[B_BA_PREFIX], (items_bound + 1) * 256) &&
+                            mi_try_reserve(sl.buf[B_BA_TOT], 2 * ba_tot);
+        if (use_ba) {
+            static const bool ba_trace = getenv("MI_MSM_BA_TRACE") != nullptr;
+            if (ba_trace) fprintf(stderr, "msm: batch-affine level 1, %u rounds, nkeys %u, items <= %llu\n", ba_rounds, nkeys, (unsigned long long)items_bound);
+            MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
+            ops.accum_affine_ba(st, (u32)ctx->cu_count * 64, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, final_out, pout, sl.buf[B_ITEMTAB].p,
+                                rp_partials ? 1u : 0u, ba_rounds, items_bound + 1, ba_waves, sl.buf[B_BA_NODES].p, sl.buf[B_BA_PREFIX].p, sl.buf[B_BA_TOT].p,
+                                (char *)sl.buf[B_BA_TOT].p + ba_tot, time_first ? sl.ev[1] : nullptr);
+        } else if (rp_path) {
             MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
             ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p,
                                 (rp_partials ? 1u : 0u) | (knobs_of(ctx)->l1_waves == 2 ? 2u : 0u), time_first ? sl.ev[1] : nullptr);
@@ -791,6 +807,11 @@ int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on) {
 int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on) {
     if (!ctx || on > 1) return MI_EINVAL;
     knobs_of(ctx)->precompute_unbatched = on ? 0 : 1;
+    return MI_OK;
+}
+int32_t mi_debug_set_msm_batch_affine(mi_ctx *ctx, uint32_t rounds) {
+    if (!ctx || rounds > 4) return MI_EINVAL;
+    knobs_of(ctx)->ba_rounds = rounds;
     return MI_OK;
 }
 int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves) {

@@ -35,8 +35,33 @@ struct MsmCurveOps {
     // curve keeps its partial sums in the standard form (G2), and rp_partials must be 0.
     void (*accum_xyzz_rp)(hipStream_t st, unsigned grid, const void *partial_in, const uint32_t *start, const uint32_t *cnt, const uint32_t *items,
                           const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out);
+    // Level-1 accumulation by batch-affine rounds (msm_ba_g1.cuh): same inputs and outputs as accum_affine_rp for items of <= 16
+    // entries.  rounds = 1..4; scratch: nodes (512 B per item), prefix (256 B per item), totals / invs (msm_ba_scratch_bytes each).
+    // Null where no such kernels exist (G2).
+    void (*accum_affine_ba)(hipStream_t st, unsigned grid_cap, const void *pts_rp, const uint32_t *sorted, const uint32_t *start, const uint32_t *cnt,
+                            const uint32_t *items, const uint32_t *item_start, uint32_t nkeys, void *bucket, void *partial_out, void *item_table,
+                            uint32_t rp_partials, uint32_t rounds, uint64_t items_bound, uint32_t target_waves, void *nodes, void *prefix, void *totals,
+                            void *invs, hipEvent_t ev_before);
     // dst[i] = src[i] with both coordinates multiplied by 2^5 mod p: standard Montgomery form -> the R' packed form (dst may be src)
     void (*to_rprime)(hipStream_t st, void *dst, const void *src, size_t n);
 };
+// slots per lane and chunk (K) of a batch-affine round over at most `slots_bound` slots: enough chunks to fill `target_waves` waves, 4..32
+static inline uint32_t msm_ba_K(uint64_t slots_bound, uint32_t target_waves) {
+    const uint64_t k = slots_bound / (64ull * (target_waves ? target_waves : 1));
+    return k < 4 ? 4u : k > 32 ? 32u : (uint32_t)k;
+}
+static inline uint64_t msm_ba_chunks(uint64_t slots_bound, uint32_t target_waves) {
+    const uint64_t per = 64ull * msm_ba_K(slots_bound, target_waves);
+    return (slots_bound + per - 1) / per;
+}
+// bytes of the totals (and of the invs) scratch array: the largest round is the first (8 slots per item)
+static inline size_t msm_ba_scratch_bytes(uint64_t items_bound, uint32_t target_waves) {
+    size_t m = 0;
+    for (int r = 1; r <= 4; r++) {
+        const size_t b = (size_t)msm_ba_chunks(items_bound << (4 - r), target_waves) * 64 * 32;
+        m = b > m ? b : m;
+    }
+    return m;
+}
 const MsmCurveOps &msm_g1_ops();   // msm_g1.hip
 const MsmCurveOps &msm_g2_ops();   // msm_g2.hip

@@ -2,6 +2,7 @@
 // 9 x 29-bit representation (curve29.cuh).
 #include "msm_curve_kernels.cuh"
 #include "curve29.cuh"
+#include "msm_ba_g1.cuh"
 
 // Level-1 bucket accumulation over points in the R' packed form: the item decomposition of k_msm_accum_affine, the mixed
 // additions of an item in nine 29-bit limbs (162 multiplications and no carry instruction per product instead of 136 + 120;
@@ -79,6 +80,43 @@ static void launch_accum_affine29(hipStream_t st, unsigned grid, const void *pts
     else hipLaunchKernelGGL(k_msm_accum_affine29, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
                             (G1X *)bucket, (G1X *)pout, rp_partials & 1u);
 }
+// one batch-affine round (msm_ba_g1.cuh)
+template <int R>
+static void ba_round(hipStream_t st, unsigned grid_cap, const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys, uint64_t items_bound,
+                     u32 target_waves, uint4 *nodes, uint4 *prefix, uint4 *totals, uint4 *invs) {
+    const uint64_t slots = items_bound << (BA_LOG_L - R);
+    const u32 K = msm_ba_K(slots, target_waves);
+    const uint64_t chunks = msm_ba_chunks(slots, target_waves);
+    const unsigned grid = (unsigned)(chunks < grid_cap ? (chunks ? chunks : 1) : grid_cap);
+    hipLaunchKernelGGL(k_ba_fwd<R>, dim3(grid), dim3(64), 0, st, pts, sorted, tab, item_start, nkeys, (const uint4 *)nodes, prefix, totals, K);
+    hipLaunchKernelGGL(k_ba_inv, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, st, item_start, nkeys, BA_LOG_L - R, K, (const u32 *)totals, (u32 *)invs);
+    hipLaunchKernelGGL(k_ba_bwd<R>, dim3(grid), dim3(64), 0, st, pts, sorted, tab, item_start, nkeys, nodes, (const uint4 *)prefix, (const uint4 *)invs, K);
+}
+static void launch_accum_affine_ba(hipStream_t st, unsigned grid_cap, const void *pts_, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
+                                   const u32 *item_start, u32 nkeys, void *bucket, void *pout, void *item_tab, u32 rp_partials, u32 rounds, uint64_t items_bound,
+                                   u32 target_waves, void *nodes_, void *prefix_, void *totals_, void *invs_, hipEvent_t ev_before) {
+    const G1Aff *pts = (const G1Aff *)pts_;
+    const uint4 *tab = (const uint4 *)item_tab;
+    uint4 *nodes = (uint4 *)nodes_, *prefix = (uint4 *)prefix_, *totals = (uint4 *)totals_, *invs = (uint4 *)invs_;
+    unsigned tgrid = (unsigned)((items_bound + 255) / 256);
+    hipLaunchKernelGGL(k_msm_item_table<Fp>, dim3(tgrid < 8192 ? (tgrid ? tgrid : 1) : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
+    if (ev_before) (void)hipEventRecord(ev_before, st);
+    if (rounds >= 1) ba_round<1>(st, grid_cap, pts, sorted, tab, item_start, nkeys, items_bound, target_waves, nodes, prefix, totals, invs);
+    if (rounds >= 2) ba_round<2>(st, grid_cap, pts, sorted, tab, item_start, nkeys, items_bound, target_waves, nodes, prefix, totals, invs);
+    if (rounds >= 3) ba_round<3>(st, grid_cap, pts, sorted, tab, item_start, nkeys, items_bound, target_waves, nodes, prefix, totals, invs);
+    if (rounds >= 4) ba_round<4>(st, grid_cap, pts, sorted, tab, item_start, nkeys, items_bound, target_waves, nodes, prefix, totals, invs);
+    unsigned fgrid = (unsigned)((items_bound + 63) / 64);
+    if (fgrid > grid_cap) fgrid = grid_cap;
+    if (!fgrid) fgrid = 1;
+    G1X *bk = (G1X *)bucket, *po = (G1X *)pout;
+    const u32 rpp = rp_partials & 1u;
+    switch (rounds) {
+    case 1: hipLaunchKernelGGL(k_ba_finish<1>, dim3(fgrid), dim3(64), 0, st, pts, sorted, tab, item_start, nkeys, (const uint4 *)nodes, bk, po, rpp); break;
+    case 2: hipLaunchKernelGGL(k_ba_finish<2>, dim3(fgrid), dim3(64), 0, st, pts, sorted, tab, item_start, nkeys, (const uint4 *)nodes, bk, po, rpp); break;
+    case 3: hipLaunchKernelGGL(k_ba_finish<3>, dim3(fgrid), dim3(64), 0, st, pts, sorted, tab, item_start, nkeys, (const uint4 *)nodes, bk, po, rpp); break;
+    default: hipLaunchKernelGGL(k_ba_finish<4>, dim3(fgrid), dim3(64), 0, st, pts, sorted, tab, item_start, nkeys, (const uint4 *)nodes, bk, po, rpp); break;
+    }
+}
 __global__ void k_g1_to_rprime(G1Aff *dst, const G1Aff *src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -90,6 +128,6 @@ static void launch_to_rprime(hipStream_t st, void *dst, const void *src, size_t 
 }
 
 const MsmCurveOps &msm_g1_ops() {
-    static const MsmCurveOps ops = {sizeof(G1X), launch_accum_affine<Fp>, launch_accum_xyzz<Fp>, launch_bucket_reduce<Fp>, SumT<Fp>::value, launch_sum_tree<Fp>, launch_precompute<Fp>, launch_precompute_batched<Fp>, sizeof(Fp), host_combine_windows<Fp>, launch_sum_slices<Fp>, launch_accum_affine29, launch_accum_xyzz29, launch_to_rprime};
+    static const MsmCurveOps ops = {sizeof(G1X), launch_accum_affine<Fp>, launch_accum_xyzz<Fp>, launch_bucket_reduce<Fp>, SumT<Fp>::value, launch_sum_tree<Fp>, launch_precompute<Fp>, launch_precompute_batched<Fp>, sizeof(Fp), host_combine_windows<Fp>, launch_sum_slices<Fp>, launch_accum_affine29, launch_accum_xyzz29, launch_accum_affine_ba, launch_to_rprime};
     return ops;
 }

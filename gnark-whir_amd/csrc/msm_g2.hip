@@ -126,6 +126,6 @@ static void launch_g2_to_rprime(hipStream_t st, void *dst, const void *src, size
 }
 
 const MsmCurveOps &msm_g2_ops() {
-    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, launch_precompute_batched<Fp2>, sizeof(Fp2), host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, nullptr, launch_g2_to_rprime};
+    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, launch_precompute_batched<Fp2>, sizeof(Fp2), host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, nullptr, nullptr, launch_g2_to_rprime};
     return ops;
 }

@@ -405,6 +405,11 @@ int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on);
  * (leaves registers for other kernels' waves on the same SIMD: +1.7 % proofs/s with three proofs in flight at N = 2^23, slower when
  * one proof fills the GPU).  Same results. */
 int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves);
+/* EXPERIMENT, default 0 (off).  rounds = 1..4: the G1 level-1 accumulation by batch-affine rounds (affine additions, one shared inversion
+ * per 64 * K additions; csrc/msm_ba_g1.cuh) wherever the buckets hold >= 32 entries on average and the scratch (768 B per item) fits.
+ * 32 % fewer multiplications per addition, the same results -- and half the speed on MI355X: every pass is bound by its random 64-byte
+ * reads at ~3 TB/s.  Kept for the measurement and the parity test. */
+int32_t mi_debug_set_msm_batch_affine(mi_ctx *ctx, uint32_t rounds);
 /* on = 1 (default): the fixed-base window tables of mi_pk_load / mi_msm_precompute_* convert to affine with one inversion per 16 points
  * (needs n XYZZ + n coordinates of scratch while building; falls back by itself without room); 0: one inversion per point.  Same tables. */
 int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);

@@ -494,3 +494,28 @@ def test_msm_exact_and_worst_case_level_counts_agree_with_oracle(ctx, n, dist):
             assert np.array_equal(ctx.msm_g2(p2, s2), want2), on
     finally:
         assert ctx.lib.mi_debug_set_msm_bound_levels(ctx.h, 0) == 0
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 3, 4])
+def test_batch_affine_level1_rounds_agree_with_oracle(ctx, rounds):
+    """the experimental batch-affine level 1 (mi_debug_set_msm_batch_affine, csrc/msm_ba_g1.cuh; off by default): buckets of many
+    entries (small windows) so that it engages, with repeated points (doublings: the slots that leave the batch), opposite pairs
+    (cancellation inside an item), points at infinity, ragged items; and every pair an equal-point addition (one point, one scalar)"""
+    lib = ctx.lib
+    n = 1 << 16
+    pts = cref.gen_g1(n, 188); sc = cref.gen_scalars(n, 189, 1)
+    pts[3] = 0; pts[6] = pts[5]; sc[6] = sc[5]; pts[8] = g1_arr([P.g1_neg(g1_pts(pts[7:8])[0])])[0]; sc[8] = sc[7]; pts[100:300] = pts[99]
+    pts[1000:1100] = 0
+    want = cref.msm_g1(pts, sc)
+    same = cref.gen_g1(n, 190); same[:] = same[0]
+    ssc = cref.gen_scalars(n, 191, 0); ssc[:] = ssc[0]
+    want_same = cref.msm_g1(same, ssc)
+    try:
+        assert lib.mi_debug_set_msm_batch_affine(ctx.h, rounds) == 0
+        for c in (8, 9):
+            assert lib.mi_debug_set_msm_plan(ctx.h, c, 0, 0, 0, 0) == 0
+            assert _jac_eq(ctx.msm_g1(pts, sc), want), (rounds, c)
+        assert lib.mi_debug_set_msm_plan(ctx.h, 5, 0, 0, 0, 0) == 0
+        assert _jac_eq(ctx.msm_g1(same, ssc), want_same), rounds
+    finally:
+        assert lib.mi_debug_set_msm_batch_affine(ctx.h, 0) == 0 and lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
