@@ -97,16 +97,6 @@ MI_HD void g1x29_madd(G1X29 &acc, const u32 *q, bool negate) {
 }
 
 // ---- partial sums in the packed R' form
-// exact normalisation (limbs 0..7 < 2^29) of a number whose limbs are < 2^31: one sequential carry pass, same value
-MI_HD F29 f29_norm(const F29 &x) {
-    constexpr u32 M = (1u << 29) - 1;
-    F29 z;
-    u32 carry = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { const u32 v = x.l[i] + carry; z.l[i] = v & M; carry = v >> 29; }
-    z.l[8] = x.l[8] + carry;
-    return z;
-}
 // acc -> 32 words X | Y | ZZ | ZZZ.  X (weak, < 5.7 p) is brought below 4p + 2^233 < 2^256 first; the others are products' results
 // (normalised, < 2 p).  Infinity = all zero, like XYZZ::inf().
 MI_HD void g1x29_store_rp(const G1X29 &a, u32 *w) {

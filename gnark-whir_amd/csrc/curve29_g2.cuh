@@ -1,6 +1,6 @@
 // G2 bucket accumulation in the 9 x 29-bit representation (field29.cuh): Fp2 = Fp[u]/(u^2 + 1) over lazy 29-bit-limb Fp, and the
 // XYZZ mixed addition with hand-tracked bounds.  Same group law and special cases as xyzz_madd (curve.cuh); replaces it inside
-// the G2 level-1 accumulate kernel only.
+// the G2 level-1 accumulate kernel, and (g2x29_add, at the end of this file) xyzz_add in the levels above it.
 //
 // An Fp2 product is two DUAL products (field29.cuh f29_mul2: two multiplications accumulated in the same 64-bit columns, one
 // Montgomery reduction): c0 = a0 b0 + a1 (K p - b1), c1 = a0 b1 + a1 b0 -- 486 multiplications, no Karatsuba additions; a
@@ -112,5 +112,53 @@ MI_HD void g2x29_madd(Acc &A, bool &inf, const u32 *q, bool negate) {
     const F2_29 D = f2_29_sub(Q, X3, P29<P_>::c4);
     const F2_29 M1 = f2_29_mul(R, D, P29<P_>::c8);
     const F2_29 M2 = f2_29_mul(Y, PPP, P29<P_>::c2);
+    A.st(1, f2_29_sub(M1, M2, P29<P_>::c2));
+}
+
+// ---- partial sums in the packed R' form (the G2 twin of g1x29_store_rp / g1x29_load_rp / g1x29_add in curve29.cuh)
+// An accumulator component -> 16 words (a0 | a1); every stored coordinate is below 3.6 p < 2^256 (bounds in the header).
+MI_HD void f2_29_pack(const F2_29 &x, u32 *w) { f29_pack(f29_norm(x.a0), w); f29_pack(f29_norm(x.a1), w + 8); }
+// Acc += b, b = 64 packed words X | Y | ZZ | ZZZ read through ldb(comp) (the caller decides where they live: global memory, read when
+// needed, so that only the operands of the current step occupy registers).  add-2008-s, same special cases as xyzz_add (curve.cuh).
+// Bounds: both operands X < 2.1, Y < 3.6, ZZ, ZZZ < 1.1 (what g2x29_madd and this function leave behind)
+//   U1 = Xa ZZb, U2 = Xb ZZa, S1 = Ya ZZZb, S2 = Yb ZZZa < 1.1      P = U2 + 2p - U1, R = S2 + 2p - S1 < 3.1
+//   PP = P^2 < 1.6 / 1.2     PPP = P PP < 1.1     Q = U1 PP < 1.1     T = PPP + 2Q < 3.3     X3 = R^2 + 4p - T < 5.6 -> below 2p: < 2.1
+//   D = Q + 4p - X3 < 5.1    M1 = R D < 1.4       M2 = S1 PPP < 1.1   Y3 = M1 + 2p - M2 < 3.4
+//   ZZ3 = (ZZa ZZb) PP < 1.1     ZZZ3 = (ZZZa ZZZb) PPP < 1.1
+template <class Acc, class LoadB>
+MI_HD void g2x29_add(Acc &A, bool &inf, const LoadB &ldb, bool b_inf) {
+    if (b_inf) return;
+    if (inf) {
+        A.st(0, ldb(0)); A.st(1, ldb(1)); A.st(2, ldb(2)); A.st(3, ldb(3));
+        inf = false;
+        return;
+    }
+    const F2_29 ZZb = ldb(2);
+    const F2_29 U1 = f2_29_mul(A.ld(0), ZZb, P29<P_>::c2);
+    const F2_29 Pp = f2_29_sub(f2_29_mul(ldb(0), A.ld(2), P29<P_>::c2), U1, P29<P_>::c2);
+    const F2_29 PP = f2_29_sqr(Pp);
+    if (f2_29_is_zero_mod_p(PP)) {   // equal x: doubling or cancellation -- rare: the standard arithmetic handles it
+        G2X sa{f2_29_to_std(A.ld(0)), f2_29_to_std(A.ld(1)), f2_29_to_std(A.ld(2)), f2_29_to_std(A.ld(3))};
+        const G2X sb{f2_29_to_std(ldb(0)), f2_29_to_std(ldb(1)), f2_29_to_std(ZZb), f2_29_to_std(ldb(3))};
+        xyzz_add(sa, sb);
+        inf = sa.is_inf();
+        if (!inf) { A.st(0, f2_29_from_std(sa.x)); A.st(1, f2_29_from_std(sa.y)); A.st(2, f2_29_from_std(sa.zz)); A.st(3, f2_29_from_std(sa.zzz)); }
+        return;
+    }
+    A.st(2, f2_29_mul(f2_29_mul(A.ld(2), ZZb, P29<P_>::c2), PP, P29<P_>::c2));
+    const F2_29 PPP = f2_29_mul(Pp, PP, P29<P_>::c2);
+    const F2_29 Q = f2_29_mul(U1, PP, P29<P_>::c2);
+    const F2_29 ZZZb = ldb(3);
+    const F2_29 S1 = f2_29_mul(A.ld(1), ZZZb, P29<P_>::c2);
+    const F2_29 R = f2_29_sub(f2_29_mul(ldb(1), A.ld(3), P29<P_>::c2), S1, P29<P_>::c2);
+    A.st(3, f2_29_mul(f2_29_mul(A.ld(3), ZZZb, P29<P_>::c2), PPP, P29<P_>::c2));
+    const F2_29 RR = f2_29_sqr(R);
+    const F2_29 T = f2_29_wnorm(f2_29_add(f2_29_add(PPP, Q), Q));
+    F2_29 X3 = f2_29_sub(RR, T, P29<P_>::c4);
+    X3.a0 = f29_below_2p(X3.a0); X3.a1 = f29_below_2p(X3.a1);
+    A.st(0, X3);
+    const F2_29 D = f2_29_sub(Q, X3, P29<P_>::c4);
+    const F2_29 M1 = f2_29_mul(R, D, P29<P_>::c8);
+    const F2_29 M2 = f2_29_mul(S1, PPP, P29<P_>::c2);
     A.st(1, f2_29_sub(M1, M2, P29<P_>::c2));
 }

@@ -195,6 +195,16 @@ MI_HD F29 f29_wnorm(const F29 &x) {
     z.l[8] = x.l[8] + (x.l[7] >> 29);
     return z;
 }
+// exact normalisation (limbs 0..7 < 2^29) of a number whose limbs are < 2^31: one sequential carry pass, same value
+MI_HD F29 f29_norm(const F29 &x) {
+    constexpr u32 M = (1u << 29) - 1;
+    F29 z;
+    u32 carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const u32 v = x.l[i] + carry; z.l[i] = v & M; carry = v >> 29; }
+    z.l[8] = x.l[8] + carry;
+    return z;
+}
 // if x >= K p (decided on the top limb: x_8 > (K p)_8, so surely x > K p): x -= K p.  kp = K p normalised.  Input weak; the result has
 // limbs < 2^30 (one f29_wnorm later) and is < K p + 2^232 + (what the top-limb test cannot see) -- "almost < K p".
 MI_HD F29 f29_condsub(const F29 &x, const u32 (&kp)[9]) {

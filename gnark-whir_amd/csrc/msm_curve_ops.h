@@ -25,14 +25,14 @@ struct MsmCurveOps {
     // own[i] += sum_p recv[p * own_len + i]  (XYZZ; bucket slices received from the other devices of a sharded MSM)
     void (*sum_slices)(hipStream_t st, void *own, const void *recv, uint32_t n_peers, uint32_t own_len);
     // Level-1 accumulation over points kept in the R' = 2^261 packed form (curve29.cuh: nine 29-bit limbs, lazy arithmetic);
-    // same arguments and results as accum_affine.  Null where no such kernel exists (G2).
+    // same arguments and results as accum_affine.
     void (*accum_affine_rp)(hipStream_t st, unsigned grid, const void *pts_rp, const uint32_t *sorted, const uint32_t *start, const uint32_t *cnt,
                             const uint32_t *items, const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out,
                             void *item_table /* 16 B per item of scratch */, uint32_t rp_partials /* bit 0; bit 1: the G1 kernel's two-wave build */,
                             hipEvent_t ev_before /* recorded on st between the item-table kernel and the accumulate kernel when non-null (stats) */);
     // Levels >= 2 over partial sums the level before left in the packed R' form (accum_affine_rp with rp_partials = 1, or this
     // kernel): same arguments as accum_xyzz; bucket sums leave in the standard form, partial sums in the R' form.  Null = the
-    // curve keeps its partial sums in the standard form (G2), and rp_partials must be 0.
+    // curve keeps its partial sums in the standard form, and rp_partials must be 0.  (G1: k_msm_accum_xyzz29, G2: k_msm_accum_xyzz_g2_29.)
     void (*accum_xyzz_rp)(hipStream_t st, unsigned grid, const void *partial_in, const uint32_t *start, const uint32_t *cnt, const uint32_t *items,
                           const uint32_t *item_start, uint32_t nkeys, uint32_t L, void *bucket, void *partial_out);
     // Level-1 accumulation by batch-affine rounds (msm_ba_g1.cuh): same inputs and outputs as accum_affine_rp for items of <= 16

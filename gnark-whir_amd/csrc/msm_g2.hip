@@ -85,8 +85,24 @@ struct LdsAccG2_29 {
         for (int i = 0; i < 9; i++) { base[(comp * 18 + i) * 64] = v.a0.l[i]; base[(comp * 18 + 9 + i) * 64] = v.a1.l[i]; }
     }
 };
+// an accumulator (or the point at infinity) -> 64 packed words in the R' form (curve29_g2.cuh); infinity = all zero
+static __device__ __forceinline__ void g2x29_store_rp(const LdsAccG2_29 &A, bool inf, G2X *dst) {
+    uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+#pragma unroll
+    for (int comp = 0; comp < 4; comp++) {
+        u32 w[16];
+        if (inf) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) w[i] = 0;
+        } else {
+            f2_29_pack(A.ld(comp), w);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) d4[4 * comp + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+    }
+}
 __global__ void __launch_bounds__(64, 2) k_msm_accum_affine_g2_29(const G2Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
-                                                                  G2X *bucket, G2X *partial_out) {
+                                                                  G2X *bucket, G2X *partial_out, u32 rp_partials) {
     __shared__ u32 lds[72 * 64];
     const LdsAccG2_29 A{&lds[threadIdx.x]};
     const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
@@ -102,18 +118,51 @@ __global__ void __launch_bounds__(64, 2) k_msm_accum_affine_g2_29(const G2Aff *p
             for (int j = 0; j < 8; j++) { const uint4 t = q4[j]; w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w; }
             g2x29_madd(A, inf, w, (v >> 31) != 0);
         }
+        // a bucket's only item leaves in the standard form (what the bucket reduce reads); a partial sum stays in the R' form for the
+        // next level (k_msm_accum_xyzz_g2_29): a pack instead of eight conversion products
+        if (!rec.w && rp_partials) { g2x29_store_rp(A, inf, partial_out + item); continue; }
         G2X out = G2X::inf();
         if (!inf) out = G2X{f2_29_to_std(A.ld(0)), f2_29_to_std(A.ld(1)), f2_29_to_std(A.ld(2)), f2_29_to_std(A.ld(3))};
         if (rec.w) bucket[key] = out; else partial_out[item] = out;
     }
 }
+// Levels >= 2 of the item machinery over partial sums in the packed R' form: k_msm_accum_xyzz's decomposition, the additions in nine
+// 29-bit limbs (g2x29_add) with the running sum in the same LDS image as level 1, the operand's coordinates read from global memory as
+// each is needed; a bucket's final sum converted to the standard form once.
+__global__ void __launch_bounds__(64, 2) k_msm_accum_xyzz_g2_29(const G2X *partial_in, const u32 *start, const u32 *cnt, const u32 *items, const u32 *item_start,
+                                                                u32 nkeys, G2X *bucket, G2X *partial_out) {
+    __shared__ u32 lds[72 * 64];
+    const LdsAccG2_29 A{&lds[threadIdx.x]};
+    const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
+    for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
+        const u32 key = msm_item_key(item_start, nkeys, item);
+        u32 b, e;
+        msm_item_range(start[key], cnt[key], items[key], item - item_start[key], b, e);
+        bool inf = true;
+        for (u32 k = b; k < e; k++) {
+            const u32 *bw = reinterpret_cast<const u32 *>(partial_in + k);
+            u32 any = 0;
+#pragma unroll
+            for (int i = 32; i < 48; i++) any |= bw[i];   // ZZ = 0 exactly: only the stored infinity
+            g2x29_add(A, inf, [bw](int comp) { return f2_29_unpack(bw + 16 * comp); }, any == 0);
+        }
+        if (items[key] != 1) { g2x29_store_rp(A, inf, partial_out + item); continue; }
+        G2X out = G2X::inf();
+        if (!inf) out = G2X{f2_29_to_std(A.ld(0)), f2_29_to_std(A.ld(1)), f2_29_to_std(A.ld(2)), f2_29_to_std(A.ld(3))};
+        bucket[key] = out;
+    }
+}
+static void launch_accum_xyzz_g2_29(hipStream_t st, unsigned grid, const void *pin, const u32 *start, const u32 *cnt, const u32 *items, const u32 *item_start,
+                                    u32 nkeys, u32 L, void *bucket, void *pout) {
+    hipLaunchKernelGGL(k_msm_accum_xyzz_g2_29, dim3(grid), dim3(64), 0, st, (const G2X *)pin, start, cnt, items, item_start, nkeys, (G2X *)bucket, (G2X *)pout);
+}
 static void launch_accum_affine_g2_29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
-                                      const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab, u32 /* rp_partials: G2 keeps the standard form */,
+                                      const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab, u32 rp_partials,
                                       hipEvent_t ev_before) {
     hipLaunchKernelGGL(k_msm_item_table<Fp2>, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
     if (ev_before) (void)hipEventRecord(ev_before, st);
     hipLaunchKernelGGL(k_msm_accum_affine_g2_29, dim3(grid), dim3(64), 0, st, (const G2Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
-                       (G2X *)bucket, (G2X *)pout);
+                       (G2X *)bucket, (G2X *)pout, rp_partials & 1u);
 }
 __global__ void k_g2_to_rprime(G2Aff *dst, const G2Aff *src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,6 +175,6 @@ static void launch_g2_to_rprime(hipStream_t st, void *dst, const void *src, size
 }
 
 const MsmCurveOps &msm_g2_ops() {
-    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, launch_precompute_batched<Fp2>, sizeof(Fp2), host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, nullptr, nullptr, launch_g2_to_rprime};
+    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, launch_precompute_batched<Fp2>, sizeof(Fp2), host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, launch_accum_xyzz_g2_29, nullptr, launch_g2_to_rprime};
     return ops;
 }

@@ -114,6 +114,51 @@ extern "C" int emu_g2_madd29_chain(void *out_aff, const void *pts_std, const uns
     *(G2Aff *)out_aff = xyzz_to_affine(s);
     return 0;
 }
+// the G2 twin of emu_g1_rp_levels: items of mixed additions, their sums packed (f2_29_pack) and added up with g2x29_add -- what
+// k_msm_accum_affine_g2_29 + k_msm_accum_xyzz_g2_29 do on the device
+extern "C" int emu_g2_rp_levels(void *out_aff, const void *pts_std, const unsigned char *neg, size_t n, size_t item_len) {
+    const G2Aff *p = (const G2Aff *)pts_std;
+    struct Slot { u32 w[64]; };
+    auto store = [](const RegAccG2_29 &A, bool inf) {
+        Slot s;
+        memset(&s, 0, sizeof(s));
+        if (!inf) for (int c = 0; c < 4; c++) f2_29_pack(A.ld(c), s.w + 16 * c);
+        return s;
+    };
+    auto is_inf = [](const Slot &s) { u32 any = 0; for (int i = 32; i < 48; i++) any |= s.w[i]; return any == 0; };
+    std::vector<Slot> partial;
+    for (size_t b = 0; b < n; b += item_len) {
+        RegAccG2_29 A{};
+        bool inf = true;
+        for (size_t i = b; i < n && i < b + item_len; i++) {
+            G2Aff rp{Fp2{fe_to_rprime_packed(p[i].x.a0), fe_to_rprime_packed(p[i].x.a1)}, Fp2{fe_to_rprime_packed(p[i].y.a0), fe_to_rprime_packed(p[i].y.a1)}};
+            u32 w[32];
+            memcpy(w, &rp, 128);
+            g2x29_madd(A, inf, w, neg[i] != 0);
+        }
+        partial.push_back(store(A, inf));
+    }
+    while (partial.size() > 1) {   // levels of up to three partial sums per item
+        std::vector<Slot> next;
+        for (size_t b = 0; b < partial.size(); b += 3) {
+            RegAccG2_29 A{};
+            bool inf = true;
+            for (size_t k = b; k < partial.size() && k < b + 3; k++) {
+                const u32 *bw = partial[k].w;
+                g2x29_add(A, inf, [bw](int comp) { return f2_29_unpack(bw + 16 * comp); }, is_inf(partial[k]));
+            }
+            next.push_back(store(A, inf));
+        }
+        partial.swap(next);
+    }
+    G2X s = G2X::inf();
+    if (!partial.empty() && !is_inf(partial[0])) {
+        const u32 *bw = partial[0].w;
+        s = G2X{f2_29_to_std(f2_29_unpack(bw)), f2_29_to_std(f2_29_unpack(bw + 16)), f2_29_to_std(f2_29_unpack(bw + 32)), f2_29_to_std(f2_29_unpack(bw + 48))};
+    }
+    *(G2Aff *)out_aff = xyzz_to_affine(s);
+    return 0;
+}
 // raw primitives of field29.cuh on limb vectors chosen by the test (9 x u32 each); field 1 = Fp, 0 = Fr
 extern "C" int emu_f29_prim(int field, int op, u32 *out, const u32 *a, const u32 *b, const u32 *c, const u32 *d) {
     F29 A, B, C, D, R;

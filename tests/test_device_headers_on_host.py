@@ -212,6 +212,37 @@ def test_limb29_partial_sums_in_rprime_form_match_oracle(emu):
     assert np.array_equal(run(zer, z4, 2), want(zer, z4))
 
 
+def test_limb29_g2_partial_sums_in_rprime_form_match_oracle(emu):
+    """curve29_g2.cuh f2_29_pack / g2x29_add (overflow traps on): items of G2 mixed additions whose sums stay packed in the R' form and
+    are added level by level (k_msm_accum_affine_g2_29 + k_msm_accum_xyzz_g2_29), against the oracle's group law -- including equal
+    partial sums (doubling), opposite ones (cancellation), infinite ones, items of one point"""
+    g = cref.gen_g2(120, 21)
+    def run(pts, neg, item_len):
+        out = np.zeros(16, np.uint64)
+        pts = np.ascontiguousarray(pts); neg = np.ascontiguousarray(neg, dtype=np.uint8)
+        emu.emu_g2_rp_levels(_p(out), _p(pts), neg.ctypes.data_as(C.c_char_p), C.c_size_t(pts.shape[0]), C.c_size_t(item_len))
+        return out
+    def want(pts, neg):
+        acc = None
+        for p_, n_ in zip(g2_pts(pts), neg):
+            q = P.g2_neg(p_) if (n_ and p_ is not None) else p_
+            acc = q if acc is None else P.g2_add(acc, q)
+        return g2_arr([acc])[0]
+    rng = np.random.default_rng(14)
+    for n, L in ((1, 1), (2, 1), (7, 2), (64, 4), (120, 16), (60, 1), (100, 7)):
+        neg = rng.integers(0, 2, n)
+        assert np.array_equal(run(g[:n], neg, L), want(g[:n], neg)), (n, L)
+    z4 = np.zeros(4, np.uint8)
+    same = np.stack([g[0], g[1], g[0], g[1]])                      # two equal partial sums: doubling through the slow path
+    assert np.array_equal(run(same, z4, 2), want(same, z4))
+    opp = np.stack([g[0], g[1], g[0], g[1]]); ng = np.array([0, 0, 1, 1], np.uint8)   # opposite partial sums: infinity
+    assert not run(opp, ng, 2).any()
+    infs = np.stack([g[2], g[2], g[3], g[4]]); ni = np.array([0, 1, 0, 0], np.uint8)  # first item sums to infinity
+    assert np.array_equal(run(infs, ni, 2), want(infs, ni))
+    zer = np.stack([np.zeros(16, np.uint64), np.zeros(16, np.uint64), g[5], g[6]])    # an item of infinity entries only
+    assert np.array_equal(run(zer, z4, 2), want(zer, z4))
+
+
 def test_limb29_g2_mixed_addition_chain_matches_oracle(emu):
     """curve29_g2.cuh on the host (overflow traps on): Fp2 over 29-bit limbs, dual products, the conditional -4p / -2p of X3; chains
     with sign flips, doubling, cancellation, infinity entries"""
