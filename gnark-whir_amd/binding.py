@@ -27,8 +27,8 @@ EXPORTS = [
     "mi_debug_set_prove_fixed_base", "mi_debug_set_prove_schedule", "mi_debug_set_msm_batch_affine", "mi_debug_set_msm_group_bits", "mi_debug_inject_hip_failure", "mi_debug_set_ntt_plan", "mi_debug_set_ntt_threads", "mi_debug_set_ntt_wave_stages",
     "mi_debug_set_msm_plan", "mi_debug_set_msm_chunk", "mi_debug_set_msm_one_pass_sort", "mi_debug_set_msm_bound_levels", "mi_debug_set_msm_limb29", "mi_debug_set_msm_l1_waves", "mi_debug_set_msm_precompute_batched", "mi_debug_set_ntt_fuse_pair",
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
-    "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait",
-    "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
+    "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22",
+    "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_create_rank_ex", "mi_group_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
     "mi_group_last_error", "mi_group_transport", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
     "mi_groth16_prove_sharded", "mi_groth16_prove_sharded_dev", "mi_pk_load_sharded_dev", "mi_msm_g1_sharded", "mi_msm_g2_sharded",
     "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
@@ -66,6 +66,10 @@ def pk_raw_inspect(blob: bytes):
     if load().mi_pk_raw_inspect(buf, C.c_size_t(len(blob)), C.byref(info)) != 0:
         raise MiError("mi_pk_raw_inspect: not a gnark v0.11.0 ProvingKey.WriteRawTo stream (as recalled)")
     return info
+
+
+class Bsb22Input(C.Structure):
+    _fields_ = [("key", C.c_void_p), ("values", C.c_void_p), ("n", C.c_size_t)]
 
 
 class Stats(C.Structure):
@@ -228,7 +232,7 @@ class Context:
 
     def compute_h(self, log_n, a, b, c):
         h = np.zeros((1 << log_n, 4), np.uint64)
-        a, b, c = _u64(a), _u64(b), _u64(c)
+        a, b, c = _u64(a), _u64(b), (None if c is None else _u64(c))
         self._ck(self.lib.mi_compute_h(self.h, C.c_uint32(log_n), _p(a), _p(b), _p(c), C.c_size_t(a.shape[0]), _p(h)))
         return h
 
@@ -311,7 +315,7 @@ class Context:
             self._ck(self.lib.mi_groth16_prove_dev(self.h, pkh, _p(W), C.c_size_t(n_wires), _p(a), _p(b), _p(c),
                                                    C.c_size_t(n_constraints), _p(r), _p(s), _p(out), C.byref(st)))
         else:
-            W, a, b, c = _u64(W), _u64(a), _u64(b), _u64(c)
+            W, a, b, c = _u64(W), _u64(a), _u64(b), (None if c is None else _u64(c))   # c = None: formed on the device as a o b
             self._ck(self.lib.mi_groth16_prove(self.h, pkh, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c),
                                                C.c_size_t(a.shape[0]), _p(r), _p(s), _p(out), C.byref(st)))
         return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
@@ -381,7 +385,7 @@ class Prover:
             rc = self.lib.mi_prover_submit_dev(self.h, pkh, _p(W), C.c_size_t(n_wires), _p(a), _p(b), _p(c), C.c_size_t(n_constraints),
                                                _p(r), _p(s), _p(out), C.byref(st), C.byref(t))
         else:
-            W, a, b, c = _u64(W), _u64(a), _u64(b), _u64(c)
+            W, a, b, c = _u64(W), _u64(a), _u64(b), (None if c is None else _u64(c))   # c = None: formed on the device as a o b
             keep = (W, a, b, c)
             rc = self.lib.mi_prover_submit(self.h, pkh, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c), C.c_size_t(a.shape[0]),
                                            _p(r), _p(s), _p(out), C.byref(st), C.byref(t))
@@ -391,11 +395,39 @@ class Prover:
         return t.value
 
     def wait(self, ticket):
-        out, st, _ = self._pending.pop(ticket)
+        out, st, keep = self._pending.pop(ticket)
         rc = self.lib.mi_prover_wait(self.h, C.c_uint64(ticket))
         if rc != 0:
             raise MiError(f"rc={rc}: {self.lib.mi_prover_last_error(self.h).decode()}")
-        return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
+        res = {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}
+        if isinstance(keep, dict) and "pok" in keep:
+            res["pok"] = keep["pok"]
+        return res, st.as_dict()
+
+    # ---- BSB22 through the pool (mi_prover_commit / mi_prover_submit_bsb22)
+    def commit(self, ped_pk, values):
+        """pedersen Commit inside the solve: synchronous, thread-safe"""
+        values = _u64(values); out = np.zeros(8, np.uint64)
+        rc = self.lib.mi_prover_commit(self.h, ped_pk, _p(values), C.c_size_t(values.shape[0]), _p(out))
+        if rc != 0:
+            raise MiError(f"mi_prover_commit rc={rc}: {self.lib.mi_prover_last_error(self.h).decode()}")
+        return out
+
+    def submit_bsb22(self, pkh, W, a, b, c, r, s, commitments, challenge) -> int:
+        """host inputs; commitments = [(pedersen key handle, private committed values)]; wait() returns the proof with res['pok']"""
+        out = np.zeros(32, np.uint64); st = Stats(); t = C.c_uint64(); pok = np.zeros(8, np.uint64)
+        r, s, challenge = _u64(r), _u64(s), _u64(challenge)
+        W, a, b, c = _u64(W), _u64(a), _u64(b), (None if c is None else _u64(c))
+        vals = [_u64(v) for _, v in commitments]
+        arr = (Bsb22Input * len(commitments))()
+        for i, ((key, _), v) in enumerate(zip(commitments, vals)):
+            arr[i].key = key if isinstance(key, int) else key.value; arr[i].values = v.ctypes.data; arr[i].n = v.shape[0]
+        rc = self.lib.mi_prover_submit_bsb22(self.h, pkh, _p(W), C.c_size_t(W.shape[0]), _p(a), _p(b), _p(c), C.c_size_t(a.shape[0]),
+                                             _p(r), _p(s), arr, C.c_uint32(len(commitments)), _p(challenge), _p(out), _p(pok), C.byref(st), C.byref(t))
+        if rc != 0:
+            raise MiError(f"mi_prover_submit_bsb22: rc={rc}")
+        self._pending[t.value] = (out, st, {"keep": (W, a, b, c, vals, arr, challenge), "pok": pok})
+        return t.value
 
     def close(self):
         if self.h:
@@ -452,11 +484,12 @@ class Group:
         return bytes(buf)
 
     @classmethod
-    def rank(cls, device_id, rank, world, uid: bytes):
+    def rank(cls, device_id, rank, world, uid: bytes, transport=1):
+        """transport 1 = RCCL (uid from unique_id()), 3 = host-staged through shared memory (uid = any 128 bytes the ranks share)"""
         h = C.c_void_p(); buf = (C.c_uint8 * 128)(*uid)
-        rc = load().mi_group_create_rank(C.c_int(device_id), C.c_int(rank), C.c_int(world), buf, C.byref(h))
+        rc = load().mi_group_create_rank_ex(C.c_int(device_id), C.c_int(rank), C.c_int(world), buf, C.c_int(transport), C.byref(h))
         if rc != 0:
-            raise MiError(f"mi_group_create_rank failed: {rc}")
+            raise MiError(f"mi_group_create_rank_ex failed: {rc}")
         return cls(_h=h)
 
     def _ck(self, rc):
@@ -470,7 +503,10 @@ class Group:
         return Context(_borrowed=p)
 
     def transport(self):
-        return {1: "rccl", 2: "peer-copy"}[int(self.lib.mi_group_transport(self.h))]
+        return {1: "rccl", 2: "peer-copy", 3: "host-staged"}[int(self.lib.mi_group_transport(self.h))]
+
+    def rank_index(self):
+        return int(self.lib.mi_group_rank(self.h))
 
     def exchange_selftest(self, nbytes=4096):
         self._ck(self.lib.mi_group_exchange_selftest(self.h, C.c_size_t(nbytes)))

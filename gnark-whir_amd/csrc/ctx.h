@@ -116,7 +116,8 @@ int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t 
 int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                               size_t n_constraints, mi_fr *h_out);
 // computeH one input vector at a time (ntt.hip): part 0 = a, 1 = b, 2 = c (src = that vector), 3 = the rest (src unused)
-int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *src, size_t n_constraints, mi_fr *h_out);
+// part 2 with src2 != null: c is not given; it is formed as src o src2 (the original a and b) on the way into its transform
+int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *src, size_t n_constraints, mi_fr *h_out, const mi_fr *src2 = nullptr);
 void mi_ntt_state_init(mi_ctx *ctx);
 size_t mi_ntt_table_bytes(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);

@@ -10,37 +10,78 @@
 //                  slice of h device-to-device.
 //   exchange       EC addition is not an ncclRedOp, so the "all-reduce of partial bucket sums" is byte-typed:
 //                  mode 0 (SURVEY 8e option i)  every rank finishes its Pippenger locally and contributes ONE partial sum per
-//                         MSM (128 / 256 B XYZZ); combine = world point additions (single process: on the host, the window sums
-//                         land in pinned host memory anyway; one rank per process: ncclAllGather of the partials).
+//                         MSM (128 / 256 B XYZZ); combine = world point additions (the partials of all five MSMs travel in ONE
+//                         all-gather together with every rank's status).
 //                  mode 1 (option ii, the north_star's wording)  every rank stops at its BUCKET sums; rank r owns the keys
 //                         [r K / world, (r+1) K / world) and receives that slice from every other rank -- a reduce-scatter written
 //                         as grouped ncclSend / ncclRecv, one hop on the full xGMI mesh, all 7 links at once -- adds the slices
 //                         (k_msm_sum_slices), runs the bucket reduce on its slice only, and the per-rank results are combined as
 //                         in mode 0 (Horner over the windows is linear, so combining after it is the same sum).
-//   transport      RCCL (ncclCommInitAll in one process, ncclCommInitRank for one rank per process).  A group that names the
-//                  same device twice (the 1-GPU rehearsal the tests run) cannot have an RCCL communicator and moves the same
-//                  slices with hipMemcpyPeerAsync instead.
+//   transport      1  RCCL (ncclCommInitAll in one process, ncclCommInitRank for one rank per process).
+//                  2  same-process copies (hipMemcpyPeerAsync / device-to-device): a single-process group that names a device twice
+//                     (the 1-GPU rehearsal of the tests) cannot have an RCCL communicator.
+//                  3  host-staged: one rank per process, the processes meet in a POSIX shared-memory segment named after the group
+//                     id; slices travel device -> segment -> device through per-(source, destination) chunk rings, small values
+//                     (status words, partial sums) through an all-gather area.  For ranks that cannot have an RCCL communicator
+//                     between them -- two processes on ONE device (how a 1-GPU box rehearses the one-rank-per-process flow: RCCL
+//                     refuses two ranks per device, the bookkeeping does not care) or a box without a working RCCL fabric.  Every
+//                     wait has a deadline (MI_GROUP_TIMEOUT_MS, default 60 s): a peer that died is an error, not a hang.
+//   failures       with one rank per process every entry point is a collective, and a rank that returned early from a local failure
+//                  would leave its peers waiting in the next exchange.  So every phase that can fail locally (argument checks,
+//                  workspaces, uploads, enqueues) is followed by an AGREEMENT -- an all-gather of the ranks' status words -- before
+//                  the next exchange starts, and the last all-gather (the partial sums) carries the status too: either every rank
+//                  enters an exchange or every rank returns an error (its own, or "another rank failed") and its MSM slots are drained.
 #include "prove_internal.h"
 #include "msm_curve_ops.h"
 #include <rccl/rccl.h>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <future>
 #include <thread>
 #include <vector>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+// ---------------------------------------------------------------- transport 3: the shared-memory segment
+static constexpr uint32_t SHM_MAGIC = 0x6d693335u, SHM_MAX_WORLD = 64, SHM_AG_MAX = 1024;
+struct alignas(64) ShmRing { std::atomic<uint64_t> head; char pad0[56]; std::atomic<uint64_t> tail; char pad1[56]; };   // chunks produced (by the source) / consumed (by the destination)
+struct alignas(64) ShmAg { std::atomic<uint64_t> seq; char pad[56]; unsigned char data[2][SHM_AG_MAX]; };              // collective k writes data[k & 1], then seq = k
+struct ShmHeader {
+    std::atomic<uint32_t> magic;      // set by rank 0 when the header is initialised
+    uint32_t world, nslot;
+    uint64_t chunk;                   // bytes per ring slot
+    std::atomic<uint32_t> attached;   // ranks that have mapped the segment
+    std::atomic<uint32_t> poisoned;   // a rank hit a transport error: everyone waiting gives up at once
+    ShmAg ag[SHM_MAX_WORLD];
+    ShmRing ring[SHM_MAX_WORLD * SHM_MAX_WORLD];   // ring[src * world + dst]
+};
+struct ShmLink {
+    ShmHeader *h = nullptr;
+    unsigned char *data = nullptr;    // ring r, slot k: data + ((size_t)r * nslot + k) * chunk
+    size_t map_bytes = 0;
+    uint64_t ag_seq = 0;              // collectives of the all-gather area this rank has entered (all ranks in lockstep)
+    int timeout_ms = 60000;
+    bool registered = false;          // the data area is pinned for the device (hipHostRegister)
+};
 
 struct mi_group {
     int world = 0;                 // ranks in the group
     int rank0 = 0;                 // global rank of the first local context
+    int transport = 0;             // 1 = RCCL, 2 = same-process copies, 3 = host-staged (shared memory)
     std::vector<int> dev;          // device of every LOCAL rank
     std::vector<mi_ctx *> ctx;     // one context per local rank
-    std::vector<ncclComm_t> comm;  // RCCL communicator per local rank; empty = peer copies inside this process
+    std::vector<ncclComm_t> comm;  // transport 1: RCCL communicator per local rank
+    ShmLink shm;                   // transport 3
     std::vector<hipStream_t> xs;   // per local rank: the exchange stream (sends, receives, slice sums)
     std::vector<hipEvent_t> ev_x, ev_in, ev_done, ev_h;
     std::vector<DevBuf> recv;      // per local rank: bucket slices received from the other ranks
-    std::vector<DevBuf> stage;     // per local rank: small staging area for the partial-sum all-gather
+    std::vector<DevBuf> stage;     // per local rank: small staging area for the all-gathers (transport 1)
     std::string err;
+    bool broken = false;           // a transport call failed half-way: rings / communicator are in an unknown state, every later call is refused
     std::atomic<bool> busy{false};   // calls on one group must not overlap: an entry point that finds it set returns MI_EINVAL (GroupCall)
     int n_local() const { return (int)ctx.size(); }
     bool local(int r) const { return r >= rank0 && r < rank0 + n_local(); }
@@ -53,7 +94,7 @@ struct mi_pk_sharded {
 };
 
 #define G_FAIL(g, code, msg) do { (g)->err = (msg); return (code); } while (0)
-#define G_HIP(g, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e__); \
+#define G_HIP(g, call) do { hipError_t e__ = mi_fault_hit() ? hipErrorUnknown : (call); if (e__ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e__); \
                             return e__ == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP; } } while (0)
 #define G_NCCL(g, call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { (g)->err = std::string(#call) + ": " + ncclGetErrorString(r__); \
                              return MI_EHIP; } } while (0)
@@ -66,15 +107,195 @@ struct GroupCall {
     explicit GroupCall(mi_group *g_) : g(g_), ok(g_ && !g_->busy.exchange(true, std::memory_order_acquire)) {}
     ~GroupCall() { if (ok) g->busy.store(false, std::memory_order_release); }
 };
-#define G_ENTER(g) GroupCall call__(g); if (!call__.ok) return MI_EINVAL
+#define G_ENTER(g) GroupCall call__(g); if (!call__.ok) return MI_EINVAL; \
+                   if ((g)->broken) G_FAIL(g, MI_EHIP, "group: an earlier exchange failed half-way; destroy the group and create a new one")
 
 static void range_of(u64 total, int world, int r, u64 &lo, u64 &hi) { lo = total * (u64)r / (u64)world; hi = total * (u64)(r + 1) / (u64)world; }
 
+// ---------------------------------------------------------------- transport 3: shared-memory link
+static std::string shm_name_of(const uint8_t id[128]) {
+    uint64_t h = 1469598103934665603ull;   // FNV-1a over the 128 id bytes
+    for (int i = 0; i < 128; i++) { h ^= id[i]; h *= 1099511628211ull; }
+    char buf[64];
+    snprintf(buf, sizeof buf, "/mi355x_grp_%016llx", (unsigned long long)h);
+    return buf;
+}
+struct Deadline {
+    std::chrono::steady_clock::time_point t;
+    explicit Deadline(int ms) : t(std::chrono::steady_clock::now() + std::chrono::milliseconds(ms)) {}
+    bool passed() const { return std::chrono::steady_clock::now() > t; }
+};
+static void shm_pause(unsigned &spins) {
+    if (++spins < 200) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+}
+// Rank 0 creates and initialises the segment, the others map it as soon as it shows its magic; once every rank is attached rank 0
+// unlinks the name, so that nothing outlives the processes whatever way they end.
+static int32_t shm_attach(mi_group *g, const uint8_t id[128]) {
+    ShmLink &L = g->shm;
+    if (const char *e = getenv("MI_GROUP_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) L.timeout_ms = v; }
+    uint64_t chunk = (uint64_t)1 << 20;
+    uint32_t nslot = 4;
+    if (const char *e = getenv("MI_GROUP_SHM_CHUNK_KB")) { const long v = atol(e); if (v >= 4 && v <= (1 << 16)) chunk = (uint64_t)v << 10; }
+    const int W = g->world, rank = g->rank0;
+    if (W > (int)SHM_MAX_WORLD) G_FAIL(g, MI_EINVAL, "group: the host-staged transport serves at most 64 ranks");
+    const size_t hdr = (sizeof(ShmHeader) + 4095) & ~(size_t)4095;
+    const std::string name = shm_name_of(id);
+    const Deadline dl(L.timeout_ms);
+    int fd = -1;
+    if (rank == 0) {
+        (void)shm_unlink(name.c_str());   // a leftover of a run that died before everyone had attached
+        fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) G_FAIL(g, MI_EHIP, "group: shm_open (create) failed");
+        L.map_bytes = hdr + (size_t)W * W * nslot * chunk;   // tmpfs allocates a page when it is first touched: rings nobody uses cost nothing
+        if (ftruncate(fd, (off_t)L.map_bytes) != 0) { close(fd); (void)shm_unlink(name.c_str()); G_FAIL(g, MI_ENOMEM, "group: ftruncate of the shared segment failed"); }
+    } else {
+        unsigned spins = 0;
+        for (;;) {
+            fd = shm_open(name.c_str(), O_RDWR, 0600);
+            if (fd >= 0) {
+                struct stat sb;
+                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= hdr) { L.map_bytes = (size_t)sb.st_size; break; }   // sized: rank 0 is past ftruncate
+                close(fd); fd = -1;
+            }
+            if (dl.passed()) G_FAIL(g, MI_EHIP, "group: rank 0 never created the shared segment (timeout)");
+            shm_pause(spins);
+        }
+    }
+    void *m = mmap(nullptr, L.map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { if (rank == 0) (void)shm_unlink(name.c_str()); G_FAIL(g, MI_ENOMEM, "group: mmap of the shared segment failed"); }
+    L.h = (ShmHeader *)m;
+    L.data = (unsigned char *)m + hdr;
+    if (rank == 0) {   // (a fresh tmpfs file reads as zeros: rings, sequence numbers and flags start at 0)
+        L.h->world = (uint32_t)W; L.h->nslot = nslot; L.h->chunk = chunk;
+        L.h->magic.store(SHM_MAGIC, std::memory_order_release);
+    } else {
+        unsigned spins = 0;
+        while (L.h->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+            if (dl.passed()) G_FAIL(g, MI_EHIP, "group: the shared segment was never initialised (timeout)");
+            shm_pause(spins);
+        }
+        if ((int)L.h->world != W || hdr + (size_t)W * W * L.h->nslot * L.h->chunk > L.map_bytes) G_FAIL(g, MI_EINVAL, "group: the shared segment belongs to a group of another shape");
+    }
+    L.h->attached.fetch_add(1, std::memory_order_acq_rel);
+    unsigned spins = 0;
+    while ((int)L.h->attached.load(std::memory_order_acquire) < W) {
+        if (dl.passed()) { if (rank == 0) (void)shm_unlink(name.c_str()); G_FAIL(g, MI_EHIP, "group: not every rank attached to the shared segment (timeout)"); }
+        shm_pause(spins);
+    }
+    if (rank == 0) (void)shm_unlink(name.c_str());
+    // the rings as pinned memory: copies to and from them run at the bus rate and do not stage a second time (best effort)
+    if (hipHostRegister(L.data, L.map_bytes - hdr, hipHostRegisterDefault) == hipSuccess) L.registered = true;
+    else (void)hipGetLastError();
+    return MI_OK;
+}
+static void shm_detach(mi_group *g) {
+    ShmLink &L = g->shm;
+    if (!L.h) return;
+    if (L.registered) (void)hipHostUnregister(L.data);
+    (void)munmap((void *)L.h, L.map_bytes);
+    L.h = nullptr; L.data = nullptr;
+}
+static int32_t shm_fail(mi_group *g, const char *msg) {
+    g->shm.h->poisoned.store(1, std::memory_order_release);
+    g->broken = true;
+    G_FAIL(g, MI_EHIP, msg);
+}
+// all-gather of `bytes` (<= SHM_AG_MAX) per rank through the segment's all-gather area
+static int32_t shm_allgather(mi_group *g, const void *local, size_t bytes, void *all) {
+    ShmLink &L = g->shm;
+    if (bytes > SHM_AG_MAX) G_FAIL(g, MI_EINVAL, "group: all-gather payload too large");
+    const uint64_t k = ++L.ag_seq;
+    ShmAg &mine = L.h->ag[g->rank0];
+    std::memcpy(mine.data[k & 1], local, bytes);
+    mine.seq.store(k, std::memory_order_release);
+    const Deadline dl(L.timeout_ms);
+    for (int r = 0; r < g->world; r++) {
+        unsigned spins = 0;
+        // (a rank may be one collective ahead -- it then wrote the OTHER buffer -- never two: collective k + 1 completes only once
+        //  every rank has entered it, i.e. has finished reading k)
+        while (L.h->ag[r].seq.load(std::memory_order_acquire) < k) {
+            if (L.h->poisoned.load(std::memory_order_acquire)) { g->broken = true; G_FAIL(g, MI_EHIP, "group: another rank reported a transport failure"); }
+            if (dl.passed()) return shm_fail(g, "group: a rank did not reach the all-gather (timeout; did its process end?)");
+            shm_pause(spins);
+        }
+        std::memcpy((char *)all + (size_t)r * bytes, L.h->ag[r].data[k & 1], bytes);
+    }
+    return MI_OK;
+}
+
 // ---------------------------------------------------------------- point-to-point batches
 struct Xfer { int src, dst; const void *sp; void *dp; size_t bytes; };   // global ranks; a pointer is meaningful in its owner's process only
+// transport 3: every transfer this process takes part in advances chunk by chunk through ring[src][dst] -- the source copies a chunk
+// device -> slot and publishes it (head), the destination copies slot -> device and releases it (tail).  A process both sends and
+// receives in one batch and the rings are finite, so the two directions are interleaved in ONE progress loop (two ranks that each
+// first sent everything would wait for each other's free slots forever).  Transfers of one (src, dst) pair complete in list order
+// (the ring is a FIFO and both sides build the same list).
+static int32_t run_xfers_shm(mi_group *g, const std::vector<Xfer> &list, const std::vector<hipStream_t> &xs) {
+    ShmLink &L = g->shm;
+    const int W = g->world, me = g->rank0;
+    const size_t chunk = (size_t)L.h->chunk;
+    const uint32_t nslot = L.h->nslot;
+    (void)hipSetDevice(g->dev[0]);
+    G_HIP(g, hipStreamSynchronize(xs[0]));   // what this rank sends is complete; what it receives into is no longer read
+    struct St { size_t sent = 0, rcvd = 0; };
+    std::vector<St> st(list.size());
+    // per pair: index of the first transfer of the list that is not finished on this side
+    const Deadline dl(L.timeout_ms);
+    unsigned spins = 0;
+    for (;;) {
+        bool all_done = true, progress = false;
+        std::vector<char> pair_send_busy((size_t)W * W, 0), pair_recv_busy((size_t)W * W, 0);
+        for (size_t k = 0; k < list.size(); k++) {
+            const Xfer &x = list[k];
+            if (!x.bytes) continue;
+            const size_t pr = (size_t)x.src * W + x.dst;
+            ShmRing &ring = L.h->ring[pr];
+            unsigned char *slots = L.data + pr * nslot * chunk;
+            if (x.src == me && st[k].sent < x.bytes) {
+                all_done = false;
+                if (!pair_send_busy[pr]) {
+                    pair_send_busy[pr] = 1;   // later transfers of this pair wait for this one
+                    uint64_t head = ring.head.load(std::memory_order_relaxed);
+                    while (st[k].sent < x.bytes && head - ring.tail.load(std::memory_order_acquire) < nslot) {
+                        const size_t nb = x.bytes - st[k].sent < chunk ? x.bytes - st[k].sent : chunk;
+                        G_HIP(g, hipMemcpyAsync(slots + (head % nslot) * chunk, (const char *)x.sp + st[k].sent, nb, hipMemcpyDeviceToHost, xs[0]));
+                        G_HIP(g, hipStreamSynchronize(xs[0]));
+                        st[k].sent += nb;
+                        ring.head.store(++head, std::memory_order_release);
+                        progress = true;
+                    }
+                }
+            }
+            if (x.dst == me && st[k].rcvd < x.bytes) {
+                all_done = false;
+                if (!pair_recv_busy[pr]) {
+                    pair_recv_busy[pr] = 1;
+                    uint64_t tail = ring.tail.load(std::memory_order_relaxed);
+                    while (st[k].rcvd < x.bytes && tail < ring.head.load(std::memory_order_acquire)) {
+                        const size_t nb = x.bytes - st[k].rcvd < chunk ? x.bytes - st[k].rcvd : chunk;
+                        G_HIP(g, hipMemcpyAsync((char *)x.dp + st[k].rcvd, slots + (tail % nslot) * chunk, nb, hipMemcpyHostToDevice, xs[0]));
+                        G_HIP(g, hipStreamSynchronize(xs[0]));
+                        st[k].rcvd += nb;
+                        ring.tail.store(++tail, std::memory_order_release);
+                        progress = true;
+                    }
+                }
+            }
+        }
+        if (all_done) return MI_OK;
+        if (progress) { spins = 0; continue; }
+        if (L.h->poisoned.load(std::memory_order_acquire)) { g->broken = true; G_FAIL(g, MI_EHIP, "group: another rank reported a transport failure"); }
+        if (dl.passed()) return shm_fail(g, "group: a peer did not take part in the exchange (timeout; did its process end?)");
+        shm_pause(spins);
+    }
+}
 // Runs the batch on the exchange streams xs[local rank].  Afterwards xs[i] is ordered after every transfer rank i sends or receives.
-static int32_t run_xfers(mi_group *g, const std::vector<Xfer> &xs_list, const std::vector<hipStream_t> &xs) {
-    if (!g->comm.empty()) {
+// A failure inside a batch leaves the transport in an unknown state (some ranks may be waiting in it): the group is marked broken.
+static int32_t run_xfers_impl(mi_group *g, const std::vector<Xfer> &xs_list, const std::vector<hipStream_t> &xs) {
+    if (g->transport == 3) return run_xfers_shm(g, xs_list, xs);
+    if (g->transport == 1) {
         G_NCCL(g, ncclGroupStart());
         for (const Xfer &x : xs_list) {
             if (!x.bytes) continue;
@@ -107,6 +328,70 @@ static int32_t run_xfers(mi_group *g, const std::vector<Xfer> &xs_list, const st
     }
     return MI_OK;
 }
+static int32_t run_xfers(mi_group *g, const std::vector<Xfer> &xs_list, const std::vector<hipStream_t> &xs) {
+    const int32_t rc = run_xfers_impl(g, xs_list, xs);
+    if (rc != MI_OK && g->n_local() != g->world) {   // the peers may be inside the exchange this rank just left
+        g->broken = true;
+        if (g->transport == 3) g->shm.h->poisoned.store(1, std::memory_order_release);
+    }
+    return rc;
+}
+
+// ---------------------------------------------------------------- all-gather of small host values, agreement
+// local: n_local x bytes (this process's ranks, in order); all: world x bytes in rank order.  Single process: a copy.  One rank
+// per process: ncclAllGather(ncclUint8) through a staging area (transport 1) or the shared segment (transport 3).
+static int32_t group_allgather(mi_group *g, const void *local, size_t bytes, void *all) {
+    if (g->n_local() == g->world) { std::memcpy(all, local, bytes * (size_t)g->world); return MI_OK; }
+    if (g->n_local() != 1) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
+    int32_t rc;
+    if (g->transport == 3) rc = shm_allgather(g, local, bytes, all);
+    else if (g->transport != 1 || g->comm.size() != 1) G_FAIL(g, MI_EINVAL, "group: no transport between the processes of this group");
+    else rc = [&]() -> int32_t {
+        (void)hipSetDevice(g->dev[0]);
+        G_CTX(g, 0, mi_reserve(g->ctx[0], g->stage[0], bytes * (size_t)(g->world + 1)));
+        char *st = (char *)g->stage[0].p;
+        hipStream_t s = g->xs[0];
+        G_HIP(g, hipMemcpyAsync(st, local, bytes, hipMemcpyHostToDevice, s));
+        G_NCCL(g, ncclAllGather(st, st + bytes, bytes, ncclUint8, g->comm[0], s));
+        G_HIP(g, hipMemcpyAsync(all, st + bytes, bytes * (size_t)g->world, hipMemcpyDeviceToHost, s));
+        G_HIP(g, hipStreamSynchronize(s));
+        return MI_OK;
+    }();
+    if (rc != MI_OK) g->broken = true;   // some ranks may have got through, others not: nothing collective can follow
+    return rc;
+}
+// What every rank says before the group enters an exchange: its status and up to ten values all ranks must agree on.
+struct Agree { int32_t rc; uint32_t check_n; uint64_t check[10]; };
+// local_rc / local_err: the first failure among this process's ranks (MI_OK: none).  Every rank of the group returns MI_OK or every
+// rank returns an error: the failing rank its own, the others "another rank failed".  check[0..check_n): values that must be EQUAL on
+// all ranks (bucket layouts of an exchange).
+static int32_t group_agree(mi_group *g, int32_t local_rc, const std::string &local_err, const char *phase, const uint64_t *check = nullptr, uint32_t check_n = 0) {
+    std::vector<Agree> mine((size_t)g->n_local()), all((size_t)g->world);
+    for (auto &a : mine) {
+        std::memset(&a, 0, sizeof a);
+        a.rc = local_rc; a.check_n = check_n;
+        for (uint32_t k = 0; k < check_n && k < 10; k++) a.check[k] = check[k];
+    }
+    MI_TRY(group_allgather(g, mine.data(), sizeof(Agree), all.data()));
+    for (int r = 0; r < g->world; r++)
+        if (all[r].rc != MI_OK) {
+            if (local_rc != MI_OK) { g->err = local_err; return local_rc; }
+            g->err = std::string("group: rank ") + std::to_string(r) + " failed " + phase + " (status " + std::to_string(all[r].rc) + "); nothing was exchanged";
+            return all[r].rc;
+        }
+    for (int r = 1; r < g->world; r++)
+        if (all[r].check_n != all[0].check_n || std::memcmp(all[r].check, all[0].check, sizeof all[0].check) != 0)
+            G_FAIL(g, MI_EINVAL, std::string("group: the ranks disagree on the shape of the exchange ") + phase);
+    return MI_OK;
+}
+// Group-wide minimum and maximum of one 64-bit value per local rank (plans every rank must agree on: table budgets, window widths).
+static int32_t group_min_max(mi_group *g, const std::vector<u64> &local, u64 *mn, u64 *mx) {
+    std::vector<u64> all((size_t)g->world, 0);
+    MI_TRY(group_allgather(g, local.data(), 8, all.data()));
+    *mn = ~(u64)0; *mx = 0;
+    for (u64 v : all) { if (v < *mn) *mn = v; if (v > *mx) *mx = v; }
+    return MI_OK;
+}
 
 // ---------------------------------------------------------------- lifecycle
 static int32_t group_finish_init(mi_group *g) {
@@ -136,8 +421,9 @@ int32_t mi_group_destroy(mi_group *g) {
         for (auto *v : {&g->ev_x, &g->ev_in, &g->ev_done, &g->ev_h}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
         if (i < (int)g->recv.size() && g->recv[i].p) (void)hipFree(g->recv[i].p);
         if (i < (int)g->stage.size() && g->stage[i].p) (void)hipFree(g->stage[i].p);
-        if (g->ctx[i]) mi_shutdown(g->ctx[i]);
     }
+    shm_detach(g);
+    for (int i = 0; i < g->n_local(); i++) if (g->ctx[i]) { (void)hipSetDevice(g->dev[i]); mi_shutdown(g->ctx[i]); }
     delete g;
     return MI_OK;
 }
@@ -158,6 +444,7 @@ int32_t mi_group_create(const int *dev_ids, int n_dev, mi_group **out) {
         g->dev.push_back(dev_ids[i]); g->ctx.push_back(c);
     }
     int32_t rc = group_finish_init(g);
+    g->transport = distinct ? 1 : 2;
     if (rc == MI_OK && distinct) {
         // full-mesh xGMI: let every device map every other one (peer copies of the h slices; RCCL does its own set-up)
         for (int i = 0; i < n_dev; i++) for (int j = 0; j < n_dev; j++) if (i != j) {
@@ -183,37 +470,43 @@ int32_t mi_group_unique_id(uint8_t id[128]) {
     std::memcpy(id, &u, 128);
     return MI_OK;
 }
-int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t id[128], mi_group **out) {
-    if (!id || !out || world < 1 || rank < 0 || rank >= world) return MI_EINVAL;
+int32_t mi_group_create_rank_ex(int device_id, int rank, int world, const uint8_t id[128], int transport, mi_group **out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world || (transport != MI_GROUP_TRANSPORT_RCCL && transport != MI_GROUP_TRANSPORT_HOST)) return MI_EINVAL;
     *out = nullptr;
     mi_group *g = new (std::nothrow) mi_group();
     if (!g) return MI_ENOMEM;
-    g->world = world; g->rank0 = rank;
+    g->world = world; g->rank0 = rank; g->transport = transport;
     mi_ctx *c = nullptr;
     int32_t rc = mi_init(device_id, &c);
     if (rc != MI_OK) { delete g; return rc; }
     g->dev.push_back(device_id); g->ctx.push_back(c);
     rc = group_finish_init(g);
-    if (rc == MI_OK) {
+    if (rc == MI_OK && transport == MI_GROUP_TRANSPORT_RCCL) {
         ncclUniqueId u;
         std::memcpy(&u, id, 128);
         (void)hipSetDevice(device_id);
         g->comm.assign(1, nullptr);
         if (ncclCommInitRank(&g->comm[0], world, u, rank) != ncclSuccess) { g->comm.clear(); rc = MI_EHIP; }
     }
+    if (rc == MI_OK && transport == MI_GROUP_TRANSPORT_HOST) { (void)hipSetDevice(device_id); rc = shm_attach(g, id); }
     if (rc != MI_OK) { mi_group_destroy(g); return rc; }
     *out = g;
     return MI_OK;
 }
+int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t id[128], mi_group **out) {
+    return mi_group_create_rank_ex(device_id, rank, world, id, MI_GROUP_TRANSPORT_RCCL, out);
+}
 int32_t mi_group_world(const mi_group *g) { return g ? g->world : 0; }
+int32_t mi_group_rank(const mi_group *g) { return g ? g->rank0 : -1; }
 int32_t mi_group_local(const mi_group *g) { return g ? g->n_local() : 0; }
 mi_ctx *mi_group_ctx(mi_group *g, int local_rank) { return g && local_rank >= 0 && local_rank < g->n_local() ? g->ctx[local_rank] : nullptr; }
 const char *mi_group_last_error(mi_group *g) { return g ? g->err.c_str() : "null group"; }
-// 1 = RCCL communicator, 2 = peer copies inside this process (a device named twice)
-int32_t mi_group_transport(const mi_group *g) { return !g ? 0 : (g->comm.empty() ? 2 : 1); }
+// 1 = RCCL communicator, 2 = copies inside this process (a device named twice), 3 = host-staged through shared memory
+int32_t mi_group_transport(const mi_group *g) { return !g ? 0 : g->transport; }
 
 // Every local rank sends a distinct pattern of `bytes` bytes to every rank of the group (itself included) and checks what it
-// received: the transport (RCCL grouped send / recv, or peer copies) in isolation.  All ranks of the group call it together.
+// received: the transport (RCCL grouped send / recv, peer copies, or the shared-memory rings) in isolation, then the all-gather of
+// host values the agreements and the partial-sum combine use.  All ranks of the group call it together.
 int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes) {
     if (!g || !bytes || bytes > ((size_t)1 << 28)) return MI_EINVAL;
     G_ENTER(g);
@@ -223,7 +516,7 @@ int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes) {
     std::vector<Xfer> list;
     auto pat = [](int src, int dst, size_t k) { return (unsigned char)(17 * src + 101 * dst + 3 * k + (k >> 8)); };
     int32_t rc = MI_OK;
-    auto body = [&]() -> int32_t {
+    auto prepare = [&]() -> int32_t {
         for (int i = 0; i < nl; i++) {
             (void)hipSetDevice(g->dev[i]);
             G_HIP(g, hipMalloc(&sbuf[i], bytes * W)); G_HIP(g, hipMalloc(&rbuf[i], bytes * W));
@@ -234,13 +527,9 @@ int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes) {
             G_HIP(g, hipMemsetAsync(rbuf[i], 0, bytes * W, xs[i]));
             G_HIP(g, hipStreamSynchronize(xs[i]));
         }
-        for (int s = 0; s < W; s++) for (int d = 0; d < W; d++) {
-            Xfer x{s, d, nullptr, nullptr, bytes};
-            if (g->local(s)) x.sp = (char *)sbuf[s - g->rank0] + (size_t)d * bytes;
-            if (g->local(d)) x.dp = (char *)rbuf[d - g->rank0] + (size_t)s * bytes;
-            list.push_back(x);
-        }
-        MI_TRY(run_xfers(g, list, xs));
+        return MI_OK;
+    };
+    auto verify = [&]() -> int32_t {
         for (int i = 0; i < nl; i++) {
             (void)hipSetDevice(g->dev[i]);
             std::vector<unsigned char> h(bytes * W);
@@ -251,6 +540,25 @@ int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes) {
         }
         return MI_OK;
     };
+    auto body = [&]() -> int32_t {
+        int32_t lrc = prepare();
+        MI_TRY(group_agree(g, lrc, g->err, "while preparing the self-test"));   // a rank without buffers must not leave the others in the exchange
+        for (int s = 0; s < W; s++) for (int d = 0; d < W; d++) {
+            Xfer x{s, d, nullptr, nullptr, bytes};
+            if (g->local(s)) x.sp = (char *)sbuf[s - g->rank0] + (size_t)d * bytes;
+            if (g->local(d)) x.dp = (char *)rbuf[d - g->rank0] + (size_t)s * bytes;
+            list.push_back(x);
+        }
+        MI_TRY(run_xfers(g, list, xs));
+        lrc = verify();
+        // the all-gather of host values: every rank contributes (rank, 3 rank + 1) and must read that back from everyone
+        std::vector<u64> mine(2 * (size_t)nl), all(2 * (size_t)W);
+        for (int i = 0; i < nl; i++) { mine[2 * i] = (u64)(g->rank0 + i); mine[2 * i + 1] = 3 * (u64)(g->rank0 + i) + 1; }
+        MI_TRY(group_allgather(g, mine.data(), 16, all.data()));
+        for (int r = 0; r < W && lrc == MI_OK; r++)
+            if (all[2 * r] != (u64)r || all[2 * r + 1] != 3 * (u64)r + 1) { g->err = "group: all-gather self-test received wrong values"; lrc = MI_EHIP; }
+        return group_agree(g, lrc, g->err, "in the transport self-test");
+    };
     rc = body();
     for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); if (sbuf[i]) (void)hipFree(sbuf[i]); if (rbuf[i]) (void)hipFree(rbuf[i]); }
     return rc;
@@ -258,99 +566,105 @@ int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes) {
 
 }  // extern "C"
 
-// ---------------------------------------------------------------- mode 1: reduce-scatter of the bucket sums of one MSM slot
-// Every local rank has enqueued the MSM of `slot` with MI_MSM_DEFER_REDUCE.  Afterwards every rank's reduce is enqueued.
-static int32_t exchange_buckets(mi_group *g, int slot, int curve) {
+// ---------------------------------------------------------------- mode 1: reduce-scatter of the bucket sums of MSM slots
+// Every local rank has enqueued the MSMs of `slots` with MI_MSM_DEFER_REDUCE.  prepare (local, may fail): bucket views, receive
+// buffer, the layout values the ranks must agree on.  run (after the agreement): ONE batch of the transport for all the slots,
+// then per slot the sum of the received slices and the reduce.  Local failures inside run are returned AFTER the rank has taken part
+// in the batch (the peers are in it).
+struct BucketExchange {
+    std::vector<int> slots, curves;
+    std::vector<std::vector<MsmBucketView>> v;   // [slot index][local rank]
+    std::vector<size_t> off;                     // receive-buffer offset of every slot's region
+};
+static int32_t exchange_prepare(mi_group *g, BucketExchange &bx, const int *slots, const int *curves, int n_slots, std::vector<uint64_t> &check) {
     const int nl = g->n_local(), W = g->world;
-    const MsmCurveOps &ops = mi_msm_ops(curve);
-    std::vector<MsmBucketView> v(nl);
-    for (int i = 0; i < nl; i++) {
-        G_CTX(g, i, mi_msm_bucket_view(g->ctx[i], slot, curve, &v[i]));
-        if (!v[i].bucket) G_FAIL(g, MI_EINVAL, "group: mode 1 (bucket exchange) needs every rank to hold at least one pair of every MSM");
-        if (v[i].nkeys != v[0].nkeys || v[i].c != v[0].c) G_FAIL(g, MI_EINVAL, "group: the ranks disagree on the bucket layout of an MSM");
+    bx.slots.assign(slots, slots + n_slots); bx.curves.assign(curves, curves + n_slots);
+    bx.v.assign(n_slots, std::vector<MsmBucketView>(nl));
+    bx.off.assign(n_slots + 1, 0);
+    for (int k = 0; k < n_slots; k++) {
+        const MsmCurveOps &ops = mi_msm_ops(curves[k]);
+        for (int i = 0; i < nl; i++) {
+            G_CTX(g, i, mi_msm_bucket_view(g->ctx[i], slots[k], curves[k], &bx.v[k][i]));
+            if (!bx.v[k][i].bucket) G_FAIL(g, MI_EINVAL, "group: mode 1 (bucket exchange) needs every rank to hold at least one pair of every MSM");
+            if (bx.v[k][i].nkeys != bx.v[k][0].nkeys || bx.v[k][i].c != bx.v[k][0].c) G_FAIL(g, MI_EINVAL, "group: the ranks disagree on the bucket layout of an MSM");
+        }
+        const size_t K = bx.v[k][0].nkeys, own_max = (K + W - 1) / W + 1;
+        bx.off[k + 1] = bx.off[k] + (size_t)(W > 1 ? W - 1 : 1) * own_max * ops.xyzz_bytes;
+        check.push_back(((uint64_t)K << 8) | bx.v[k][0].c);
     }
-    const size_t K = v[0].nkeys, B = ops.xyzz_bytes;
-    const size_t own_max = (K + W - 1) / W + 1;
-    std::vector<hipStream_t> xs(nl);
     for (int i = 0; i < nl; i++) {
         (void)hipSetDevice(g->dev[i]);
-        xs[i] = g->xs[i];
-        G_CTX(g, i, mi_reserve(g->ctx[i], g->recv[i], (size_t)(W > 1 ? W - 1 : 1) * own_max * B));
-        G_HIP(g, hipStreamWaitEvent(xs[i], v[i].ready, 0));
+        // the previous batch's slice sums still read the buffer on xs[i]: growing it (hipFree) synchronises the device, reusing it is ordered by xs[i]
+        G_CTX(g, i, mi_reserve(g->ctx[i], g->recv[i], bx.off[n_slots] + 256));
+    }
+    return MI_OK;
+}
+static int32_t exchange_run(mi_group *g, const BucketExchange &bx, int first, int count) {
+    const int nl = g->n_local(), W = g->world;
+    int32_t local_rc = MI_OK;
+    std::string local_err;
+    auto note = [&](int32_t rc, const std::string &msg) { if (rc != MI_OK && local_rc == MI_OK) { local_rc = rc; local_err = msg; } };
+    for (int i = 0; i < nl; i++) {
+        (void)hipSetDevice(g->dev[i]);
+        for (int k = first; k < first + count; k++) {
+            const hipError_t e = hipStreamWaitEvent(g->xs[i], bx.v[k][i].ready, 0);
+            if (e != hipSuccess) note(MI_EHIP, std::string("hipStreamWaitEvent (bucket sums ready): ") + hipGetErrorString(e));
+        }
     }
     std::vector<Xfer> list;
-    for (int s = 0; s < W; s++) for (int d = 0; d < W; d++) {
-        if (s == d) continue;
-        u64 lo, hi;
-        range_of(K, W, d, lo, hi);
-        Xfer x{s, d, nullptr, nullptr, (size_t)(hi - lo) * B};
-        if (g->local(s)) x.sp = (const char *)v[s - g->rank0].bucket + lo * B;
-        if (g->local(d)) x.dp = (char *)g->recv[d - g->rank0].p + (size_t)(s < d ? s : s - 1) * (hi - lo) * B;
-        list.push_back(x);
+    for (int k = first; k < first + count; k++) {
+        const size_t K = bx.v[k][0].nkeys, B = mi_msm_ops(bx.curves[k]).xyzz_bytes;
+        for (int s = 0; s < W; s++) for (int d = 0; d < W; d++) {
+            if (s == d) continue;
+            u64 lo, hi;
+            range_of(K, W, d, lo, hi);
+            Xfer x{s, d, nullptr, nullptr, (size_t)(hi - lo) * B};
+            if (g->local(s)) x.sp = (const char *)bx.v[k][s - g->rank0].bucket + lo * B;
+            if (g->local(d)) x.dp = (char *)g->recv[d - g->rank0].p + bx.off[k] + (size_t)(s < d ? s : s - 1) * (hi - lo) * B;
+            list.push_back(x);
+        }
     }
-    MI_TRY(run_xfers(g, list, xs));
+    MI_TRY(run_xfers(g, list, g->xs));   // a transport failure: the group is broken, nothing below matters
     for (int i = 0; i < nl; i++) {
         (void)hipSetDevice(g->dev[i]);
-        u64 lo, hi;
-        range_of(K, W, g->rank0 + i, lo, hi);
-        char *bk = (char *)v[i].bucket;
-        ops.sum_slices(xs[i], bk + lo * B, g->recv[i].p, (u32)(W - 1), (u32)(hi - lo));
-        G_HIP(g, hipGetLastError());
-        // keys of other owners: their sums live there now; here they read as infinity for the reduce
-        if (lo) G_HIP(g, hipMemsetAsync(bk, 0, lo * B, xs[i]));
-        if (hi < K) G_HIP(g, hipMemsetAsync(bk + hi * B, 0, (K - hi) * B, xs[i]));
-        G_HIP(g, hipEventRecord(g->ev_done[i], xs[i]));
-        G_HIP(g, hipStreamWaitEvent(v[i].stream, g->ev_done[i], 0));
-        G_CTX(g, i, mi_msm_reduce_enqueue(g->ctx[i], slot, curve));
+        for (int k = first; k < first + count; k++) {
+            const MsmCurveOps &ops = mi_msm_ops(bx.curves[k]);
+            const size_t K = bx.v[k][0].nkeys, B = ops.xyzz_bytes;
+            const auto post = [&]() -> int32_t {
+                u64 lo, hi;
+                range_of(K, W, g->rank0 + i, lo, hi);
+                char *bk = (char *)bx.v[k][i].bucket;
+                ops.sum_slices(g->xs[i], bk + lo * B, (const char *)g->recv[i].p + bx.off[k], (u32)(W - 1), (u32)(hi - lo));
+                G_HIP(g, hipGetLastError());
+                // keys of other owners: their sums live there now; here they read as infinity for the reduce
+                if (lo) G_HIP(g, hipMemsetAsync(bk, 0, lo * B, g->xs[i]));
+                if (hi < K) G_HIP(g, hipMemsetAsync(bk + hi * B, 0, (K - hi) * B, g->xs[i]));
+                G_HIP(g, hipEventRecord(g->ev_done[i], g->xs[i]));
+                G_HIP(g, hipStreamWaitEvent(bx.v[k][i].stream, g->ev_done[i], 0));
+                G_CTX(g, i, mi_msm_reduce_enqueue(g->ctx[i], bx.slots[k], bx.curves[k]));
+                return MI_OK;
+            };
+            const int32_t rc = post();
+            note(rc, g->err);
+        }
     }
-    return MI_OK;
+    if (local_rc != MI_OK) g->err = local_err;
+    return local_rc;
 }
 
-// Sum of the per-rank partial results of one MSM (XYZZ on the host).  Single process: plain additions.  One rank per process:
-// byte-typed ncclAllGather of the partials, then the same additions (in rank order) on every rank.
-template <class F>
-static int32_t combine_partials(mi_group *g, const std::vector<XYZZ<F>> &local, XYZZ<F> *out) {
-    XYZZ<F> acc = XYZZ<F>::inf();
-    if (g->n_local() == g->world) {
-        for (const auto &p : local) xyzz_add(acc, p);
-        *out = acc;
-        return MI_OK;
+// Whatever a failed call left on a context's MSM slots is collected (a deferred slot runs its reduce over its local buckets first), so
+// that the next call finds every slot idle.  Errors here change nothing any more.
+static void drain_slots(mi_group *g, const int *slots, const int *curves, int n) {
+    for (int i = 0; i < g->n_local(); i++) {
+        (void)hipSetDevice(g->dev[i]);
+        G1X t1; G2X t2;
+        for (int k = 0; k < n; k++) {
+            (void)mi_msm_reduce_enqueue(g->ctx[i], slots[k], curves[k]);
+            (void)mi_msm_finish(g->ctx[i], slots[k], curves[k], curves[k] == 1 ? (void *)&t1 : (void *)&t2);
+        }
+        (void)hipStreamSynchronize(g->ctx[i]->stream);
+        (void)hipStreamSynchronize(g->xs[i]);
     }
-    if (g->n_local() != 1 || g->comm.size() != 1) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
-    const size_t B = sizeof(XYZZ<F>);
-    std::vector<XYZZ<F>> all((size_t)g->world);
-    (void)hipSetDevice(g->dev[0]);
-    G_CTX(g, 0, mi_reserve(g->ctx[0], g->stage[0], B * (size_t)(g->world + 1)));
-    char *st = (char *)g->stage[0].p;
-    hipStream_t s = g->xs[0];
-    G_HIP(g, hipMemcpyAsync(st, &local[0], B, hipMemcpyHostToDevice, s));
-    G_NCCL(g, ncclAllGather(st, st + B, B, ncclUint8, g->comm[0], s));
-    G_HIP(g, hipMemcpyAsync(all.data(), st + B, B * (size_t)g->world, hipMemcpyDeviceToHost, s));
-    G_HIP(g, hipStreamSynchronize(s));
-    for (const auto &p : all) xyzz_add(acc, p);
-    *out = acc;
-    return MI_OK;
-}
-
-// Group-wide minimum and maximum of one 64-bit value per local rank (plans every rank must agree on: table budgets, window widths).
-// Single process: over the local values.  One rank per process: ncclAllGather of the 8 bytes.
-static int32_t group_min_max(mi_group *g, const std::vector<u64> &local, u64 *mn, u64 *mx) {
-    std::vector<u64> all = local;
-    if (g->n_local() != g->world) {
-        if (g->n_local() != 1 || g->comm.size() != 1) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
-        all.assign((size_t)g->world, 0);
-        (void)hipSetDevice(g->dev[0]);
-        G_CTX(g, 0, mi_reserve(g->ctx[0], g->stage[0], 8 * (size_t)(g->world + 1)));
-        char *st = (char *)g->stage[0].p;
-        hipStream_t s = g->xs[0];
-        G_HIP(g, hipMemcpyAsync(st, &local[0], 8, hipMemcpyHostToDevice, s));
-        G_NCCL(g, ncclAllGather(st, st + 8, 8, ncclUint8, g->comm[0], s));
-        G_HIP(g, hipMemcpyAsync(all.data(), st + 8, 8 * (size_t)g->world, hipMemcpyDeviceToHost, s));
-        G_HIP(g, hipStreamSynchronize(s));
-    }
-    *mn = ~(u64)0; *mx = 0;
-    for (u64 v : all) { if (v < *mn) *mn = v; if (v > *mx) *mx = v; }
-    return MI_OK;
 }
 
 template <class F, class JacT>
@@ -359,6 +673,24 @@ static void write_jac(const XYZZ<F> &r, JacT *out) {
     if (r.is_inf()) j = Jac<F>{F::one(), F::one(), F::zero()};
     else { Affine<F> a = xyzz_to_affine(r); j = Jac<F>{a.x, a.y, F::one()}; }
     std::memcpy(out, &j, sizeof(j));
+}
+// runs fn(i) for every local rank, rank 0 on this thread and the others on threads of their own (an MSM enqueue waits once on the
+// host for its sort's largest bucket, msm.hip: one after the other, rank i + 1 would not even start its sort before rank i's has
+// counted); returns the first failure in rank order with its text in *err
+template <class Fn>
+static int32_t for_each_local_rank(mi_group *g, std::string *err, Fn fn) {
+    const int nl = g->n_local();
+    std::vector<int32_t> rcs((size_t)nl, MI_OK);
+    auto guarded = [&](int i) { try { (void)hipSetDevice(g->dev[i]); rcs[i] = fn(i); } catch (...) { rcs[i] = MI_ENOMEM; } };
+    std::vector<std::thread> th;
+    for (int i = 1; i < nl; i++) {
+        try { th.emplace_back(guarded, i); } catch (...) { guarded(i); }   // no thread to be had: in line
+    }
+    guarded(0);
+    for (auto &t : th) t.join();
+    (void)hipSetDevice(g->dev[0]);
+    for (int i = 0; i < nl; i++) if (rcs[i] != MI_OK) { *err = mi_last_error(g->ctx[i]); return rcs[i]; }
+    return MI_OK;
 }
 
 // One MSM whose (point, scalar) pairs are already spread over the local ranks' devices.
@@ -371,21 +703,42 @@ static int32_t msm_sharded_dev(mi_group *g, int curve, const void *const *pts_de
     const u32 c = mi_msm_auto_c((n_total + g->world - 1) / g->world);
     const uint32_t df = mode == 1 ? MI_MSM_DEFER_REDUCE : 0;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < nl; i++) {
-        (void)hipSetDevice(g->dev[i]);
+    const int slots[1] = {0}, curves[1] = {curve};
+    std::string lerr;
+    int32_t lrc = for_each_local_rank(g, &lerr, [&](int i) -> int32_t {
         mi_ctx *ctx = g->ctx[i];
         std::memset(&ctx->stats, 0, sizeof(ctx->stats));
-        G_HIP(g, hipEventRecord(ctx->ev[0], ctx->stream));
-        G_CTX(g, i, mi_msm_enqueue(ctx, 0, -1, curve, pts_dev[i], sc_dev[i], n_local[i], flags | df, ctx->ev[0], curve == 1, 0, 0, c));
+        MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+        return mi_msm_enqueue(ctx, 0, -1, curve, pts_dev[i], sc_dev[i], n_local[i], flags | df, ctx->ev[0], curve == 1, 0, 0, c);
+    });
+    BucketExchange bx;
+    std::vector<uint64_t> check{(uint64_t)n_total, (uint64_t)mode, (uint64_t)flags};
+    if (mode == 1 && lrc == MI_OK) { lrc = exchange_prepare(g, bx, slots, curves, 1, check); lerr = g->err; }
+    int32_t rc = group_agree(g, lrc, lerr, "while enqueueing its share of the MSM", check.data(), (uint32_t)check.size());
+    if (rc == MI_OK && mode == 1) { lrc = exchange_run(g, bx, 0, 1); lerr = g->err; if (g->broken) rc = lrc; }
+    // the partial sums and the status of every rank in ONE all-gather: all ranks return the sum, or all return an error
+    struct Part { int32_t rc; uint32_t pad[3]; XYZZ<F> p; };
+    std::vector<Part> mine((size_t)nl), all((size_t)g->world);
+    if (rc == MI_OK) {
+        for (int i = 0; i < nl; i++) {
+            (void)hipSetDevice(g->dev[i]);
+            std::memset(&mine[i], 0, sizeof(Part));
+            const int32_t r = lrc != MI_OK ? lrc : mi_msm_finish(g->ctx[i], 0, curve, &mine[i].p);
+            if (r != MI_OK && lrc == MI_OK) { lrc = r; lerr = mi_last_error(g->ctx[i]); }
+            mine[i].rc = lrc;
+        }
+        rc = group_allgather(g, mine.data(), sizeof(Part), all.data());
+        if (rc == MI_OK)
+            for (int r = 0; r < g->world && rc == MI_OK; r++)
+                if (all[r].rc != MI_OK) {
+                    rc = all[r].rc;
+                    g->err = lrc != MI_OK ? lerr : std::string("group: rank ") + std::to_string(r) + " failed in its share of the MSM (status " + std::to_string(rc) + ")";
+                    if (lrc != MI_OK) rc = lrc;
+                }
     }
-    if (mode == 1) MI_TRY(exchange_buckets(g, 0, curve));
-    std::vector<XYZZ<F>> part((size_t)nl);
-    for (int i = 0; i < nl; i++) {
-        (void)hipSetDevice(g->dev[i]);
-        G_CTX(g, i, mi_msm_finish(g->ctx[i], 0, curve, &part[i]));
-    }
-    XYZZ<F> total;
-    MI_TRY(combine_partials<F>(g, part, &total));
+    if (rc != MI_OK) { const std::string keep = g->err; drain_slots(g, slots, curves, 1); g->err = keep; return rc; }
+    XYZZ<F> total = XYZZ<F>::inf();
+    for (const Part &p : all) xyzz_add(total, p.p);
     write_jac<F>(total, out);
     g->ctx[0]->stats.total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MI_OK;
@@ -439,7 +792,8 @@ int32_t mi_msm_g2_sharded(mi_group *g, const mi_g2_affine *pts, const mi_fr *sca
 // ---------------------------------------------------------------- sharded proving key
 int32_t mi_pk_sharded_free(mi_group *g, mi_pk_sharded *spk) {
     if (!g || !spk) return MI_EINVAL;
-    G_ENTER(g);
+    GroupCall call__(g);
+    if (!call__.ok) return MI_EINVAL;   // (a broken group still frees its keys)
     for (size_t i = 0; i < spk->part.size(); i++) if (spk->part[i]) { (void)hipSetDevice(g->dev[i]); mi_pk_free(g->ctx[i], spk->part[i]); }
     delete spk;
     return MI_OK;
@@ -455,11 +809,18 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
     if (!g || !descs || !out) return MI_EINVAL;
     *out = nullptr;
     const mi_pk_desc *d = descs;
-    if (d->log_n > 28 || !d->infinity_a || !d->infinity_b || d->nb_public > d->nb_wires) G_FAIL(g, MI_EINVAL, "pk: bad header");
     const int nl = g->n_local(), W = g->world;
-    if (device_points) for (int i = 1; i < nl; i++)
-        if (descs[i].log_n != d->log_n || descs[i].nb_wires != d->nb_wires || descs[i].nb_public != d->nb_public || !descs[i].infinity_a || !descs[i].infinity_b)
-            G_FAIL(g, MI_EINVAL, "pk: the per-rank descriptors disagree on the key's header");
+    {   // the header every process passes must be acceptable AND the same everywhere before anything collective starts
+        int32_t lrc = MI_OK;
+        std::string lerr;
+        if (d->log_n > 28 || !d->infinity_a || !d->infinity_b || d->nb_public > d->nb_wires) { lrc = MI_EINVAL; lerr = "pk: bad header"; }
+        if (lrc == MI_OK && device_points) for (int i = 1; i < nl; i++)
+            if (descs[i].log_n != d->log_n || descs[i].nb_wires != d->nb_wires || descs[i].nb_public != d->nb_public || !descs[i].infinity_a || !descs[i].infinity_b) {
+                lrc = MI_EINVAL; lerr = "pk: the per-rank descriptors disagree on the key's header";
+            }
+        const uint64_t check[3] = {d->log_n, d->nb_wires, d->nb_public};
+        MI_TRY(group_agree(g, lrc, lerr, "while checking the key's header", check, 3));
+    }
     const u64 N = (u64)1 << d->log_n;
     mi_pk_sharded *spk = new (std::nothrow) mi_pk_sharded();
     if (!spk) return MI_ENOMEM;
@@ -545,37 +906,48 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
 
 // One proof over the ranks of the group (groth16.Prove, mt.go:496).  Inputs either in host memory (host = true: W is the WHOLE wire
 // vector, a process reads only the ranges of its local ranks; a, b, c are read by the process that holds rank 0) or already on the
-// devices (W_dev[i] = the wire range of local rank i on its device; a, b, c on rank 0's device).
+// devices (W_dev[i] = the wire range of local rank i on its device; a, b, c on rank 0's device).  c == null on the lead: c = a o b,
+// formed on the device (mi_groth16_prove).
 // mode 0: per-rank partial sums (option i); mode 1: bucket reduce-scatter before the reduce (option ii).
+// Phases: [local: checks, workspaces, uploads, wire MSMs, computeH + Z on the lead] AGREE [h slices over the transport] [local: the other
+// ranks' Z MSMs; mode 1: bucket views] (mode 1: AGREE [bucket slices of A, B1, B2, K] [bucket slices of Z]) [local: collect] ALL-GATHER
+// of every rank's status and five partial sums.
 static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, const mi_fr *W_host, const mi_fr *const *W_dev, size_t n_wires,
                                   const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m,
                                   uint32_t mode, mi_proof_out *out, mi_stats *stats) {
-    if (!g || !spk || !r_m || !s_m || !out || mode > 1 || (host ? !W_host : !W_dev)) return MI_EINVAL;
+    if (!g || !spk || !out) return MI_EINVAL;
     const int nl = g->n_local(), W = g->world;
     if ((nl != W && nl != 1) || (int)spk->part.size() != nl) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
+    static const int slots[5] = {0, 1, 2, 3, 4}, curves[5] = {1, 1, 2, 1, 1};   // A, B1, B2, K, Z: the same order on every rank
     const bool lead_here = g->rank0 == 0;   // global rank 0 runs computeH and owns a, b, c
-    if (lead_here && (!a || !b || !c)) return MI_EINVAL;
     const size_t N = (size_t)1 << spk->log_n;
-    if (n_wires != spk->nb_wires || n_constraints > N) G_FAIL(g, MI_EINVAL, "prove: witness size does not match the proving key");
-    if (mode == 1 && !spk->uniform) G_FAIL(g, MI_EINVAL, "group: mode 1 needs every part to use the same MSM plan and every rank to hold pairs of every MSM");
     const auto t_begin = std::chrono::steady_clock::now();
     const size_t cb = n_constraints * sizeof(mi_fr);
-    // workspaces first, each on its own device: W slice (+ a, b, c on the lead) for host inputs; h (whole on the lead, a slice elsewhere)
-    for (int i = 0; i < nl; i++) {
+    const bool defer = mode == 1;
+    // ---- local phase 1.  Nothing returns from here on without the group having agreed on it (a process that left alone would leave
+    //      the others waiting in the next exchange): failures are noted and carried to the agreement.
+    int32_t lrc = MI_OK;
+    std::string lerr;
+    auto note = [&](int32_t rc, const std::string &msg) { if (rc != MI_OK && lrc == MI_OK) { lrc = rc; lerr = msg; } };
+    if (!r_m || !s_m || mode > 1 || (host ? (!W_host && n_wires) : !W_dev)) note(MI_EINVAL, "prove: null argument or unknown mode");
+    if (lead_here && (!a || !b) && n_constraints) note(MI_EINVAL, "prove: the process that holds rank 0 must pass a and b");
+    if (n_wires != spk->nb_wires || (lead_here && n_constraints > N)) note(MI_EINVAL, "prove: witness size does not match the proving key");
+    if (mode == 1 && !spk->uniform) note(MI_EINVAL, "group: mode 1 needs every part to use the same MSM plan and every rank to hold pairs of every MSM");
+    // workspaces, each on its own device: W slice (+ a, b, c on the lead) for host inputs; h (whole on the lead, a slice elsewhere)
+    for (int i = 0; i < nl && lrc == MI_OK; i++) {
         (void)hipSetDevice(g->dev[i]);
         mi_ctx *ctx = g->ctx[i];
         mi_pk *pk = spk->part[i];
         const bool lead = g->rank0 + i == 0;
         std::memset(&ctx->stats, 0, sizeof(ctx->stats));
-        if (host) G_CTX(g, i, mi_reserve(ctx, ctx->ws[16], pk->nb_wires * sizeof(mi_fr) + (lead ? 3 * cb : 0) + 128));
-        G_CTX(g, i, mi_reserve(ctx, ctx->ws[14], (lead ? N : pk->n_z_msm + 1) * sizeof(Fr)));
+        int32_t rc = MI_OK;
+        if (host) rc = mi_reserve(ctx, ctx->ws[16], pk->nb_wires * sizeof(mi_fr) + (lead ? 3 * cb : 0) + 128);
+        if (rc == MI_OK) rc = mi_reserve(ctx, ctx->ws[14], (lead ? N : pk->n_z_msm + 1) * sizeof(Fr));
+        note(rc, mi_last_error(ctx));
     }
-    const bool defer = mode == 1;
-    std::vector<int32_t> rcs(nl, MI_OK);
     // every local rank: its slice of W, its wire MSMs; the lead also a, b, c, computeH and its own Z MSM.  One host thread per rank:
     // enqueueing the wire MSMs waits once for the count pass of their sorts (msm.hip, MI_MSM_EXACT_SIZE)
     auto rank_main = [&](int i) -> int32_t {
-        (void)hipSetDevice(g->dev[i]);
         mi_ctx *ctx = g->ctx[i];
         mi_pk *pk = spk->part[i];
         hipEvent_t *ev = ctx->ev;
@@ -597,11 +969,11 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
         const mi_fr *da = a, *db = b, *dc = c;
         if (host) {
             char *base = (char *)ctx->ws[16].p;
-            da = (mi_fr *)(base + wb); db = (mi_fr *)(base + wb + cb); dc = (mi_fr *)(base + wb + 2 * cb);
+            da = (mi_fr *)(base + wb); db = (mi_fr *)(base + wb + cb); dc = c ? (mi_fr *)(base + wb + 2 * cb) : nullptr;
             if (cb) {
                 MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)da, a, cb, hipMemcpyHostToDevice, ctx->copy_stream));
                 MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)db, b, cb, hipMemcpyHostToDevice, ctx->copy_stream));
-                MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dc, c, cb, hipMemcpyHostToDevice, ctx->copy_stream));
+                if (c) MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dc, c, cb, hipMemcpyHostToDevice, ctx->copy_stream));
                 MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
             }
             ctx->stats.h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_up).count();
@@ -612,17 +984,16 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
         MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
         return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)(h + pk->z_lo), ev[3], defer);
     };
+    if (lrc == MI_OK) { std::string e; note(for_each_local_rank(g, &e, rank_main), e); }
+    auto fail = [&](int32_t rc) { const std::string keep = g->err; drain_slots(g, slots, curves, 5); g->err = keep; return rc; };
     {
-        std::vector<std::thread> th;
-        for (int i = 1; i < nl; i++) th.emplace_back([&, i] { rcs[i] = rank_main(i); });
-        rcs[0] = rank_main(0);
-        for (auto &t : th) t.join();
+        const uint64_t check[3] = {(uint64_t)n_wires, (uint64_t)mode, (uint64_t)spk->log_n};   // (n_constraints is the lead's alone)
+        const int32_t rc = group_agree(g, lrc, lerr, "before the exchange of the h slices", check, 3);
+        if (rc != MI_OK) return fail(rc);
     }
-    (void)hipSetDevice(g->dev[0]);
-    for (int i = 0; i < nl; i++) if (rcs[i] != MI_OK) { g->err = mi_last_error(g->ctx[i]); return rcs[i]; }
-    // h: rank 0 hands every other rank its slice device to device, as one batch of the group's transport (grouped ncclSend / ncclRecv,
-    // or same-process copies) on the exchange streams; the events that order the Z MSMs behind it are recorded by each RECEIVER on its
-    // own stream (an event is recorded only on a stream of the device it was created on)
+    // ---- h: rank 0 hands every other rank its slice device to device, as one batch of the group's transport (grouped ncclSend / ncclRecv,
+    // same-process copies or the shared-memory rings) on the exchange streams; the events that order the Z MSMs behind it are recorded by
+    // each RECEIVER on its own stream (an event is recorded only on a stream of the device it was created on)
     if (W > 1) {
         std::vector<Xfer> list;
         for (int j = 1; j < W; j++) {
@@ -633,51 +1004,82 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
             if (g->local(j)) x.dp = g->ctx[j - g->rank0]->ws[14].p;
             list.push_back(x);
         }
-        if (lead_here) { (void)hipSetDevice(g->dev[0]); G_HIP(g, hipStreamWaitEvent(g->xs[0], g->ctx[0]->ev[3], 0)); }
-        MI_TRY(run_xfers(g, list, g->xs));
-        for (int i = 0; i < nl; i++) {
-            if (g->rank0 + i == 0) continue;
-            (void)hipSetDevice(g->dev[i]);
-            G_HIP(g, hipEventRecord(g->ev_h[i], g->xs[i]));
-            G_CTX(g, i, mi_prove_enqueue_z_msm(g->ctx[i], spk->part[i], (const mi_fr *)g->ctx[i]->ws[14].p, g->ev_h[i], defer));
+        if (lead_here) {
+            (void)hipSetDevice(g->dev[0]);
+            const hipError_t e = hipStreamWaitEvent(g->xs[0], g->ctx[0]->ev[3], 0);
+            if (e != hipSuccess) note(MI_EHIP, std::string("hipStreamWaitEvent (h ready): ") + hipGetErrorString(e));   // (still takes part in the batch)
+        }
+        const int32_t rc = run_xfers(g, list, g->xs);
+        if (rc != MI_OK) return fail(rc);   // transport failure: the group is broken
+        if (lrc == MI_OK) {
+            std::string e;
+            note(for_each_local_rank(g, &e, [&](int i) -> int32_t {
+                if (g->rank0 + i == 0) return MI_OK;
+                mi_ctx *ctx = g->ctx[i];
+                MI_CHECK_HIP(ctx, hipEventRecord(g->ev_h[i], g->xs[i]));
+                return mi_prove_enqueue_z_msm(ctx, spk->part[i], (const mi_fr *)ctx->ws[14].p, g->ev_h[i], defer);
+            }), e);
         }
     }
     if (defer) {
-        // same order on every rank: A, B1, B2, K, Z
-        static const int slots[5] = {0, 1, 2, 3, 4}, curves[5] = {1, 1, 2, 1, 1};
-        for (int k = 0; k < 5; k++) MI_TRY(exchange_buckets(g, slots[k], curves[k]));
+        // the wire MSMs' slices go first (one batch), Z's -- the last to have its bucket sums -- second: their reduces then run under
+        // Z's accumulation.  No local failure point lies between the agreement and the end of the second batch that a rank does not carry
+        // THROUGH both batches.
+        BucketExchange bx;
+        std::vector<uint64_t> check;
+        if (lrc == MI_OK) { const int32_t rc = exchange_prepare(g, bx, slots, curves, 5, check); note(rc, g->err); }
+        const int32_t rc = group_agree(g, lrc, lerr, "before the exchange of the bucket sums", check.data(), (uint32_t)check.size());
+        if (rc != MI_OK) return fail(rc);
+        int32_t r1 = exchange_run(g, bx, 0, 4);
+        if (g->broken) return fail(r1);
+        note(r1, g->err);
+        r1 = exchange_run(g, bx, 4, 1);
+        if (g->broken) return fail(r1);
+        note(r1, g->err);
     }
     ProofAssembler as;
-    as.start(spk->part[0], r_m, s_m);
-    // collect: per MSM the sum of the ranks' partial results (every process ends with the same five sums)
-    G1X sum_a, sum_b1, sum_k, sum_z;
-    G2X sum_b2;
-    auto collect1 = [&](int slot, G1X *acc) -> int32_t {
-        std::vector<G1X> part((size_t)nl);
-        for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); G_CTX(g, i, mi_msm_finish(g->ctx[i], slot, 1, &part[i])); }
-        return combine_partials<Fp>(g, part, acc);
-    };
-    auto collect2 = [&](int slot, G2X *acc) -> int32_t {
-        std::vector<G2X> part((size_t)nl);
-        for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); G_CTX(g, i, mi_msm_finish(g->ctx[i], slot, 2, &part[i])); }
-        return combine_partials<Fp2>(g, part, acc);
-    };
-    MI_TRY(collect1(0, &sum_a));
-    MI_TRY(collect1(1, &sum_b1));
-    as.have_a_b1(sum_a, sum_b1);
-    MI_TRY(collect1(3, &sum_k));
-    MI_TRY(collect2(2, &sum_b2));
-    MI_TRY(collect1(4, &sum_z));
-    for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); G_HIP(g, hipStreamSynchronize(g->ctx[i]->stream)); G_HIP(g, hipStreamSynchronize(g->xs[i])); }
+    if (lrc == MI_OK) as.start(spk->part[0], r_m, s_m);
+    // ---- collect: this process's partial results of the five MSMs, then ONE all-gather of (status, five partial sums) per rank: every
+    // process ends with the same five sums, or every process returns an error
+    struct Part { int32_t rc; uint32_t pad[3]; G1X a, b1, k, z; G2X b2; };
+    std::vector<Part> mine((size_t)nl), all((size_t)W);
+    for (int i = 0; i < nl; i++) {
+        (void)hipSetDevice(g->dev[i]);
+        std::memset(&mine[i], 0, sizeof(Part));
+        if (lrc == MI_OK) {
+            mi_ctx *ctx = g->ctx[i];
+            int32_t rc = mi_msm_finish(ctx, 0, 1, &mine[i].a);
+            if (rc == MI_OK) rc = mi_msm_finish(ctx, 1, 1, &mine[i].b1);
+            if (rc == MI_OK) rc = mi_msm_finish(ctx, 3, 1, &mine[i].k);
+            if (rc == MI_OK) rc = mi_msm_finish(ctx, 2, 2, &mine[i].b2);
+            if (rc == MI_OK) rc = mi_msm_finish(ctx, 4, 1, &mine[i].z);
+            if (rc == MI_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipStreamSynchronize(g->xs[i]) != hipSuccess)) { mi_set_err(ctx, "prove: stream synchronisation failed"); rc = MI_EHIP; }
+            note(rc, mi_last_error(ctx));
+        }
+    }
+    for (int i = 0; i < nl; i++) mine[i].rc = lrc;
+    {
+        const int32_t rc = group_allgather(g, mine.data(), sizeof(Part), all.data());
+        if (rc != MI_OK) return fail(rc);
+        for (int r = 0; r < W; r++)
+            if (all[r].rc != MI_OK) {
+                if (lrc != MI_OK) { g->err = lerr; return fail(lrc); }
+                g->err = std::string("group: rank ") + std::to_string(r) + " failed in its part of the proof (status " + std::to_string(all[r].rc) + ")";
+                return fail(all[r].rc);
+            }
+    }
+    G1X sum_a = G1X::inf(), sum_b1 = G1X::inf(), sum_k = G1X::inf(), sum_z = G1X::inf();
+    G2X sum_b2 = G2X::inf();
+    for (const Part &p : all) { xyzz_add(sum_a, p.a); xyzz_add(sum_b1, p.b1); xyzz_add(sum_k, p.k); xyzz_add(sum_z, p.z); xyzz_add(sum_b2, p.b2); }
     const auto t_gpu_done = std::chrono::steady_clock::now();
+    as.have_a_b1(sum_a, sum_b1);
     as.finish(sum_k, sum_b2, sum_z, out);
     const auto t_end = std::chrono::steady_clock::now();
     (void)hipSetDevice(g->dev[0]);
     mi_stats &st = g->ctx[0]->stats;
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<float, std::milli>(y - x).count(); };
-    if (lead_here) {
-        G_HIP(g, hipEventElapsedTime(&st.compute_h_ms, g->ctx[0]->ev[11], g->ctx[0]->ev[3]));
-    }
+    // (statistics are best effort: past the last all-gather nothing may fail on one rank alone)
+    if (lead_here && hipEventElapsedTime(&st.compute_h_ms, g->ctx[0]->ev[11], g->ctx[0]->ev[3]) != hipSuccess) { (void)hipGetLastError(); st.compute_h_ms = 0; }
     st.assemble_ms = ms(t_gpu_done, t_end);
     st.total_ms = ms(t_begin, t_end);
     if (stats) *stats = st;

@@ -493,7 +493,8 @@ int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t 
 // PCIe one after the other) can start a's transforms while b is still on the bus:
 //   part 0 (src = a), part 1 (src = b)   N FFTInverse(., DIF) and the coset FFT up to (not including) its last pass when that pass runs in
 //                                        the strided triple, else all of it; a lives in h_out, b in ws[0]
-//   part 2 (src = c)                     den FFTInverse(c, DIF) into ws[1]
+//   part 2 (src = c)                     den FFTInverse(c, DIF) into ws[1]; src2 != null: c is not given and is formed as src o src2 (the ORIGINAL a and b,
+//                                        row by row) on the way into the first pass -- what c is for every witness gnark's solver accepts
 //   part 3                               the strided triple (or the coset FFTs' last passes) and the last transform -> h_out
 // The same launches as the one-call form, in an order that differs only between independent vectors: identical h.
 struct ComputeHPlan {
@@ -523,7 +524,7 @@ static int32_t compute_h_plan(mi_ctx *ctx, uint32_t log_n, Fr *A, ComputeHPlan &
     }
     return MI_OK;
 }
-int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *src, size_t n_constraints, mi_fr *h_out) {
+int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *src, size_t n_constraints, mi_fr *h_out, const mi_fr *src2) {
     const size_t n = (size_t)1 << log_n;
     // gnark's computeH (7 transforms): a, b, c <- FFTInverse; a, b, c <- FFT on the coset; a <- (a b - c) den; h <- FFTInverse on
     // the coset.  The last transform is linear and undoes the coset FFT of c exactly:
@@ -557,7 +558,7 @@ int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *sr
         return ntt_run(ctx, v, v, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | (cp.triple ? 2u : 0u), &px, &tx);
     }
     if (part == 2)   // c <- den FFTInverse(c, DIF) (one constant den / N on the way out), bit-reversed like h
-        return ntt_run(ctx, C, (const Fr *)src, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4);
+        return ntt_run(ctx, C, (const Fr *)src, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4, (const Fr *)src2);
     // 3. h <- den FFTInverse(a b, DIF, OnCoset) - c, left bit-reversed like gnark: the product a b is taken on the way into the
     //    first pass, the subtraction on the way out of the last (no pointwise kernel, no extra round trip through HBM)
     if (!cp.triple) return ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C);
@@ -577,7 +578,8 @@ int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const
                               size_t n_constraints, mi_fr *h_out) {
     MI_TRY(mi_compute_h_part(ctx, log_n, 0, a, n_constraints, h_out));
     MI_TRY(mi_compute_h_part(ctx, log_n, 1, b, n_constraints, h_out));
-    MI_TRY(mi_compute_h_part(ctx, log_n, 2, c, n_constraints, h_out));
+    if (c) MI_TRY(mi_compute_h_part(ctx, log_n, 2, c, n_constraints, h_out));
+    else MI_TRY(mi_compute_h_part(ctx, log_n, 2, a, n_constraints, h_out, b));   // c = a o b, formed on the device
     return mi_compute_h_part(ctx, log_n, 3, nullptr, n_constraints, h_out);
 }
 
@@ -631,7 +633,7 @@ int32_t mi_ntt(mi_ctx *ctx, mi_fr *inout, uint32_t log_n, uint32_t flags) {
 }
 int32_t mi_compute_h_dev(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                          size_t n_constraints, mi_fr *h_out) {
-    if (!ctx || !a || !b || !c || !h_out || log_n > 28 || n_constraints > ((size_t)1 << log_n)) return MI_EINVAL;
+    if (!ctx || !a || !b || !h_out || log_n > 28 || n_constraints > ((size_t)1 << log_n)) return MI_EINVAL;   // c may be null: c = a o b
     stats_begin(ctx);
     MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     MI_TRY(mi_compute_h_dev_impl(ctx, log_n, a, b, c, n_constraints, h_out));
@@ -643,15 +645,15 @@ int32_t mi_compute_h_dev(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_f
 }
 int32_t mi_compute_h(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                      size_t n_constraints, mi_fr *h_out) {
-    if (!ctx || !a || !b || !c || !h_out || log_n > 28 || n_constraints > ((size_t)1 << log_n)) return MI_EINVAL;
+    if (!ctx || !a || !b || !h_out || log_n > 28 || n_constraints > ((size_t)1 << log_n)) return MI_EINVAL;   // c may be null: c = a o b
     size_t nb = n_constraints * sizeof(Fr), full = sizeof(Fr) << log_n;
     MI_TRY(mi_reserve(ctx, ctx->ws[2], full));
     MI_TRY(mi_reserve(ctx, ctx->ws[3], nb * 3 + 96));
     char *in = (char *)ctx->ws[3].p;
     MI_CHECK_HIP(ctx, hipMemcpyAsync(in, a, nb, hipMemcpyHostToDevice, ctx->stream));
     MI_CHECK_HIP(ctx, hipMemcpyAsync(in + nb, b, nb, hipMemcpyHostToDevice, ctx->stream));
-    MI_CHECK_HIP(ctx, hipMemcpyAsync(in + 2 * nb, c, nb, hipMemcpyHostToDevice, ctx->stream));
-    MI_TRY(mi_compute_h_dev(ctx, log_n, (mi_fr *)in, (mi_fr *)(in + nb), (mi_fr *)(in + 2 * nb), n_constraints, (mi_fr *)ctx->ws[2].p));
+    if (c) MI_CHECK_HIP(ctx, hipMemcpyAsync(in + 2 * nb, c, nb, hipMemcpyHostToDevice, ctx->stream));
+    MI_TRY(mi_compute_h_dev(ctx, log_n, (mi_fr *)in, (mi_fr *)(in + nb), c ? (mi_fr *)(in + 2 * nb) : nullptr, n_constraints, (mi_fr *)ctx->ws[2].p));
     MI_CHECK_HIP(ctx, hipMemcpyAsync(h_out, ctx->ws[2].p, full, hipMemcpyDeviceToHost, ctx->stream));
     MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MI_OK;

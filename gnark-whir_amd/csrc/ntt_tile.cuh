@@ -123,6 +123,7 @@ MI_HD bool ntt_edge_factor(const NttPass &p, const NttTables &t, u32 rho, u64 g,
         e = x << (p.log_n - log_m);
         lo = t.tw_lo; hi = t.tw_hi;
     } else if (phase == 0 && p.load_mul) {
+        if (g >= p.n_valid) return false;   // zero padding: the element is zero and load_mul may be as short as the data (computeH's c = a o b)
         f = p.load_mul[g];
         return true;
     } else {

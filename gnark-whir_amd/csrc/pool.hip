@@ -42,6 +42,10 @@ struct Job {
     bool gated = false;    // handed to a worker before a, b, c had arrived: it waits for the set's abc_state
     float h2d_ms = 0;      // wall-clock of the staging copies
     std::string err;
+    // BSB22 (mi_prover_submit_bsb22): the proof's CommitmentPok = sum_i challenge^i * ProveKnowledge_i(values_i), computed by the job
+    std::vector<mi_bsb22_input> bsb;
+    mi_fr challenge{};
+    mi_g1_affine *pok_out = nullptr;
 };
 struct InputSet {          // W | a | b | c of one staged host job
     void *p = nullptr;
@@ -66,6 +70,8 @@ struct mi_prover {
     std::unordered_map<uint64_t, Job *> jobs;   // submitted, not yet collected by mi_prover_wait
     uint64_t next_id = 1;
     bool stop = false, uploading = false;
+    mi_ctx *commit_ctx = nullptr; // mi_prover_commit: the mid-solve Pedersen commitments of all callers, one at a time
+    std::mutex commit_m;
     uint32_t busy = 0;            // workers inside a prove
     bool early_handover = true;   // a host job goes to a worker once W has arrived (MI_POOL_EARLY_HANDOVER=0: only when W, a, b, c all have)
     std::string err;
@@ -96,7 +102,16 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
             p->queue.pop_front();
             p->busy++;
         }
-        int32_t rc;
+        int32_t rc, rc_pok = MI_OK;
+        // BSB22: ProveKnowledge of every commitment but the last runs before the proof, the last one rides on slot 5 BESIDE the proof's
+        // five MSMs and is collected after it (prove.go computes the PoK between the solve and computeH: same values, same points)
+        const size_t nb = j->bsb.size();
+        std::vector<mi_g1_affine> poks(nb);
+        std::string pok_err;
+        for (size_t i = 0; i + 1 < nb && rc_pok == MI_OK; i++) rc_pok = mi_pedersen_prove_knowledge(ctx, j->bsb[i].key, j->bsb[i].values, j->bsb[i].n, &poks[i]);
+        bool pok_pending = false;
+        if (nb && rc_pok == MI_OK) { rc_pok = mi_pedersen_pok_enqueue(ctx, j->bsb[nb - 1].key, j->bsb[nb - 1].values, j->bsb[nb - 1].n); pok_pending = rc_pok == MI_OK; }
+        if (rc_pok != MI_OK) pok_err = mi_last_error(ctx);
         if (j->gated) {
             InputSet &set = p->sets[j->set];
             const std::function<bool()> abc = [&]() -> bool {   // blocks until a, b, c are resident (or their upload has failed)
@@ -110,15 +125,26 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
                 arrived = set.abc_state == 1;   // the steady state: the uploader is a job ahead
             }
             rc = mi_groth16_prove_dev_gated(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats, abc, arrived);
+            // Whatever the prove returned -- it can fail BEFORE it reaches the gate (witness size mismatch, a part of a sharded key, a
+            // workspace that does not fit) -- the uploader may still be copying this job's a, b, c from the caller's buffers and will
+            // still write j->h2d_ms: the job is not finished (its waiter may free the Job and the buffers) until the uploader is done with it.
+            (void)abc();
         } else {
             rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
         }
+        std::string prove_err = rc != MI_OK ? mi_last_error(ctx) : "";
+        if (pok_pending) {   // collected whatever the proof did: slot 5 must be idle for the next job
+            const int32_t r2 = mi_pedersen_pok_collect(ctx, &poks[nb - 1]);
+            if (r2 != MI_OK && rc_pok == MI_OK) { rc_pok = r2; pok_err = mi_last_error(ctx); }
+        }
+        if (rc == MI_OK && rc_pok != MI_OK) { rc = rc_pok; prove_err = pok_err; }
+        if (rc == MI_OK && nb && j->pok_out) rc = mi_pedersen_fold(poks.data(), nb, &j->challenge, j->pok_out);
         if (rc == MI_OK && j->host && j->stats) j->stats->h2d_ms = j->h2d_ms;
         {
             std::lock_guard<std::mutex> lk(p->m);
             p->busy--;
         }
-        finish_job(p, j, rc, rc != MI_OK ? mi_last_error(ctx) : nullptr);
+        finish_job(p, j, rc, rc != MI_OK ? prove_err.c_str() : nullptr);
     }
 }
 
@@ -180,7 +206,7 @@ static void uploader_main(mi_prover *p) {
         auto hand_over = [&](bool gated) {   // gated: a, b, c are still on their way (the worker waits for abc_state before computeH)
             {
                 std::lock_guard<std::mutex> lk(p->m);
-                j->W = (const mi_fr *)base; j->a = (const mi_fr *)(base + wb); j->b = (const mi_fr *)(base + wb + cb); j->c = (const mi_fr *)(base + wb + 2 * cb);
+                j->W = (const mi_fr *)base; j->a = (const mi_fr *)(base + wb); j->b = (const mi_fr *)(base + wb + cb); j->c = hc ? (const mi_fr *)(base + wb + 2 * cb) : nullptr;
                 j->gated = gated;
                 p->queue.push_back(j);
             }
@@ -209,7 +235,7 @@ static void uploader_main(mi_prover *p) {
         maybe_hand_over();
         if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + cb, hb, cb, hipMemcpyHostToDevice, p->copy_stream);
         maybe_hand_over();
-        if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + 2 * cb, hc, cb, hipMemcpyHostToDevice, p->copy_stream);
+        if (e == hipSuccess && cb && hc) e = hipMemcpyAsync(base + wb + 2 * cb, hc, cb, hipMemcpyHostToDevice, p->copy_stream);   // hc == null: c = a o b on the device
         if (e == hipSuccess) e = hipStreamSynchronize(p->copy_stream);   // a, b, c are resident when abc_state says so
         if (e != hipSuccess) (void)hipGetLastError();
         {
@@ -251,6 +277,12 @@ int32_t mi_prover_create(int device_id, uint32_t in_flight, mi_prover **out) {
         delete p;
         return MI_EHIP;
     }
+    if (mi_init_prio(device_id, MI_PRIO_POOL_FIRST, &p->commit_ctx) != MI_OK) {   // mid-solve commitments: a caller is blocked on each of them
+        (void)hipStreamDestroy(p->copy_stream);
+        for (mi_ctx *q : p->ctx) mi_shutdown(q);
+        delete p;
+        return MI_EHIP;
+    }
     p->sets.resize(in_flight + 1);
     if (const char *e = getenv("MI_POOL_EARLY_HANDOVER")) p->early_handover = atoi(e) != 0;
     for (mi_ctx *c : p->ctx) p->workers.emplace_back(worker_main, p, c);
@@ -275,6 +307,7 @@ int32_t mi_prover_destroy(mi_prover *p) {
     for (InputSet &s : p->sets) if (s.p) (void)hipFree(s.p);
     if (p->copy_stream) (void)hipStreamDestroy(p->copy_stream);
     for (mi_ctx *c : p->ctx) mi_shutdown(c);
+    if (p->commit_ctx) mi_shutdown(p->commit_ctx);
     for (auto &kv : p->jobs) delete kv.second;
     delete p;
     return MI_OK;
@@ -291,10 +324,15 @@ const char *mi_prover_last_error(mi_prover *p) {
 }
 
 static int32_t submit(mi_prover *p, bool host, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
-                      size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket) {
-    if (!p || !pk || !r || !s || !out || !ticket || (!W && n_wires) || ((!a || !b || !c) && n_constraints)) return MI_EINVAL;
+                      size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket,
+                      const mi_bsb22_input *bsb = nullptr, uint32_t n_bsb = 0, const mi_fr *challenge = nullptr, mi_g1_affine *pok_out = nullptr) {
+    if (!p || !pk || !r || !s || !out || !ticket || (!W && n_wires) || ((!a || !b) && n_constraints)) return MI_EINVAL;   // c == null: c = a o b
+    if (n_bsb && (!bsb || !challenge || !pok_out || n_bsb > MI_PK_RAW_MAX_COMMITMENTS)) return MI_EINVAL;
+    for (uint32_t i = 0; i < n_bsb; i++) if (!bsb[i].key || (!bsb[i].values && bsb[i].n)) return MI_EINVAL;
     Job *j = new (std::nothrow) Job();
     if (!j) return MI_ENOMEM;
+    try { j->bsb.assign(bsb, bsb + n_bsb); } catch (...) { delete j; return MI_ENOMEM; }
+    if (n_bsb) { j->challenge = *challenge; j->pok_out = pok_out; }
     j->host = host; j->pk = pk; j->W = W; j->a = a; j->b = b; j->c = c;
     j->n_wires = n_wires; j->n_constraints = n_constraints;
     j->r = *r; j->s = *s;   // copied: the caller's r, s need not outlive the call
@@ -319,6 +357,22 @@ int32_t mi_prover_submit_dev(mi_prover *p, mi_pk *pk, const mi_fr *W_dev, size_t
                              const mi_fr *c_dev, size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats,
                              uint64_t *ticket) {
     return submit(p, false, pk, W_dev, n_wires, a_dev, b_dev, c_dev, n_constraints, r, s, out, stats, ticket);
+}
+
+int32_t mi_prover_submit_bsb22(mi_prover *p, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
+                               size_t n_constraints, const mi_fr *r, const mi_fr *s, const mi_bsb22_input *commitments, uint32_t n_commitments,
+                               const mi_fr *challenge, mi_proof_out *out, mi_g1_affine *pok_out, mi_stats *stats, uint64_t *ticket) {
+    return submit(p, true, pk, W, n_wires, a, b, c, n_constraints, r, s, out, stats, ticket, commitments, n_commitments, challenge, pok_out);
+}
+// Pedersen Commit inside the solve (gnark's BSB22 hint override): synchronous, from any thread; one commitment at a time on a context of
+// its own whose streams rank with the pool's first context, so that a blocked solver waits for one small MSM, not for a proof
+int32_t mi_prover_commit(mi_prover *p, mi_pedersen_pk *key, const mi_fr *values, size_t n, mi_g1_affine *commitment) {
+    if (!p || !key || !commitment || (!values && n)) return MI_EINVAL;
+    std::lock_guard<std::mutex> lk(p->commit_m);
+    (void)hipSetDevice(p->dev);
+    const int32_t rc = mi_pedersen_commit(p->commit_ctx, key, values, n, commitment);
+    if (rc != MI_OK) { std::lock_guard<std::mutex> lk2(p->m); p->err = mi_last_error(p->commit_ctx); }
+    return rc;
 }
 
 int32_t mi_prover_wait(mi_prover *p, uint64_t ticket) {

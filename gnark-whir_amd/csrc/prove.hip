@@ -199,19 +199,32 @@ struct mi_pedersen_pk {
     void *basis = nullptr, *basis_exp_sigma = nullptr;
     size_t n = 0;
 };
-static int32_t pedersen_msm(mi_ctx *ctx, const void *bases_dev, size_t key_n, const mi_fr *values, size_t n, mi_g1_affine *out) {
-    if (!ctx || !out || (!values && n)) return MI_EINVAL;
+// One Pedersen MSM on slot 5 of ctx (its own stream: it runs beside the five MSMs of a proof), in two halves so that a prover-pool job
+// can enqueue its proof's ProveKnowledge MSM, prove, and collect (pool.hip); host values in, affine point out.
+static int32_t pedersen_enqueue(mi_ctx *ctx, const void *bases_dev, size_t key_n, const mi_fr *values, size_t n) {
+    if (!ctx || (!values && n)) return MI_EINVAL;
     if (n > key_n) MI_FAIL(ctx, MI_EINVAL, "pedersen: more values than basis points");   // gnark: "must have as many values as basis elements"
     MI_TRY(mi_reserve(ctx, ctx->ws[19], n * sizeof(mi_fr) + 64));
-    if (n) MI_CHECK_HIP(ctx, hipMemcpyAsync(ctx->ws[19].p, values, n * sizeof(mi_fr), hipMemcpyHostToDevice, ctx->stream));
-    MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[14], ctx->stream));
-    MI_TRY(mi_msm_enqueue(ctx, 5, -1, 1, bases_dev, ctx->ws[19].p, n, 0, ctx->ev[14], false));
+    if (n) MI_CHECK_HIP(ctx, hipMemcpyAsync(ctx->ws[19].p, values, n * sizeof(mi_fr), hipMemcpyHostToDevice, ctx->msm[5].stream));
+    return mi_msm_enqueue(ctx, 5, -1, 1, bases_dev, ctx->ws[19].p, n, 0, nullptr, false);
+}
+static int32_t pedersen_collect(mi_ctx *ctx, mi_g1_affine *out) {
     G1X r;
     MI_TRY(mi_msm_finish(ctx, 5, 1, &r));
     G1Aff a = xyzz_to_affine(r);
-    std::memcpy(out, &a, sizeof(a));
+    if (out) std::memcpy(out, &a, sizeof(a));
     return MI_OK;
 }
+static int32_t pedersen_msm(mi_ctx *ctx, const void *bases_dev, size_t key_n, const mi_fr *values, size_t n, mi_g1_affine *out) {
+    if (!out) return MI_EINVAL;
+    MI_TRY(pedersen_enqueue(ctx, bases_dev, key_n, values, n));
+    return pedersen_collect(ctx, out);
+}
+int32_t mi_pedersen_pok_enqueue(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n) {
+    if (!pk) return MI_EINVAL;
+    return pedersen_enqueue(ctx, pk->basis_exp_sigma, pk->n, values, n);
+}
+int32_t mi_pedersen_pok_collect(mi_ctx *ctx, mi_g1_affine *pok) { return pedersen_collect(ctx, pok); }
 
 extern "C" {
 int32_t mi_pedersen_pk_load(mi_ctx *ctx, const mi_g1_affine *basis, const mi_g1_affine *basis_exp_sigma, size_t n, mi_pedersen_pk **out) {
@@ -359,7 +372,7 @@ int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEv
     std::future<int32_t> fb;
     int32_t rb = MI_OK;
     try {
-        fb = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer, nullptr); });
+        fb = std::async(std::launch::async, [=]() -> int32_t { try { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer, nullptr); } catch (...) { return MI_ENOMEM; } });
     } catch (...) {
         rb = mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, defer, nullptr);
     }
@@ -374,15 +387,27 @@ int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h, hipEvent_
     return mi_msm_enqueue(ctx, 4, -1, 1, pk->g1_z, h, pk->n_z_msm, df, ev_h, true, 0, 0, pk->gen_c_z);
 }
 
+// a host helper thread for one independent scalar multiplication; without a thread to be had the work runs here (no exception may
+// cross the C-ABI: std::async throws std::system_error when the process is out of threads)
+template <class Fn>
+static auto async_or_inline(Fn fn) -> std::future<decltype(fn())> {
+    try {
+        return std::async(std::launch::async, fn);
+    } catch (...) {
+        std::promise<decltype(fn())> p;
+        p.set_value(fn());
+        return p.get_future();
+    }
+}
 void ProofAssembler::start(const mi_pk *pk_, const mi_fr *r_m, const mi_fr *s_m) {
     pk = pk_;
     Fr r, s;
     std::memcpy(&r, r_m, 32); std::memcpy(&s, s_m, 32);
     rc = fe_from_mont(r); sc = fe_from_mont(s); krc = fe_from_mont(fe_neg(r * s));
     // (independent 256-bit scalar multiplications: one host thread each; for small circuits they are the longest chain)
-    f_r = std::async(std::launch::async, [this] { return host_scalar_mul<Fp>(pk->delta1, rc); });
-    f_s = std::async(std::launch::async, [this] { return host_scalar_mul<Fp>(pk->delta1, sc); });
-    f_kr = std::async(std::launch::async, [this] { return host_scalar_mul<Fp>(pk->delta1, krc); });
+    f_r = async_or_inline([this] { return host_scalar_mul<Fp>(pk->delta1, rc); });
+    f_s = async_or_inline([this] { return host_scalar_mul<Fp>(pk->delta1, sc); });
+    f_kr = async_or_inline([this] { return host_scalar_mul<Fp>(pk->delta1, krc); });
     s_delta2 = host_scalar_mul<Fp2>(pk->delta2, sc);
     r_delta = f_r.get(); s_delta = f_s.get(); kr_delta = f_kr.get();
 }
@@ -394,7 +419,7 @@ void ProofAssembler::have_a_b1(const G1X &msm_a, const G1X &msm_b1) {
     xyzz_madd(bs1, pk->beta1, false);
     xyzz_add(bs1, s_delta);
     ar_aff = xyzz_to_affine(ar); bs1_aff = xyzz_to_affine(bs1);
-    f_sar = std::async(std::launch::async, [this] { return host_scalar_mul<Fp>(ar_aff, sc); });   // overlaps the remaining MSMs
+    f_sar = async_or_inline([this] { return host_scalar_mul<Fp>(ar_aff, sc); });   // overlaps the remaining MSMs
     r_bs1 = host_scalar_mul<Fp>(bs1_aff, rc);
 }
 void ProofAssembler::finish(const G1X &msm_k, const G2X &msm_b2, const G1X &msm_z, mi_proof_out *out) {
@@ -423,7 +448,11 @@ struct AbcGate { const std::function<bool()> *abc; bool abc_arrived; /* a, b, c 
 static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                             size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, mi_proof_out *out, mi_stats *stats, const HostInputs *host,
                             const AbcGate *gate = nullptr) {
-    if (!ctx || !pk || !W || !a || !b || !c || !r_m || !s_m || !out) return MI_EINVAL;
+    if (!ctx || !pk || !r_m || !s_m || !out) return MI_EINVAL;
+    // null W / a / b only where the matching count is 0 (the header's rule, as the pool's submit applies it); c == null: c = a o b on the device
+    if ((!W && n_wires) || ((!a || !b) && n_constraints)) MI_FAIL(ctx, MI_EINVAL, "prove: null W, a or b with a non-zero count");
+    if (host && ((!host->W && n_wires) || ((!host->a || !host->b) && n_constraints))) MI_FAIL(ctx, MI_EINVAL, "prove: null host W, a or b with a non-zero count");
+    const bool derive_c = host ? !host->c : !c;
     const size_t N = (size_t)1 << pk->log_n;
     if (pk->wire_lo || pk->n_z_msm != N - 1) MI_FAIL(ctx, MI_EINVAL, "prove: this key is one part of a sharded key (use mi_groth16_prove_sharded)");
     if (n_wires != pk->nb_wires || n_constraints > N) MI_FAIL(ctx, MI_EINVAL, "prove: witness size does not match the proving key");
@@ -443,7 +472,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     const std::shared_future<hipEvent_t> h_fut = h_recorded.get_future().share();
     const std::function<hipEvent_t()> h_gate = [h_fut] { return h_fut.get(); };
     auto enqueue_h_and_z = [&]() -> int32_t {
-        MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, c, n_constraints, (mi_fr *)h));
+        MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, derive_c ? nullptr : c, n_constraints, (mi_fr *)h));
         MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
         h_recorded.set_value(ev[3]); h_promised = true;
         return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);
@@ -469,12 +498,12 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
             return;
         }
         try {
-            f_b = std::async(std::launch::async, [=] { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, false, g); });
+            f_b = std::async(std::launch::async, [=]() -> int32_t { try { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, false, g); } catch (...) { return MI_ENOMEM; } });
         } catch (...) {   // no thread to be had: this thread does it (without the hold: it would wait for itself); no exception crosses the C-ABI
             rc_inline = mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, false, nullptr);
         }
         try {
-            f_ak = std::async(std::launch::async, [=] { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, false, g); });
+            f_ak = std::async(std::launch::async, [=]() -> int32_t { try { return mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, false, g); } catch (...) { return MI_ENOMEM; } });
         } catch (...) {
             const int32_t r = mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, false, nullptr);
             if (rc_inline == MI_OK) rc_inline = r;
@@ -524,9 +553,10 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         MI_TRY(mi_compute_h_part(ctx, pk->log_n, 0, a, n_constraints, (mi_fr *)h));
         MI_TRY(upload(b, host->b, cb));
         MI_TRY(mi_compute_h_part(ctx, pk->log_n, 1, b, n_constraints, (mi_fr *)h));
-        MI_TRY(upload(c, host->c, cb));
+        if (!derive_c) MI_TRY(upload(c, host->c, cb));   // (derive_c: a quarter of the proof's PCIe bytes never crosses)
         ctx->stats.h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_up).count();
-        MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, c, n_constraints, (mi_fr *)h));
+        if (derive_c) MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, a, n_constraints, (mi_fr *)h, b));
+        else MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, c, n_constraints, (mi_fr *)h));
         MI_TRY(mi_compute_h_part(ctx, pk->log_n, 3, nullptr, n_constraints, (mi_fr *)h));
         MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
         h_recorded.set_value(ev[3]); h_promised = true;
@@ -600,7 +630,7 @@ int32_t mi_groth16_prove_dev(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wi
 }
 int32_t mi_groth16_prove(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                          size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats) {
-    if (!ctx || !pk || !W || !a || !b || !c || !r || !s || !out) return MI_EINVAL;
+    if (!ctx || !pk || !r || !s || !out) return MI_EINVAL;   // W, a, b: checked against their counts in prove_common; c == null: c = a o b
     const size_t wb = n_wires * 32, cb = n_constraints * 32;
     MI_TRY(mi_reserve(ctx, ctx->ws[16], wb + 3 * cb + 128));
     char *base = (char *)ctx->ws[16].p;

@@ -43,6 +43,9 @@ struct ShardRange { u64 w_lo, w_hi, z_lo, z_hi; };   // wires [w_lo, w_hi), Z pa
 int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool device_points, const ShardRange *sr, bool adopt = false, bool *took_arrays = nullptr);
 // a Pedersen key over device arrays the key takes ownership of (mi_pk_load_raw)
 extern "C" int32_t mi_pedersen_pk_adopt(mi_ctx *ctx, void *basis_dev, void *basis_exp_sigma_dev, size_t n, mi_pedersen_pk **out);
+// ProveKnowledge of one BSB22 commitment in two halves on slot 5 of ctx (beside a proof's five MSMs): host values in, affine point out
+int32_t mi_pedersen_pok_enqueue(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n);
+int32_t mi_pedersen_pok_collect(mi_ctx *ctx, mi_g1_affine *pok_or_null);
 // The wire MSMs (A, B1, B2, K on slots 0..3) over W_dev = this key's wire range, ordered after ev_w; the Z MSM (slot 4) over
 // h_dev = this key's first h coefficient, ordered after ev_h.  defer_reduce: stop each MSM at its bucket sums (group.hip
 // exchanges them between devices before the reduce, SURVEY 8e option ii).

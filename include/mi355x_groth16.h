@@ -156,7 +156,7 @@ int32_t mi_ntt(mi_ctx *ctx, mi_fr *inout, uint32_t log_n, uint32_t flags);
 int32_t mi_ntt_dev(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t flags);
 
 /* ---- computeH (gnark prove.go): a, b, c have n_constraints entries, zero-padded to 2^log_n;
- * h_out receives 2^log_n elements in the bit-reversed order gnark leaves them in ---- */
+ * h_out receives 2^log_n elements in the bit-reversed order gnark leaves them in.  c == NULL: c = a o b (see mi_groth16_prove) ---- */
 int32_t mi_compute_h(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                      size_t n_constraints, mi_fr *h_out);
 int32_t mi_compute_h_dev(mi_ctx *ctx, uint32_t log_n, const mi_fr *a_dev, const mi_fr *b_dev,
@@ -188,7 +188,11 @@ int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_f
  * W: nb_wires wire values; a, b, c: n_constraints values each (solution.A/B/C);
  * r, s: the two blinding scalars gnark samples with fr.SetRandom (passed in so that CPU and
  * GPU proofs of the same (pk, witness, r, s) are byte-identical — SURVEY section 7 H1).
- * stats may be NULL. ---- */
+ * stats may be NULL.
+ * c may be NULL (every prove / submit / compute_h entry point): c is then formed on the device as a o b, row by row, on the way into
+ * its transform -- what solution.C is for every witness gnark's solver accepts (the solver returns satisfied constraints only), so
+ * the proof bytes are the same and a quarter of a host-input proof's PCIe bytes never crosses.  Pass c when a, b, c may NOT satisfy
+ * a o b = c (gnark's computeH does not assume it, and neither does the general path). ---- */
 int32_t mi_groth16_prove(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires,
                          const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
                          const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats);
@@ -238,6 +242,22 @@ int32_t mi_prover_submit_dev(mi_prover *p, mi_pk *pk, const mi_fr *W_dev, size_t
                              const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev, size_t n_constraints,
                              const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket);
 int32_t mi_prover_wait(mi_prover *p, uint64_t ticket);
+/* The proof the WHIR circuit really produces carries one BSB22 commitment (/root/reference/utilities/utilities.go:189
+ * logderivlookup.New and mtUtilities.go:452 uints.New force it: SURVEY 3.3 steps 1 and 3, row a10).  Through the pool:
+ *   mi_prover_commit        pedersen Commit INSIDE the solve (the hint override): synchronous, callable from any thread, one
+ *                           commitment at a time on a context of the pool's own; the SHA-256 hash-to-field stays in Go.
+ *   mi_prover_submit_bsb22  mi_prover_submit (host inputs) whose job also computes the proof's CommitmentPok as prove.go does --
+ *                           pedersen.BatchProve: sum_i challenge^i * ProveKnowledge_i(values_i) -- with the MSM over BasisExpSigma
+ *                           riding beside the proof's five MSMs.  commitments[i].values (host memory, the private committed values
+ *                           the hint received) and pok_out must stay valid until mi_prover_wait; challenge is copied.  The key pk
+ *                           must have been loaded with the committed wires removed from K (mi_pk_desc.committed_wires).
+ * Proof.WriteTo of the result: mi_proof_write(out, commitments, n, pok) = 164 + 32 n bytes (196 for the WHIR circuit). */
+typedef struct mi_bsb22_input { mi_pedersen_pk *key; const mi_fr *values; size_t n; } mi_bsb22_input;
+int32_t mi_prover_commit(mi_prover *p, mi_pedersen_pk *key, const mi_fr *values, size_t n, mi_g1_affine *commitment);
+int32_t mi_prover_submit_bsb22(mi_prover *p, mi_pk *pk, const mi_fr *W, size_t n_wires,
+                               const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
+                               const mi_fr *r, const mi_fr *s, const mi_bsb22_input *commitments, uint32_t n_commitments,
+                               const mi_fr *challenge, mi_proof_out *out, mi_g1_affine *pok_out, mi_stats *stats, uint64_t *ticket);
 
 /* ---- device groups: one proof / one MSM point-sharded over several GPUs (BASELINE configs[4]).
  * The reference's single call groth16.Prove (mt.go:496) knows no devices; a Go caller that wants one proof spread over the
@@ -254,7 +274,11 @@ int32_t mi_prover_wait(mi_prover *p, uint64_t ticket);
  * call on the same group is still running returns MI_EINVAL at once and touches nothing (the exchange streams and receive
  * buffers belong to the running call).  A process holds either ALL ranks of a group (mi_group_create) or exactly ONE
  * (mi_group_create_rank); with one rank per process every process makes the same calls in the same order (they are
- * collectives), each with its own rank's data. ---- */
+ * collectives), each with its own rank's data.
+ * Failures are collective too: before every exchange the ranks agree on their status (one small all-gather), so a call either succeeds
+ * on every rank or returns an error on every rank -- the failing rank its own, the others "rank r failed" -- with every MSM slot
+ * drained; nobody is left waiting in an exchange.  Only a failure INSIDE an exchange (a dead peer, an RCCL error) breaks the group:
+ * later calls on it return MI_EHIP until it is destroyed and created anew. ---- */
 typedef struct mi_group mi_group;
 typedef struct mi_pk_sharded mi_pk_sharded;
 /* all ranks in this process, one context per entry of dev_ids (SURVEY 8b proposed mi_init(dev_ids, n_dev, ...)).  Distinct
@@ -262,13 +286,21 @@ typedef struct mi_pk_sharded mi_pk_sharded;
 int32_t mi_group_create(const int *dev_ids, int n_dev, mi_group **out);
 /* one rank per process: id = mi_group_unique_id() from rank 0, handed to the others by the caller's own channel */
 int32_t mi_group_unique_id(uint8_t id[128]);
-int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t id[128], mi_group **out);
+int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t id[128], mi_group **out);   /* = _ex(..., MI_GROUP_TRANSPORT_RCCL, ...) */
+/* the same with the transport named.  MI_GROUP_TRANSPORT_HOST: the processes meet in a POSIX shared-memory segment named after the 128
+ * id bytes (any 128 bytes all ranks share; mi_group_unique_id is not needed) and slices travel device -> segment -> device.  For ranks
+ * RCCL cannot connect: two processes on ONE device (RCCL refuses two ranks per device; how a 1-GPU box rehearses this flow) or a box
+ * without a working RCCL fabric.  Every wait has a deadline (MI_GROUP_TIMEOUT_MS, default 60000): a peer that died is an error. */
+#define MI_GROUP_TRANSPORT_RCCL 1
+#define MI_GROUP_TRANSPORT_HOST 3
+int32_t mi_group_create_rank_ex(int device_id, int rank, int world, const uint8_t id[128], int transport, mi_group **out);
 int32_t mi_group_destroy(mi_group *g);
 int32_t mi_group_world(const mi_group *g);
 int32_t mi_group_local(const mi_group *g);                 /* ranks held by this process */
 mi_ctx *mi_group_ctx(mi_group *g, int local_rank);         /* for mi_dev_* / generators on that rank's device */
 const char *mi_group_last_error(mi_group *g);
-int32_t mi_group_transport(const mi_group *g);             /* 1 = RCCL, 2 = peer copies */
+int32_t mi_group_rank(const mi_group *g);                  /* global rank of this process's first local rank */
+int32_t mi_group_transport(const mi_group *g);             /* 1 = RCCL, 2 = copies inside one process, 3 = host-staged (shared memory) */
 /* transport check: every rank sends `bytes` patterned bytes to every rank (itself included) and verifies what it received */
 int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes);
 /* desc: the same whole-key descriptor as mi_pk_load (host arrays); with one rank per process every process passes the whole

@@ -189,3 +189,57 @@ def test_pool_host_inputs_at_2p20_early_handover_and_ledger():
         d.free()
     c0.pk_free(pkh)
     pool.close()
+
+
+def test_c_formed_on_the_device_gives_the_same_proofs():
+    """c == NULL on every prove entry point: c = a o b is formed on the device (mi_groth16_prove[_dev], mi_prover_submit[_dev]); the
+    proof bytes are those of the oracle, which is handed c explicitly"""
+    B = load_binding()
+    pk, jobs = _jobs(13, 4, 4300)
+    want = [cref.proof_write(cref.prove(pk, *j)["raw"]) for j in jobs]
+    pool = B.Prover(0, 2)
+    c0 = pool.ctx(0)
+    pkh = c0.pk_load(pk)
+    tickets = [pool.submit(pkh, W, a, b, None, r, s) for (W, a, b, c, r, s) in jobs]        # host inputs, no c
+    for t, w in zip(tickets, want):
+        assert B.proof_write(pool.wait(t)[0]["raw"]) == w
+    W, a, b, c, r, s = jobs[0]
+    dW, da, db = c0.to_dev(W), c0.to_dev(a), c0.to_dev(b)
+    c0.sync()
+    t = pool.submit(pkh, dW.ptr, da.ptr, db.ptr, None, r, s, device=True, n_wires=W.shape[0], n_constraints=a.shape[0])   # device inputs, no c
+    assert B.proof_write(pool.wait(t)[0]["raw"]) == want[0]
+    single = B.Context(0)
+    assert B.proof_write(single.prove(pkh, W, a, b, None, r, s)[0]["raw"]) == want[0]                                       # one context, host inputs
+    assert B.proof_write(single.prove(pkh, dW.ptr, da.ptr, db.ptr, None, r, s, device=True, n_wires=W.shape[0], n_constraints=a.shape[0])[0]["raw"]) == want[0]
+    h_full = single.compute_h(13, a, b, c)
+    assert np.array_equal(single.compute_h(13, a, b, None), h_full)
+    # a, b, c that do NOT satisfy a o b = c: the general path must still be gnark's computeH (c is used, not re-derived)
+    c_other = cref.gen_scalars(a.shape[0], 77, 0)
+    assert np.array_equal(single.compute_h(13, a, b, c_other), cref.compute_h(13, a, b, c_other))
+    single.close()
+    for d in (dW, da, db):
+        d.free()
+    c0.pk_free(pkh)
+    pool.close()
+
+
+def test_host_job_that_fails_before_its_gate_waits_for_its_uploads():
+    """a host job handed to an idle worker as soon as W is resident can fail BEFORE it reaches the a, b, c gate (here: a
+    witness whose length does not match the key).  The job must not complete -- its waiter frees the caller's a, b, c -- while the
+    uploader is still copying them.  The job's h2d_ms is written by the uploader after its last copy: a job that completed early would
+    report 0 (and, under a sanitizer, a use after free)."""
+    B = load_binding()
+    pk, jobs = _jobs(16, 2, 4400)
+    W, a, b, c, r, s = jobs[0]
+    pool = B.Prover(0, 2)
+    c0 = pool.ctx(0)
+    pkh = c0.pk_load(pk)
+    assert B.proof_write(pool.wait(pool.submit(pkh, W, a, b, c, r, s))[0]["raw"]) == cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    for _ in range(3):   # idle workers: the early hand-over happens
+        t = pool.submit(pkh, W[:-1], a, b, c, r, s)
+        with pytest.raises(B.MiError, match="witness size"):
+            pool.wait(t)
+    # and the pool goes on proving
+    assert B.proof_write(pool.wait(pool.submit(pkh, W, a, b, c, r, s))[0]["raw"]) == cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    c0.pk_free(pkh)
+    pool.close()
