@@ -1,18 +1,23 @@
 """bench.py --gpus N --steps K --warmup W
 
-One step = one full Groth16 prove (computeH: gnark's 7 NTTs of size 2^23, done with 6; 4 G1 MSMs + 1 G2 MSM; blinding and
-assembly) of the synthetic WHIR-verifier-shaped workload of BASELINE.json configs[1] (2^20-variable
-multilinear -> FFT domain N = 2^23) with the proving key, the witness W and the
-solution vectors a, b, c already resident in HBM.  The K steps go through the prover pool (mi_prover_*: --in-flight
-proofs overlap on the GPU, default 3; every step is submitted and completed inside the timed region; the line also
-carries the latency of one proof alone).  N > 1 GPUs: one independent pool per GPU (configs[3], no data-path
-collective) -> weak scaling, value = proofs of all ranks / max-rank time.
+One step = the proof the WHIR-verifier circuit REALLY produces (reference mt.go:496 after gnark's solve), on the path a caller can
+reach: W, a, b in HOST memory (Go slices, mt.go:494-496; c = a o b is formed on the device), one BSB22 commitment
+(utilities/utilities.go:189 logderivlookup.New and mtUtilities.go:452 uints.New force it into every proof):
+    pedersen Commit (synchronous, as inside the solve)  ->  groth16 prove: computeH (gnark's 7 NTTs of size 2^23, done with 6),
+    4 G1 MSMs + 1 G2 MSM with the committed wires removed from K, the commitment's ProveKnowledge MSM beside them, fold  ->
+    Proof.WriteTo = 196 bytes, compared with the oracle's bytes.
+Workload: the synthetic WHIR-verifier-shaped key / witness of BASELINE.json configs[1] (2^20-variable multilinear -> FFT domain
+N = 2^23).  The K steps are issued by in_flight + 1 caller threads through the prover pool (mi_prover_*: --in-flight
+proofs overlap on the GPU, default 3 -- a prover service calling groth16.Prove from several goroutines); every step starts and
+completes inside the timed region.  N > 1 GPUs: one independent pool per GPU (configs[3], no data-path collective) -> weak scaling,
+value = proofs of all ranks / max-rank time.  `python bench.py --gpus N` launched PLAINLY starts its N rank processes itself
+(children, before any GPU call); under torch.distributed.run it uses the ranks it is given.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant
-kernel (G1 level-1 bucket accumulate), `roofline_ntt`, `random_gather` / `valu` (the two ceilings that kernel runs
-against), `value_host_inputs` (the same K steps with host-pointer inputs, the cgo path), `sharded_msm` (BASELINE
-configs[4] through the C-ABI's device group) and `cpu_baseline` (the oracle's C restatement on the host cores, rank 0,
-N = 1 only: one full prove of the benchmarked workload itself, proof bytes compared with the GPU's).
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the dominant kernel (G1 level-1 bucket
+accumulate), `roofline_ntt`, `random_gather` / `valu` (the two ceilings that kernel runs against), `value_hbm_resident_inputs` (the
+GPU-side rate: the same key, inputs already in HBM, no commitment), the single-proof latencies, `sharded_msm` / `sharded_prove`
+(BASELINE configs[4] through the C-ABI's device group) and `cpu_baseline` (the oracle's C restatement on the host cores, rank 0,
+N = 1 only: the whole step of the benchmarked workload itself -- Commit, ProveKnowledge, fold, prove -- 196 bytes compared).
 """
 import argparse
 import importlib.util
@@ -40,41 +45,35 @@ def _sha16(path):
         return None
 
 
-def _last_commit(rel):
-    """hash of the last commit that touched `rel` (None where there is no git history, e.g. on the GPU box's snapshot: the sha256 of
-    the file's bytes next to it identifies the file there)"""
-    import subprocess
-    try:
-        out = subprocess.run(["git", "-C", ROOT, "log", "-n", "1", "--format=%h", "--", rel], capture_output=True, text=True, timeout=10)
-        return out.stdout.strip() or None
-    except Exception:
-        return None
-
-
-def cpu_baseline(pk_host, W, a, b, c, r, s, log_n, gpu_proof_bytes):
-    """Times the oracle's prove (oracle/groth16_ref.c, OpenMP, all host cores) ON THE BENCHMARKED WORKLOAD ITSELF -- the
-    same key, witness, solution vectors and (r, s) the GPU proofs above used, downloaded from the device -- and compares
-    its proof bytes with the GPU's (same run, identical inputs, byte for byte).  No extrapolation.
+def cpu_baseline(pk_host, W, a, b, c, r, s, ped, log_n, gpu_proof_bytes):
+    """Times the oracle (oracle/groth16_ref.c, OpenMP, all host cores) ON THE BENCHMARKED STEP ITSELF -- the same key, witness, solution
+    vectors, (r, s), Pedersen key, committed values and challenge the GPU proofs above used, downloaded from the device -- and compares
+    its 196 proof bytes with the GPU's (same run, identical inputs, byte for byte).  No extrapolation.
     The oracle is the checker and the reported baseline, never the product."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cref
     cref.WAIT_POLICY = None   # keep libgomp's default (spinning) waits for the timed sample: the CPU side at its best
     runs = []
-    want = None
+    cpu_bytes = None
     for _ in range(2):   # the first call also spins up the OpenMP team; a second one only if the first was short
         t0 = time.perf_counter()
+        if ped is not None:
+            basis, sigma, values, challenge = ped
+            cm = cref.pedersen_msm(basis, values)                                        # Commit (inside the solve in gnark)
+            pok = cref.pedersen_fold(cref.pedersen_msm(sigma, values).reshape(1, 8), challenge)   # ProveKnowledge + fold
         want = cref.prove(pk_host, W, a, b, c, r, s)
         runs.append(time.perf_counter() - t0)
+        cpu_bytes = cref.proof_write(want["raw"], cm.reshape(1, 8), pok) if ped is not None else cref.proof_write(want["raw"])
         if sum(runs) > 25.0:
             break
-    cpu_bytes = cref.proof_write(want["raw"])
+    n_vals = 0 if ped is None else ped[2].shape[0]
     if cpu_bytes != gpu_proof_bytes:
         raise SystemExit("bench.py: GPU proof bytes differ from the oracle's proof bytes on the same inputs")
     dt = min(runs)
     return {"value": 1.0 / dt, "unit": "proofs/s", "cores": cref.num_threads(), "kind": "port",
-            "sample": f"N=2^{log_n}, measured: full prove of the benchmarked workload itself (same pk, W, a, b, c, r, s; best of {len(runs)}: "
-                      f"{dt:.2f} s on {cref.num_threads()} threads); proof bytes equal the GPU proof's ({len(cpu_bytes)} B compared)",
-            "proof_bytes_match": True}
+            "sample": f"N=2^{log_n}, measured: the whole benchmarked step itself (Commit + ProveKnowledge + fold over {n_vals} committed values, prove; same pk, W, a, b, c, r, s; "
+                      f"best of {len(runs)}: {dt:.2f} s on {cref.num_threads()} threads); proof bytes equal the GPU proof's ({len(cpu_bytes)} B compared)",
+            "proof_bytes_match": True, "proof_bytes_compared": len(cpu_bytes)}
 
 
 def sharded_msm_section(B, g, rank, world, log_n_msm, steps):
@@ -200,8 +199,8 @@ def sharded_helper_main():
     """`bench.py --sharded-helper`: started by main() BEFORE the parent touches the GPU (a process that has initialised the GPU must not
     exec), idle until the parent writes one JSON line of parameters, then runs the multi-GPU legs on its own GPU context -- the
     transport self-test first (a broken communicator is diagnosed, not timed out), the point-sharded MSM, the point-sharded PROVE --
-    and answers with one JSON line.  A fault or a stuck collective in these never-before-multi-GPU paths then costs the parent
-    nothing but the `sharded_*` blocks of its line."""
+    and answers with one JSON line.  A fault or a stuck collective in these paths then costs the parent nothing but the `sharded_*`
+    blocks of its line."""
     req = sys.stdin.readline()
     if not req.strip():
         return
@@ -214,7 +213,7 @@ def sharded_helper_main():
     g = None
     try:
         B = _binding()
-        g = B.Group.rank(q["local_rank"], q["rank"], q["world"], bytes.fromhex(q["uid"]))
+        g = B.Group.rank(q["local_rank"], q["rank"], q["world"], bytes.fromhex(q["uid"]), transport=q.get("transport", 1))
         try:
             g.exchange_selftest(1 << 20)
             res["selftest"] = "ok"
@@ -240,24 +239,27 @@ def sharded_helper_main():
 
 
 def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
-    """configs[4] through the C-ABI's device group (RCCL), in the helper process started at the top of main(): the transport self-test,
-    one G1 MSM point-sharded over the ranks, and ONE PROOF point-sharded over the ranks.  Bounded by a watchdog: a stuck collective or
-    a fault there must not cost the run its proofs/s line.  Called after this process has released its own pool, key and buffers
-    (an N = 2^26 proof wants most of a GPU)."""
+    """configs[4] through the C-ABI's device group, in the helper process started at the top of main(): the transport self-test, one G1
+    MSM point-sharded over the ranks, and ONE PROOF point-sharded over the ranks.  Transport: RCCL with one rank per GPU; the
+    host-staged one (shared memory) with --rehearse-on-one-gpu, where every rank sits on device 0 and RCCL would refuse.  Bounded by a
+    watchdog: a stuck collective or a fault there must not cost the run its proofs/s line.  Called after this process has released its
+    own pool, key and buffers (an N = 2^26 proof wants most of a GPU)."""
     import threading
     sharded, sharded_prove = {"done": False}, {"done": False}
+    transport = 3 if args.rehearse_on_one_gpu else 1
+    dev = "cpu" if args.rehearse_on_one_gpu else torch.device("cuda", local_rank)
     uid = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:
-        uid = torch.tensor(list(B.Group.unique_id()), dtype=torch.uint8)
+        uid = torch.tensor(list(os.urandom(128) if transport == 3 else B.Group.unique_id()), dtype=torch.uint8)
     if dist is not None:
-        t = uid.to(torch.device("cuda", local_rank)); dist.broadcast(t, src=0); uid = t.cpu()
+        t = uid.to(dev); dist.broadcast(t, src=0); uid = t.cpu()
         dist.barrier()
     steps_msm, steps_prove = 3, 3
     answer = {}
 
     def ask():
         try:
-            helper.stdin.write(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "uid": bytes(uid.tolist()).hex(),
+            helper.stdin.write(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "uid": bytes(uid.tolist()).hex(), "transport": transport,
                                            "log_n": args.sharded_msm_log_n, "steps": steps_msm,
                                            "prove_log_n": args.sharded_prove_log_n, "prove_steps": steps_prove}) + "\n")
             helper.stdin.flush()
@@ -286,15 +288,16 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
     v = [ok, float(m.get("dt0", 0.0)), float(m.get("dt1", 0.0)), 1.0 if m.get("modes_agree") else 0.0]
     w = [okp, float(pv.get("dt0", 0.0)), float(pv.get("dt1", 0.0))]
     if dist is not None:   # every rank takes part, whatever its helper did: all ok?  slowest rank's times; all agree?
-        tmin = torch.tensor([v[0], v[3], w[0]], device="cuda", dtype=torch.float64); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        tmax = torch.tensor([v[1], v[2], w[1], w[2]], device="cuda", dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmin = torch.tensor([v[0], v[3], w[0]], device=dev, dtype=torch.float64); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        tmax = torch.tensor([v[1], v[2], w[1], w[2]], device=dev, dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         v = [float(tmin[0]), float(tmax[0]), float(tmax[1]), float(tmin[1])]
         w = [float(tmin[2]), float(tmax[2]), float(tmax[3])]
     n_msm = 1 << args.sharded_msm_log_n
     sharded["selftest"] = sharded_prove["selftest"] = res.get("selftest", "not run")
+    devices = "ONE device shared by all ranks (rehearsal: the multi-process code path, not a scaling measurement)" if args.rehearse_on_one_gpu else f"{world} device(s)"
     if v[0] == 1.0 and v[1] > 0 and v[2] > 0:
         sharded.update({"workload": f"one G1 MSM, 2^{args.sharded_msm_log_n} uniform pairs, bases point-sharded over {world} rank(s) (BASELINE configs[4])",
-                        "scaling": "strong", "transport": res.get("transport"), "steps": steps_msm, "process": "helper process per rank (own GPU context)",
+                        "scaling": "strong", "transport": res.get("transport"), "devices": devices, "steps": steps_msm, "process": "helper process per rank (own GPU context)",
                         "mode0_partial_sums_pts_per_s": n_msm * steps_msm / v[1], "mode0_ms": v[1] / steps_msm * 1e3,
                         "mode1_bucket_exchange_pts_per_s": n_msm * steps_msm / v[2], "mode1_ms": v[2] / steps_msm * 1e3,
                         "modes_agree": v[3] == 1.0, "done": True})
@@ -305,13 +308,14 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
     if w[0] == 1.0 and w[1] > 0 and w[2] > 0:
         sharded_prove.update({"workload": f"ONE Groth16 proof, FFT domain N=2^{args.sharded_prove_log_n}, WHIR-verifier-shaped synthetic key point-sharded over {world} rank(s): "
                                           "slice r of pk.G1.{A,B,K,Z} / pk.G2.B resident on rank r, computeH on rank 0, h slices over the group's transport (BASELINE configs[4])",
-                              "scaling": "strong", "transport": res.get("transport"), "steps": steps_prove, "inputs": "resident in HBM (mi_groth16_prove_sharded_dev)",
+                              "scaling": "strong", "transport": res.get("transport"), "devices": devices, "steps": steps_prove, "inputs": "resident in HBM (mi_groth16_prove_sharded_dev)",
                               "mode0_partial_sums_ms_per_proof": w[1] / steps_prove * 1e3, "mode0_proofs_per_s": steps_prove / w[1],
                               "mode1_bucket_exchange_ms_per_proof": w[2] / steps_prove * 1e3, "mode1_proofs_per_s": steps_prove / w[2],
                               "modes_agree": pv.get("modes_agree"), "equals_unsharded_prove": pv.get("equals_unsharded"),
                               "small_parity": pv.get("small_parity"), "compute_h_ms_on_rank0": pv.get("compute_h_ms_on_rank0"),
                               "pk_load_sharded_s": pv.get("pk_load_sharded_s"),
-                              "note": "ranks on distinct devices have only ever run if n_gpus > 1 in this line; with n_gpus = 1 this is the same code path over a world-1 RCCL communicator",
+                              "note": "NO SCALING CURVE EXISTS until this runs with n_gpus > 1 on distinct devices: with n_gpus = 1 this is the same code path over a world-1 RCCL "
+                                      "communicator; the one-rank-per-process flow with world 2 and 3 is parity-tested on one GPU over the host-staged transport (tests/test_gpu_group_multiprocess.py)",
                               "done": True})
     elif not args.sharded_prove_log_n:
         sharded_prove["skipped"] = "--sharded-prove-log-n 0"
@@ -324,15 +328,46 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
     return sharded, sharded_prove
 
 
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes as CHILDREN of this process -- which has not touched
+    the GPU and never will -- with the environment torch.distributed.run would give them, relay rank 0's JSON line, and exit with the
+    worst child status.  (A re-exec of this process would do as well here, but the rule is: children, before any GPU call.)"""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    line = None
+    for ln in procs[0].stdout:   # rank 0 prints the line; anything else it writes to stdout goes to stderr here
+        if ln.lstrip().startswith("{"):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rcs = [p.wait() for p in procs]
+    if line is not None:
+        print(line, flush=True)
+    bad = [rc for rc in rcs if rc != 0]
+    if bad or line is None:
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        sys.exit(bad[0] if bad else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)   # ~1.1 s of proofs: one rare runtime hiccup then moves the result by < 2 %
+    ap.add_argument("--steps", type=int, default=30)   # ~1 s of proofs: one rare runtime hiccup then moves the result by < 2 %
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=23, help="FFT domain (2^23 = BASELINE configs[1])")
     ap.add_argument("--dist", choices=["whir", "uniform"], default="whir")
+    ap.add_argument("--n-committed", type=int, default=-1,
+                    help="private wires under the proof's ONE BSB22 commitment (lookup operands; default 2^18 = N / 32, a documented estimate like the infinity ratios; 0 = a circuit without lookups: 164-byte proofs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-inputs", action="store_true", help="skip the second timed region (host-pointer submits, the cgo path)")
+    ap.add_argument("--no-hbm-resident", action="store_true", help="skip the second timed region (inputs already in HBM, no commitment: the GPU-side rate)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="proofs kept in flight per GPU by the prover pool (mi_prover_*); 1 = strictly one proof at a time; "
                          "0 = 3 up to N=2^24, 1 above (a context's workspaces take about 1.2 KB x N of HBM)")
@@ -348,33 +383,48 @@ def main():
     ap.add_argument("--sharded-msm-log-n", type=int, default=26, help="configs[4]: size of the point-sharded G1 MSM run after the proofs (0 = skip)")
     ap.add_argument("--sharded-prove-log-n", type=int, default=26, help="configs[4]: FFT domain of the ONE proof point-sharded over the ranks, run after the proofs (0 = skip)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="multi-rank control-flow rehearsal on a 1-GPU box: every rank uses device 0 and the collectives run over gloo")
+                    help="multi-rank rehearsal on a 1-GPU box: every rank uses device 0, torch.distributed runs over gloo and the device group over its "
+                         "host-staged transport (size the run to fit: e.g. --log-n 20 --sharded-msm-log-n 22 --sharded-prove-log-n 20)")
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, join them (gloo, no GPU) and print a one-line JSON summary: what the CPU test of the self-launch asserts")
     ap.add_argument("--sharded-helper", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.sharded_helper:
         return sharded_helper_main()
-    # the point-sharded MSM leg runs in a helper process of its own; it is started NOW, before anything here touches the GPU
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus, sys.argv[1:])
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: either launch plainly (bench.py starts its ranks itself) or with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.launch_check:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "world": world, "sum_of_ranks": float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+    # the point-sharded legs run in a helper process of its own; it is started NOW, before anything here touches the GPU
     helper = None
-    if (args.sharded_msm_log_n or args.sharded_prove_log_n) and not args.rehearse_on_one_gpu:
+    if args.sharded_msm_log_n or args.sharded_prove_log_n:
         import subprocess
         helper = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--sharded-helper"], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 
     import torch
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or "RANK" in os.environ:   # launched by torch.distributed.run: one rank per GPU over RCCL
+    if world > 1 or "RANK" in os.environ:   # one rank per GPU over RCCL (launched by torch.distributed.run, or by self_launch above)
         import torch.distributed as dist
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
 
     B = _binding()
     # the prover pool: --in-flight contexts on this rank's GPU (own streams, workspaces, host worker thread), one shared key
@@ -385,10 +435,8 @@ def main():
         assert pool.lib.mi_debug_set_msm_l1_waves(pool.ctx(i).h, args.g1_waves) == 0
         assert pool.lib.mi_debug_set_msm_group_bits(pool.ctx(i).h, args.msm_group_bits) == 0
         assert pool.lib.mi_debug_set_msm_chunk(pool.ctx(i).h, args.msm_chunk) == 0
-        if hasattr(pool.lib, "mi_debug_set_msm_bound_levels"):
-            assert pool.lib.mi_debug_set_msm_bound_levels(pool.ctx(i).h, 1 if args.bound_levels else 0) == 0
-        if hasattr(pool.lib, "mi_debug_set_prove_schedule"):   # (absent from older builds compared through MI355X_GROTH16_LIB)
-            assert pool.lib.mi_debug_set_prove_schedule(pool.ctx(i).h, 1 if args.hold_accum else 0) == 0
+        assert pool.lib.mi_debug_set_msm_bound_levels(pool.ctx(i).h, 1 if args.bound_levels else 0) == 0
+        assert pool.lib.mi_debug_set_prove_schedule(pool.ctx(i).h, 1 if args.hold_accum else 0) == 0
     if args.ntt_plan:
         np_ = [int(x) for x in args.ntt_plan.split(",")]
         for i in range(pool.in_flight):
@@ -409,7 +457,16 @@ def main():
     rng = np.random.default_rng(seed)
     inf_a = (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8)
     inf_b = (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
-    na, nb, nk = int((inf_a == 0).sum()), int((inf_b == 0).sum()), nb_wires - nb_public
+    # the ONE BSB22 commitment of the WHIR circuit: n_committed private wires (the lookup operands: STIR indices, every byte that passes a
+    # range check) + the commitment wire itself leave the K MSM (gnark: PrivateCommitted + CommitmentIndex); the estimate's sensitivity
+    # (2^16 / 2^18 / 2^20) is in profiles/
+    n_committed = args.n_committed if args.n_committed >= 0 else max(1, N >> 5)
+    committed_private = committed_wires = None
+    if n_committed:
+        committed_private = np.sort(np.random.default_rng(seed + 77).choice(nb_wires - 1 - nb_public, n_committed, replace=False).astype(np.uint32) + np.uint32(nb_public))
+        committed_wires = np.concatenate([committed_private, np.array([nb_wires - 1], dtype=np.uint32)])   # the last wire plays CommitmentIndex
+    na, nb = int((inf_a == 0).sum()), int((inf_b == 0).sum())
+    nk = nb_wires - nb_public - (n_committed + 1 if n_committed else 0)
     dist_id = 1 if args.dist == "whir" else 0
     g1a, g1b, g1k, g1z = ctx.gen_g1(na, seed + 1), ctx.gen_g1(nb, seed + 2), ctx.gen_g1(nk, seed + 3), ctx.gen_g1(N, seed + 4)
     g2b = ctx.gen_g2(nb, seed + 5)
@@ -417,7 +474,7 @@ def main():
     pk = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires,
           "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk), "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb),
           "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0], "delta2": small2[1],
-          "infinity_a": inf_a, "infinity_b": inf_b}
+          "infinity_a": inf_a, "infinity_b": inf_b, "committed_wires": committed_wires}
     if args.fixed_base:
         assert pool.lib.mi_debug_set_prove_fixed_base(ctx.h, *[int(x) for x in args.fixed_base.split(",")]) == 0
     ctx.sync()
@@ -438,16 +495,33 @@ def main():
     a = ctx.gen_scalars(n_constraints, seed + 9, dist_id); b = ctx.gen_scalars(n_constraints, seed + 10, 0)
     c = ctx.alloc(32 * n_constraints)
     ctx.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)   # c = a*b so that (a, b, c) is a satisfied R1CS row set
-    rs = ctx.gen_scalars(2, seed + 11, 0).download((2, 4))
+    rs = ctx.gen_scalars(3, seed + 11, 0).download((3, 4))       # r, s and the PoK fold challenge (gnark: fr.Hash of the commitment wire values, "G16-BSB22" -- Go's part)
     ctx.sync()
+    # what the caller holds: host memory (the solver's output)
+    Wh, ah, bh = W.download((nb_wires, 4)), a.download((n_constraints, 4)), b.download((n_constraints, 4))
+    # Pedersen key of the commitment (pk.CommitmentKeys[0]: Basis, BasisExpSigma) and the private committed values the hint receives
+    ped = ped_basis = ped_sigma = values = None
+    if n_committed:
+        ped_basis = ctx.gen_g1(n_committed, seed + 12).download((n_committed, 8)); ped_sigma = ctx.gen_g1(n_committed, seed + 13).download((n_committed, 8))
+        ped = ctx.pedersen_pk_load(ped_basis, ped_sigma)
+        values = np.ascontiguousarray(Wh[committed_private])
 
-    def submit():
-        return pool.submit(pkh, W.ptr, a.ptr, b.ptr, c.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
+    def proof_bytes(proof, cm):
+        return B.proof_write(proof["raw"]) if not n_committed else B.proof_write(proof["raw"], cm.reshape(1, 8), proof["pok"])
+
+    def one_step(with_c=False):
+        """the whole per-proof sequence of one caller (one goroutine of a prover service): Commit inside the solve, prove, WriteTo"""
+        if not n_committed:
+            proof, st = pool.wait(pool.submit(pkh, Wh, ah, bh, ch if with_c else None, rs[0], rs[1]))
+            return proof_bytes(proof, None), st
+        cm = pool.commit(ped, values)
+        proof, st = pool.wait(pool.submit_bsb22(pkh, Wh, ah, bh, ch if with_c else None, rs[0], rs[1], [(ped, values)], rs[2]))
+        return proof_bytes(proof, cm), st
 
     # untimed: size every context's workspaces (a pool job goes to whichever worker is free, so warm each one directly while
-    # the workers are idle) and take the single-proof latency on context 0; then the W warm-up steps through the pool
+    # the workers are idle) and take the reference bytes from the plain entry points, one call at a time on context 0
     serial_ms = None
-    serial_bytes = None
+    body_bytes = None
     for i in range(pool.in_flight):
         ci = pool.ctx(i)
         for k in range(3 if i == 0 else 1):
@@ -455,70 +529,86 @@ def main():
             pr, _ = ci.prove(pkh, W.ptr, a.ptr, b.ptr, c.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
             if i == 0:
                 serial_ms = (time.perf_counter() - t1) * 1e3
-            if serial_bytes is None:
-                serial_bytes = B.proof_write(pr["raw"])
-            elif B.proof_write(pr["raw"]) != serial_bytes:
+            if body_bytes is None:
+                body_bytes = B.proof_write(pr["raw"])
+            elif B.proof_write(pr["raw"]) != body_bytes:
                 raise SystemExit("bench.py: proof bytes differ between contexts / repetitions on the same inputs")
-    for t in [submit() for _ in range(args.warmup)]:
-        pool.wait(t)
+    serial_bytes = body_bytes
+    if n_committed:   # Commit, ProveKnowledge and fold through the plain one-context entry points: the reference the pool's proofs must equal
+        cm0 = ctx.pedersen_commit(ped, values)
+        pok0 = B.pedersen_fold(ctx.pedersen_commit(ped, values, knowledge=True).reshape(1, 8), rs[2])
+        serial_bytes = B.proof_write(pr["raw"], cm0.reshape(1, 8), pok0)
+    ch = None
+    # single-proof latency on the caller's path (host inputs, nothing else on the GPU): Commit + submit -> wait, c formed on the device /
+    # c uploaded as well
+    lat_host = lat_host_with_c = lat_commit = None
+    for k in range(3):
+        t1 = time.perf_counter()
+        bts, _ = one_step()
+        lat_host = (time.perf_counter() - t1) * 1e3
+        if bts != serial_bytes:
+            raise SystemExit("bench.py: the pool's host-input proof differs from the one-context reference proof of the same inputs")
+    if n_committed:
+        t1 = time.perf_counter(); pool.commit(ped, values); lat_commit = (time.perf_counter() - t1) * 1e3
+    ch = c.download((n_constraints, 4))
+    for k in range(2):
+        t1 = time.perf_counter()
+        bts, _ = one_step(with_c=True)
+        lat_host_with_c = (time.perf_counter() - t1) * 1e3
+        if bts != serial_bytes:
+            raise SystemExit("bench.py: the host-input proof with c uploaded differs from the reference proof")
+    if not want_cpu:
+        ch = None
+    from concurrent.futures import ThreadPoolExecutor
+    callers = pool.in_flight + 1
+    ex = ThreadPoolExecutor(callers)
+    list(ex.map(lambda _: one_step(), range(max(args.warmup, callers))))   # the W warm-up steps, through the same path
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the timed region: K steps
     fence()
     t0 = time.perf_counter()
-    accum_ms, accum_pairs, accum_launches, accum_entries, last = 0.0, 0, 0, 0, None
-    ntt_ms, ntt_elems, ntt_launches = 0.0, 0, 0
-    timed_proofs = []
-    for t in [submit() for _ in range(args.steps)]:   # K proofs queued; the pool keeps --in-flight of them on the GPU
-        proof, st = pool.wait(t)
-        timed_proofs.append(proof["raw"])
-        ntt_ms += st["ntt_kernel_ms"]; ntt_elems += st["ntt_elems"]; ntt_launches += st["ntt_launches"]
-        accum_ms += st["g1_accum_kernel_ms"]; accum_pairs += st["g1_accum_pairs"]; accum_launches += st["g1_accum_launches"]; accum_entries += st["g1_accum_entries"]; last = st
+    done = list(ex.map(lambda _: one_step(), range(args.steps)))
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cpu" if args.rehearse_on_one_gpu else "cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    accum_ms, accum_pairs, accum_launches, accum_entries, last = 0.0, 0, 0, 0, None
+    h2d = []
+    for bts, st in done:
+        if bts != serial_bytes:   # every timed proof must be THE proof: same inputs, (r, s), committed values -> the reference bytes
+            raise SystemExit("bench.py: a timed proof differs from the untimed reference proof of the same inputs")
+        accum_ms += st["g1_accum_kernel_ms"]; accum_pairs += st["g1_accum_pairs"]; accum_launches += st["g1_accum_launches"]; accum_entries += st["g1_accum_entries"]; last = st
+        h2d.append(st["h2d_ms"])
+    h2d.sort()
 
-    # every timed proof must be THE proof: same inputs and (r, s) -> same bytes as the untimed serial proof
-    for raw in timed_proofs:
-        if B.proof_write(raw) != serial_bytes:
-            raise SystemExit("bench.py: a timed proof differs from the untimed serial proof of the same inputs")
-
-    # second timed region: the same K proofs with W, a, b, c in HOST memory (mi_prover_submit, what the cgo drop-in passes:
-    # Go slices, mt.go:494-496) -- the PCIe-inclusive rate.  Reported next to `value`, never as `value`.
-    host_rate = host_ms = host_h2d_ms = serial_host_ms = None
-    if not args.no_host_inputs:
-        Wh, ah, bh, ch = W.download((nb_wires, 4)), a.download((n_constraints, 4)), b.download((n_constraints, 4)), c.download((n_constraints, 4))
-        # one proof alone through the host-pointer entry point (mi_groth16_prove, what a caller that proves strictly one circuit at a time
-        # binds -- the reference's own shape, mt.go:494-496): PCIe-inclusive single-proof latency
-        for k in range(3):
-            t1 = time.perf_counter()
-            pr, _ = ctx.prove(pkh, Wh, ah, bh, ch, rs[0], rs[1])
-            serial_host_ms = (time.perf_counter() - t1) * 1e3
-            if B.proof_write(pr["raw"]) != serial_bytes:
-                raise SystemExit("bench.py: the host-pointer proof differs from the device-pointer proof of the same inputs")
-        for t in [pool.submit(pkh, Wh, ah, bh, ch, rs[0], rs[1]) for _ in range(max(args.warmup, pool.in_flight + 1))]:
+    # second timed region: the same key with W, a, b, c ALREADY in HBM and no commitment (mi_prover_submit_dev, 164-byte proof body): the
+    # GPU-side rate no caller of the reference can reach (its solver is CPU code) -- reported next to `value`, never as `value`
+    dev_rate = dev_ms = None
+    if not args.no_hbm_resident:
+        sub = lambda: pool.submit(pkh, W.ptr, a.ptr, b.ptr, c.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
+        for t in [sub() for _ in range(args.warmup)]:
             pool.wait(t)
         fence()
-        t0h = time.perf_counter()
-        host_done = [pool.wait(t) for t in [pool.submit(pkh, Wh, ah, bh, ch, rs[0], rs[1]) for _ in range(args.steps)]]
-        host_proofs = [x[0]["raw"] for x in host_done]
-        host_h2d_ms = sorted(x[1]["h2d_ms"] for x in host_done)
+        t0d = time.perf_counter()
+        dev_done = [pool.wait(t)[0]["raw"] for t in [sub() for _ in range(args.steps)]]
         fence()
-        dth = time.perf_counter() - t0h
+        dtd = time.perf_counter() - t0d
         if dist is not None:
-            t = torch.tensor([dth], device="cpu" if args.rehearse_on_one_gpu else "cuda", dtype=torch.float64)
+            t = torch.tensor([dtd], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dth = float(t.item())
-        for raw in host_proofs:
-            if B.proof_write(raw) != serial_bytes:
-                raise SystemExit("bench.py: a host-input proof differs from the device-input proof of the same inputs")
-        host_rate, host_ms = args.steps * world / dth, dth / args.steps * 1e3
+            dtd = float(t.item())
+        for raw in dev_done:
+            if B.proof_write(raw) != body_bytes:
+                raise SystemExit("bench.py: a device-input proof differs from the reference proof of the same inputs")
+        dev_rate, dev_ms = args.steps * world / dtd, dtd / args.steps * 1e3
+    ex.shutdown()
 
     # HBM ledger of the PROVE path, taken right after the timed regions: key + tables, every context's workspaces, the pool's input sets,
     # bench.py's own inputs -- before the solo-MSM / solo-computeH / probe legs below grow the (grow-only) workspaces of context 0 for
@@ -532,7 +622,7 @@ def main():
                 if k.startswith("ctx_"):
                     hbm_ledger[k] += v
         hbm_ledger["pool_contexts"] = pool.in_flight
-        hbm_ledger["pool_input_sets_gb"] = (pool.in_flight + 1) * (nb_wires + 3 * n_constraints) * 32 / 1e9 if not args.no_host_inputs else 0.0
+        hbm_ledger["pool_input_sets_gb"] = (pool.in_flight + 1) * (nb_wires + 3 * n_constraints) * 32 / 1e9
         hbm_ledger["bench_inputs_gb"] = (nb_wires + 3 * n_constraints) * 32 / 1e9
         hbm_ledger["bench_key_source_arrays_gb"] = (N * 64 if not args.no_limb29 else (na + nb + nk + N) * 64 + nb * 128) / 1e9   # what bench.py itself still holds of the generated bases
     # the same kernel measured alone (no other stream competing for the CUs): one uniform-scalar G1 MSM over pk.G1.Z
@@ -569,11 +659,13 @@ def main():
         kh = lambda name, d, n, k: key_host[name] if name in key_host else dl(d, n, k)
         pk_host = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": kh("g1_a", g1a, na, 8), "g1_b": kh("g1_b", g1b, nb, 8),
                    "g1_k": kh("g1_k", g1k, nk, 8), "g1_z": dl(g1z, N, 8), "g2_b": kh("g2_b", g2b, nb, 16), "alpha1": small[0], "beta1": small[1],
-                   "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b}
-        cpu_inputs = (pk_host, dl(W, nb_wires, 4), dl(a, n_constraints, 4), dl(b, n_constraints, 4), dl(c, n_constraints, 4))
+                   "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b, "committed_wires": committed_wires}
+        cpu_inputs = (pk_host, Wh, ah, bh, ch)
     # configs[4]: this process gives its GPU memory back first (an N = 2^26 proof wants most of a GPU), then the helper runs the
     # transport self-test, the point-sharded MSM and the point-sharded PROVE over all ranks
     in_flight = pool.in_flight
+    if ped is not None:
+        ctx.pedersen_pk_free(ped)
     ctx.pk_free(pkh)
     for d in (g1a, g1b, g1k, g1z, g2b, W, a, b, c):
         d.free()   # (DevArray.free is idempotent)
@@ -588,54 +680,79 @@ def main():
         per_launch_bytes = 96.0 * accum_pairs / max(accum_launches, 1)
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         g1_pairs_per_proof = na + nb + nk + (N - 1)
-        # HBM traffic per launch: NOT measured by this run -- read from the committed rocprofv3 --pmc passes of this same
-        # workload (profiles/r02_pmc_bench_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, KB units), and only
-        # reported when this run has the profiled shape (N = 2^23, WHIR mix, automatic plans).  The accumulate kernel gathers 64-B
-        # points, so its FETCH_SIZE is taken raw; the NTT passes stream 16 B per lane, so theirs gets the guide's x2 correction.
+        # HBM traffic per launch: NOT measured by this run -- read from the committed rocprofv3 --pmc passes of this same workload
+        # (profiles/r04_pmc_bench_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, KB units; the file records the sha256 of the
+        # kernel sources it was collected on), and only reported when this run has the profiled shape (N = 2^23, WHIR mix, automatic
+        # plans) AND those sources are unchanged: a file older than the kernels reads as traffic: null, never as stale bytes.  The
+        # accumulate kernel gathers 64-B points, so its FETCH_SIZE is taken raw; the NTT passes stream 16 B per lane, so theirs gets
+        # the guide's x2 correction.
         traffic = traffic_ntt = None
-        pmc_file = os.path.join("profiles", "r03_pmc_bench_traffic.json")
-        if not os.path.exists(os.path.join(ROOT, pmc_file)):
-            pmc_file = os.path.join("profiles", "r02_pmc_bench_traffic.json")
-        pmc_src = f"{pmc_file} (committed PMC passes of this workload, not this run; file sha256 {_sha16(os.path.join(ROOT, pmc_file))}, last commit {_last_commit(pmc_file)})"
+        pmc_file = os.path.join("profiles", "r04_pmc_bench_traffic.json")
+        pmc_src = f"{pmc_file} (committed PMC passes of this workload, not this run; file sha256 {_sha16(os.path.join(ROOT, pmc_file))})"
+        csrc = os.path.join(ROOT, "gnark-whir_amd", "csrc")
         if log_n == 23 and args.dist == "whir" and not (args.msm_plan or args.fixed_base or args.ntt_plan or args.msm_group_bits or args.msm_chunk):
             try:
                 pmc = json.load(open(os.path.join(ROOT, pmc_file)))
+                src_now = {f: _sha16(os.path.join(csrc, f)) for f in pmc["_sources"]}
+                fresh_msm = all(src_now[f] == h for f, h in pmc["_sources"].items() if f.startswith(("msm", "curve29", "field29")))
+                fresh_ntt = all(src_now[f] == h for f, h in pmc["_sources"].items() if f.startswith(("ntt", "field.")))
                 kname = "k_msm_accum_affine29"
-                traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
-                # per pass launch (the fused contiguous pair -- two launches per computeH -- and the fused strided triple -- one -- counted with
-                # their own figures); one transform = a sixth of computeH's traffic
-                per = lambda kn: (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0
-                n_pair = 2 if "k_ntt_contig_pair" in pmc["FETCH_SIZE"] else 0
-                n_triple = 1 if "k_ntt_strided_triple" in pmc["FETCH_SIZE"] else 0
-                traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair - n_triple) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0) +
-                               (per("k_ntt_strided_triple") if n_triple else 0.0)) / 6.0
+                if fresh_msm:
+                    traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
+                else:
+                    pmc_src += "; STALE for the MSM kernels (their sources changed since the passes): traffic withheld"
+                if fresh_ntt:
+                    # per pass launch (the fused contiguous pair -- two launches per computeH -- and the fused strided triple -- one -- counted
+                    # with their own figures); one transform = a sixth of computeH's traffic
+                    per = lambda kn: (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0
+                    n_pair = 2 if "k_ntt_contig_pair" in pmc["FETCH_SIZE"] else 0
+                    n_triple = 1 if "k_ntt_strided_triple" in pmc["FETCH_SIZE"] else 0
+                    traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair - n_triple) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0) +
+                                   (per("k_ntt_strided_triple") if n_triple else 0.0)) / 6.0
+                else:
+                    pmc_src += "; STALE for the NTT kernels: traffic withheld"
             except Exception:
                 traffic = traffic_ntt = None
+        # the level-1 kernel's own instruction-issue floor, from the committed ISA census of its code object (tools/isa_census.py ->
+        # profiles/r04_isa_census_accum_affine29.json: instructions per loop iteration by class x the measured cycles per wave64
+        # instruction of profiles/r02_probe_instr_rate.txt)
+        issue_floor = census_src = None
+        try:
+            cen = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_census_accum_affine29.json")))
+            issue_floor = 2.4e9 / cen["cycles_per_addition"] * 64 * 1024
+            census_src = f"profiles/r04_isa_census_accum_affine29.json: {cen['valu_per_addition']} vector instructions per mixed addition ({cen['mad_u64_u32_per_addition']} v_mad_u64_u32) = {cen['cycles_per_addition']:.0f} cycles per wave-addition"
+        except Exception:
+            pass
         line = {
             "metric": "Groth16 proofs/sec for WHIR-verifier circuit (2^20 poly); G1 MSM pts/sec",
             "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 Montgomery (BN254 Fr/Fp, exact modular integers)", "data": "synthetic",
-            "config": {"workload": f"full Groth16 prove, WHIR-verifier-shaped synthetic key/witness, FFT domain N=2^{log_n} "
-                                   f"(BASELINE {'configs[1]' if log_n == 23 else 'configs[2]' if log_n == 26 else 'non-baseline size'}; configs[3] = one such proof stream per GPU when n_gpus>1)",
-                       "nb_wires": nb_wires, "nb_public": nb_public, "n_constraints": n_constraints, "scalar_dist": args.dist,
-                       "g1_msm_sizes": [na, nb, nk, N - 1], "g2_msm_size": nb, "proofs_in_flight_per_gpu": in_flight},
-            # latency of ONE proof with nothing else on the GPU (untimed region, context 0); value above is throughput with
-            # proofs_in_flight_per_gpu proofs overlapping, every one of the K steps submitted and completed inside the timed region
-            "single_proof_latency_ms": serial_ms,
-            # the same with W, a, b, c handed over as host pointers (mi_groth16_prove: 1.07 GB cross PCIe inside the call; W first, the wire
-            # MSMs start behind it, a's and b's transforms behind a and b, the rest behind c)
-            "single_proof_latency_host_inputs_ms": serial_host_ms,
-            # PCIe-inclusive: the same K steps with W, a, b, c handed over as host pointers (the cgo path); proofs byte-equal
-            "value_host_inputs": host_rate, "ms_per_step_host_inputs": host_ms,
-            # the upload stage's wall time per job (W, a, b, c = 1.07 GB at N = 2^23 from pageable host memory): when its median nears
-            # ms_per_step the host-input rate is bound by the PCIe / host-memory side of the box, not by the GPU
-            "host_inputs_upload_ms": None if host_rate is None else {"median": host_h2d_ms[len(host_h2d_ms) // 2], "max": host_h2d_ms[-1]},
+            "config": {"workload": f"full Groth16 prove of the WHIR-verifier-shaped synthetic key/witness, FFT domain N=2^{log_n} "
+                                   f"(BASELINE {'configs[1]' if log_n == 23 else 'configs[2]' if log_n == 26 else 'non-baseline size'}; configs[3] = one such proof stream per GPU when n_gpus>1), "
+                                   f"with its ONE BSB22 commitment over {n_committed} private wires (Commit inside the step, ProveKnowledge beside the proof's MSMs, fold; {196 if n_committed else 164}-byte proof), "
+                                   "W, a, b handed over as HOST pointers (the cgo path; c = a o b formed on the device)",
+                       "nb_wires": nb_wires, "nb_public": nb_public, "n_constraints": n_constraints, "n_committed": n_committed, "scalar_dist": args.dist,
+                       "g1_msm_sizes": [na, nb, nk, N - 1], "g2_msm_size": nb, "pedersen_msm_sizes": [n_committed, n_committed], "proofs_in_flight_per_gpu": in_flight,
+                       "caller_threads": callers, "inputs": "host memory (PCIe inside the step)"},
+            "proof_bytes": len(serial_bytes),
+            # the GPU-side rate: the same key and witness with W, a, b, c already in HBM and no commitment (164-byte body) -- what rounds 1-3
+            # reported as `value`; no caller of the reference can reach it (gnark's solver is CPU code)
+            "value_hbm_resident_inputs": dev_rate, "ms_per_step_hbm_resident_inputs": dev_ms,
+            # latency of ONE proof with nothing else on the GPU -- the reference proves one circuit per run, so this is its own metric:
+            # the caller's path (host W, a, b: Commit + submit -> wait through the pool); the same with c uploaded too; the GPU side alone
+            # (inputs in HBM, plain mi_groth16_prove_dev, no commitment)
+            "single_proof_latency_host_inputs_ms": lat_host, "single_proof_latency_host_inputs_with_c_uploaded_ms": lat_host_with_c,
+            "single_proof_latency_ms": serial_ms, "pedersen_commit_latency_ms": lat_commit,
+            # the upload stage's wall time per job (W, a, b = 0.8 GB at N = 2^23 from pageable host memory): when its median nears
+            # ms_per_step the rate is bound by the PCIe / host-memory side of the box, not by the GPU
+            "host_inputs_upload_ms": {"median": h2d[len(h2d) // 2], "max": h2d[-1]},
             # BASELINE configs[4] (one MSM point-sharded over the ranks, strong scaling); n_gpus = 1: the same code path with one rank
             "sharded_msm": sharded,
             # BASELINE configs[4] as north_star states it: ONE proof point-sharded over the ranks (strong scaling)
             "sharded_prove": sharded_prove,
-            "proofs_validated": f"{len(timed_proofs)} timed + {0 if host_rate is None else args.steps} host-input proofs byte-equal to the untimed serial proof",
+            "multi_gpu_note": "no scaling curve exists until an 8-GPU node runs this command with --gpus 2/4/8; nothing here extrapolates one",
+            "proofs_validated": f"{len(done)} timed proofs ({len(serial_bytes)} bytes each) + {0 if dev_rate is None else args.steps} HBM-resident-input proofs byte-equal to the untimed reference proofs",
             "pk_load_s": t_load,
             "hbm_in_use_gb": hbm_in_use_gb, "hbm_ledger_gb": hbm_ledger,
             # second half of BASELINE's metric: one G1 MSM of 2^23 uniform pairs alone on the GPU (standard MSM benchmark shape);
@@ -667,14 +784,12 @@ def main():
                      "kernel_mixed_adds_per_s": accum_entries / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,
                      "kernel_modmul_per_s": 10.0 * accum_entries / (accum_ms * 1e-3) if accum_ms > 0 else 0.0,
                      "note": "one XYZZ mixed addition = 8M + 2S Fp products (+ ~7 add/sub); frac = kernel_modmul_per_s / modmul_ceiling_per_s",
-                     # the kernel's OWN instruction mix (ISA of k_msm_accum_affine29: 1467 v_mad_u64_u32 of ~2450 vector instructions per addition, at
-                     # the per-instruction costs of profiles/r02_probe_instr_rate.txt ~ 10 800 cycles per wave-addition) allows a
-                     # SIMD 2.4e9 / 10800 wave-additions/s: the kernel alone on the GPU against that floor
-                     "issue_floor_adds_per_s": 2.4e9 / 10800.0 * 64 * 1024,
-                     "kernel_alone_frac_of_issue_floor": solo["mixed_adds_per_s"] / (2.4e9 / 10800.0 * 64 * 1024)},
+                     # the kernel's OWN instruction mix allows a SIMD 2.4e9 / cycles_per_addition wave-additions/s: the kernel alone on the GPU against that floor
+                     "issue_floor_adds_per_s": issue_floor, "issue_floor_source": census_src,
+                     "kernel_alone_frac_of_issue_floor": None if issue_floor is None else solo["mixed_adds_per_s"] / issue_floor},
         }
         if cpu_inputs is not None:
-            line["cpu_baseline"] = cpu_baseline(*cpu_inputs, rs[0], rs[1], log_n, serial_bytes)
+            line["cpu_baseline"] = cpu_baseline(*cpu_inputs, rs[0], rs[1], (ped_basis, ped_sigma, values, rs[2]) if n_committed else None, log_n, serial_bytes)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
