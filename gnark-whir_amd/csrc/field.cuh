@@ -29,12 +29,14 @@ struct FrParams {
     static constexpr u32 r2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
     static constexpr u32 one[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     static constexpr u32 inv = 0xefffffffu;  // -p^-1 mod 2^32
+    static constexpr u32 p2[8] = {0xe0000002u, 0x87c3eb27u, 0xf372e122u, 0x5067d090u, 0x0302b0bau, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};   // 2p (4p < 2^256 < 6p)
 };
 struct FpParams {
     static constexpr u32 p[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr u32 r2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
     static constexpr u32 one[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
     static constexpr u32 inv = 0xe4866389u;
+    static constexpr u32 p2[8] = {0xb0f9fa8eu, 0x7841182du, 0xd0e3951au, 0x2f02d522u, 0x0302b0bbu, 0x70a08b6du, 0xc2634053u, 0x60c89ce5u};   // 2p
 };
 
 template <class P>
@@ -216,6 +218,122 @@ MI_HD Fe<P> operator-(const Fe<P> &x, const Fe<P> &y) {
     return z;
 }
 #endif
+// ---------------------------------------------------------------- lazy arithmetic (the NTT butterflies, ntt_tile.cuh)
+// Values are kept as 256-bit representatives in [0, 2p) or [0, 4p) instead of [0, p): 4p < 2^256 for both moduli, so plain 8-limb
+// additions cannot carry out, and a Montgomery product of x < 4p by a table constant w < p comes out below x w / R + p < 1.76 p < 2p
+// WITHOUT its final conditional subtraction (fe_mul_lazy).  Harvey's butterflies (ntt_bfly_dif / ntt_bfly_dit) then need one
+// conditional subtraction of 2p where the classical ones need three conditional corrections by p.  Same residues; the last pass of a
+// transform brings every element back to [0, p) (fe_canon), so results are bit-identical.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI_L8(v) "v"(v.l[0]), "v"(v.l[1]), "v"(v.l[2]), "v"(v.l[3]), "v"(v.l[4]), "v"(v.l[5]), "v"(v.l[6]), "v"(v.l[7])
+#define MI_O8(v) "=&v"(v.l[0]), "=&v"(v.l[1]), "=&v"(v.l[2]), "=&v"(v.l[3]), "=&v"(v.l[4]), "=&v"(v.l[5]), "=&v"(v.l[6]), "=&v"(v.l[7])
+#define MI_2P8 "v"(P::p2[0]), "v"(P::p2[1]), "v"(P::p2[2]), "v"(P::p2[3]), "v"(P::p2[4]), "v"(P::p2[5]), "v"(P::p2[6]), "v"(P::p2[7])
+// x + y, no reduction (the caller knows the sum stays below 2^256)
+template <class P>
+MI_HD Fe<P> fe_add_nored(const Fe<P> &x, const Fe<P> &y) {
+    Fe<P> z;   // %0-7 z, %8-15 x, %16-23 y
+    asm("v_add_co_u32_e32 %0, vcc, %8, %16\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %9, %17, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %10, %18, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %12, %20, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %14, %22, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %15, %23, vcc"
+        : MI_O8(z) : MI_L8(x), MI_L8(y) : "vcc");
+    return z;
+}
+// x - y + 2p, no reduction: in (0, 4p) for x, y in [0, 2p)
+template <class P>
+MI_HD Fe<P> fe_sub_plus2p(const Fe<P> &x, const Fe<P> &y) {
+    Fe<P> z;   // %0-7 z, %8-15 x, %16-23 y, %24-31 2p
+    asm("v_sub_co_u32_e32 %0, vcc, %8, %16\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %9, %17, vcc\n\t"
+        "v_subb_co_u32_e32 %2, vcc, %10, %18, vcc\n\t"
+        "v_subb_co_u32_e32 %3, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32_e32 %4, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32_e32 %5, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32_e32 %6, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32_e32 %7, vcc, %15, %23, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, %0, %24\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %1, %25, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %26, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %3, %27, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %4, %28, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %5, %29, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %6, %30, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %7, %31, vcc"
+        : MI_O8(z) : MI_L8(x), MI_L8(y), MI_2P8 : "vcc");
+    return z;
+}
+// if x >= 2p: x -= 2p   (x < 4p -> [0, 2p))
+template <class P>
+MI_HD Fe<P> fe_condsub_2p(const Fe<P> &x) {
+    Fe<P> z;   // %0-7 z, %8-15 x, %16-23 2p
+    asm("v_subrev_co_u32_e32 %0, vcc, %16, %8\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, %17, %9, vcc\n\t"
+        "v_subbrev_co_u32_e32 %2, vcc, %18, %10, vcc\n\t"
+        "v_subbrev_co_u32_e32 %3, vcc, %19, %11, vcc\n\t"
+        "v_subbrev_co_u32_e32 %4, vcc, %20, %12, vcc\n\t"
+        "v_subbrev_co_u32_e32 %5, vcc, %21, %13, vcc\n\t"
+        "v_subbrev_co_u32_e32 %6, vcc, %22, %14, vcc\n\t"
+        "v_subbrev_co_u32_e32 %7, vcc, %23, %15, vcc\n\t"
+        "v_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
+        "v_cndmask_b32_e32 %1, %1, %9, vcc\n\t"
+        "v_cndmask_b32_e32 %2, %2, %10, vcc\n\t"
+        "v_cndmask_b32_e32 %3, %3, %11, vcc\n\t"
+        "v_cndmask_b32_e32 %4, %4, %12, vcc\n\t"
+        "v_cndmask_b32_e32 %5, %5, %13, vcc\n\t"
+        "v_cndmask_b32_e32 %6, %6, %14, vcc\n\t"
+        "v_cndmask_b32_e32 %7, %7, %15, vcc"
+        : MI_O8(z) : MI_L8(x), MI_2P8 : "vcc");
+    return z;
+}
+#undef MI_L8
+#undef MI_O8
+#undef MI_2P8
+#else
+template <class P>
+MI_HD Fe<P> fe_add_nored(const Fe<P> &x, const Fe<P> &y) {
+    Fe<P> z;
+    const u32 carry = fe_add_raw(z, x, y);
+#if defined(MI_CHECK_NOWRAP)
+    if (carry) __builtin_trap();   // the host build of the tests checks every bound the lazy arithmetic relies on
+#else
+    (void)carry;
+#endif
+    return z;
+}
+template <class P>
+MI_HD Fe<P> fe_twice_modulus() { Fe<P> z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z.l[i] = P::p2[i];
+    return z; }
+template <class P>
+MI_HD Fe<P> fe_sub_plus2p(const Fe<P> &x, const Fe<P> &y) {
+    Fe<P> d, z;
+    const u32 borrow = fe_sub_raw(d, x, y);
+    const u32 carry = fe_add_raw(z, d, fe_twice_modulus<P>());
+#if defined(MI_CHECK_NOWRAP)
+    if (borrow != carry) __builtin_trap();   // x - y + 2p must land in [0, 2^256): a borrow is always paid back, no borrow never carries
+#else
+    (void)borrow; (void)carry;
+#endif
+    return z;
+}
+template <class P>
+MI_HD Fe<P> fe_condsub_2p(const Fe<P> &x) {
+    Fe<P> d, z;
+    const u32 borrow = fe_sub_raw(d, x, fe_twice_modulus<P>());
+#pragma unroll
+    for (int i = 0; i < 8; i++) z.l[i] = borrow ? x.l[i] : d.l[i];
+    return z;
+}
+#endif
+// any representative below 4p -> the canonical one in [0, p)
+template <class P>
+MI_HD Fe<P> fe_canon(const Fe<P> &x) { return fe_reduce_once(fe_condsub_2p(x)); }
+
 template <class P>
 MI_HD Fe<P> fe_neg(const Fe<P> &x) {
     Fe<P> d;
@@ -299,11 +417,24 @@ MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
     r.l[7] = (u32)acc;   // column 15 is empty for 8-limb operands; p < 2^254 keeps the result < 2p < 2^256
     return fe_reduce_once(r);
 }
+// the same product without its final conditional subtraction: x < 4p (any limbs), y < p (a table constant: top limb < 2^30, what
+// the carry-less first products of columns >= 8 need) -> a representative below x y / R + p < 2p
+template <class P>
+MI_HD Fe<P> fe_mul_lazy(const Fe<P> &x, const Fe<P> &y) {
+    u64 acc = 0;
+    u32 c = 0;
+    u32 m[8];
+    Fe<P> r;
+    MI_MONT_LO(0) MI_MONT_LO(1) MI_MONT_LO(2) MI_MONT_LO(3) MI_MONT_LO(4) MI_MONT_LO(5) MI_MONT_LO(6) MI_MONT_LO(7)
+    MI_MONT_HI(8) MI_MONT_HI(9) MI_MONT_HI(10) MI_MONT_HI(11) MI_MONT_HI(12) MI_MONT_HI(13) MI_MONT_HI(14)
+    r.l[7] = (u32)acc;
+    return r;
+}
 #undef MI_MONT_LO
 #undef MI_MONT_HI
 #else
 template <class P>
-MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
+MI_HD Fe<P> fe_mul_lazy(const Fe<P> &x, const Fe<P> &y) {   // the product before its final conditional subtraction (see the device form)
     u64 acc = 0;
     u32 c = 0;
     u32 m[8];
@@ -333,8 +464,13 @@ MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) {
         c = 0;
     }
     r.l[7] = (u32)acc;
-    return fe_reduce_once(r);
+#if defined(MI_CHECK_NOWRAP)
+    if (acc >> 32) __builtin_trap();   // the result must fit 256 bits (x y / R + p < 2^256)
+#endif
+    return r;
 }
+template <class P>
+MI_HD Fe<P> operator*(const Fe<P> &x, const Fe<P> &y) { return fe_reduce_once(fe_mul_lazy(x, y)); }
 #endif
 // (x*y + u*v) / R mod p with ONE Montgomery reduction ("lazy reduction" of a sum of two products): 128 + 72 mads instead
 // of 2 * 136.  Inputs may be <= p (a raw p - a is accepted as the negation of a), the result is canonical.

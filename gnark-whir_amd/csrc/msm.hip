@@ -514,7 +514,10 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     u32 *C1 = (u32 *)sl.buf[B_C1].p, *S1 = C1 + (size_t)s.ngroups * G + 1;
     const int mont = (flags & MI_MSM_SCALARS_CANONICAL) ? 0 : 1;
     hipStream_t st = sl.stream;
-    u32 per = 8;   // slices per counting workgroup
+    // slices per counting workgroup: a group's counters leave as ONE segment of per x 4 B (per = 8: 32-B segments, 255 MB written for a
+    // 16 MB matrix at N = 2^23 by the PMC counters; 32: whole 128-B lines)
+    static const u32 per_knob = getenv("MI_MSM2_COUNT_PER") ? (u32)atoi(getenv("MI_MSM2_COUNT_PER")) : 32u;
+    u32 per = per_knob >= 1 && per_knob <= 64 ? per_knob : 32u;
     while (per > 1 && per * s.ngroups > 8192) per >>= 1;
     hipLaunchKernelGGL(k_msm2_count, dim3((G + per - 1) / per), dim3(512), 0, st, s, scalars, mont, per, C1);
     MI_CHECK_HIP(ctx, hipGetLastError());

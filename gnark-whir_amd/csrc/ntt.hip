@@ -180,10 +180,10 @@ __global__ void __launch_bounds__(256) k_ntt_contig_pair(Fr *data, NttPass pi, N
         // what the inverse pass would have stored at rows 2L, 2L + 1 and the forward pass loaded with its edge factor
         const u32 r0 = base + 2 * lane, r1 = r0 + 1;
         Fr f;
-        if (ntt_edge_factor(pi, ti, r0, ntt_global_index(pi, tile, r0, col), 1, f)) x0 = x0 * f;
-        if (ntt_edge_factor(pf, tf, r0, ntt_global_index(pf, tile, r0, col), 0, f)) x0 = x0 * f;
-        if (ntt_edge_factor(pi, ti, r1, ntt_global_index(pi, tile, r1, col), 1, f)) x1 = x1 * f;
-        if (ntt_edge_factor(pf, tf, r1, ntt_global_index(pf, tile, r1, col), 0, f)) x1 = x1 * f;
+        if (ntt_edge_factor(pi, ti, r0, ntt_global_index(pi, tile, r0, col), 1, f)) x0 = fe_mul_lazy(x0, f);
+        if (ntt_edge_factor(pf, tf, r0, ntt_global_index(pf, tile, r0, col), 0, f)) x0 = fe_mul_lazy(x0, f);
+        if (ntt_edge_factor(pi, ti, r1, ntt_global_index(pi, tile, r1, col), 1, f)) x1 = fe_mul_lazy(x1, f);
+        if (ntt_edge_factor(pf, tf, r1, ntt_global_index(pf, tile, r1, col), 0, f)) x1 = fe_mul_lazy(x1, f);
         wave_ntt128(x0, x1, lane, true, tf.small);
         lds_put(lds, PL, ntt_lds_slot(pf, base + lane, col), x0);
         lds_put(lds, PL, ntt_lds_slot(pf, base + lane + 64, col), x1);
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(512) k_ntt_strided_triple(Fr *a, const Fr *b, 
     __syncthreads();
     Fr x0 = lds_get(lds, PL, s0), x1 = lds_get(lds, PL, s1);
     wave_ntt128(x0, x1, lane, true, tc.small);
-    x0 = x0 * a0; x1 = x1 * a1;
+    x0 = ntt_mul_lazy2(x0, a0); x1 = ntt_mul_lazy2(x1, a1);   // DIT left both factors below 4p; the DIF stages want [0, 2p)
     wave_ntt128(x0, x1, lane, false, tl.small);    // rows L, L + 64 -> positions 2L, 2L + 1
     __syncthreads();                               // every wave has read b's tile
     lds_put(lds, PL, ntt_lds_slot(pl, base + 2 * lane, col), x0);
@@ -262,10 +262,10 @@ __global__ void __launch_bounds__(256) k_ntt_strided_triple8(Fr *a, const Fr *b,
     for (u32 k = 0; k < 2; k++) {   // (constant trip count: keep[] stays in registers)
         if (k >= nb) break;
         const u32 bf = threadIdx.x + 256 * k, col = bf & (C - 1), j = bf >> pc.log_c;
-        const Fr x = lds_get(lds, PL, ntt_lds_slot(pc, j, col));
+        Fr x = lds_get(lds, PL, ntt_lds_slot(pc, j, col));
         Fr y = lds_get(lds, PL, ntt_lds_slot(pc, j + 128, col));
-        if (j) y = y * tc.small[j << 4];           // w_256^j = w_4096^(16 j)
-        keep[2 * k] = x + y; keep[2 * k + 1] = x - y;
+        ntt_bfly_dit(x, y, j ? &tc.small[j << 4] : nullptr);           // w_256^j = w_4096^(16 j)
+        keep[2 * k] = x; keep[2 * k + 1] = y;
     }
     __syncthreads();
     ntt_tile_load(pc, tc, b, tile, threadIdx.x, blockDim.x, lds);
@@ -276,14 +276,13 @@ __global__ void __launch_bounds__(256) k_ntt_strided_triple8(Fr *a, const Fr *b,
     for (u32 k = 0; k < 2; k++) {
         if (k >= nb) break;
         const u32 bf = threadIdx.x + 256 * k, col = bf & (C - 1), j = bf >> pc.log_c;
-        const Fr x = lds_get(lds, PL, ntt_lds_slot(pc, j, col));
+        Fr x = lds_get(lds, PL, ntt_lds_slot(pc, j, col));
         Fr y = lds_get(lds, PL, ntt_lds_slot(pc, j + 128, col));
-        if (j) y = y * tc.small[j << 4];
-        const Fr p0 = (x + y) * keep[2 * k], p1 = (x - y) * keep[2 * k + 1];   // the products at rows j, j + 128
-        Fr d = p0 - p1;                                                         // DIF butterfly at distance 128
-        if (j) d = d * tl.small[j << 4];
-        lds_put(lds, PL, ntt_lds_slot(pl, j, col), p0 + p1);
-        lds_put(lds, PL, ntt_lds_slot(pl, j + 128, col), d);
+        ntt_bfly_dit(x, y, j ? &tc.small[j << 4] : nullptr);
+        Fr p0 = ntt_mul_lazy2(x, keep[2 * k]), p1 = ntt_mul_lazy2(y, keep[2 * k + 1]);   // the products at rows j, j + 128, below 2p
+        ntt_bfly_dif(p0, p1, j ? &tl.small[j << 4] : nullptr);                           // DIF butterfly at distance 128
+        lds_put(lds, PL, ntt_lds_slot(pl, j, col), p0);
+        lds_put(lds, PL, ntt_lds_slot(pl, j + 128, col), p1);
     }
     __syncthreads();
     reg_stages(pl, false, tl.small);
@@ -455,6 +454,9 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
         p.n_valid = step == 0 ? n_valid : (1u << log_n);
         if (step == 0) p.load_mul = load_mul;
         if (step == pl.n_pass - 1) p.store_sub = store_sub;
+        // the elements travel lazily reduced (below 4p) between the stages and the passes (ntt_tile.cuh); the last pass of a transform
+        // whose output is final -- fft.Domain's own transforms (variant 0) and computeH's last one (variant 3: h) -- stores canonical values
+        if (step == pl.n_pass - 1 && (variant == 0 || variant == 3)) p.canon = 1;
         // computeH's direct tables (variant != 0 only): the twiddle of the M = N pass, the coset shift of the contiguous pass
         const bool direct = variant != 0 && st->d_log_n == log_n && st->d_sc_fwd;
         if (direct && p.twiddle && i == 0 && pl.n_pass > 1) p.tw_direct = inverse ? st->d_tw_inv : st->d_tw_fwd;

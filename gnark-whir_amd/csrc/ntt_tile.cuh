@@ -58,7 +58,29 @@ struct NttPass {
     // store_sub: store_sub[g] is subtracted from every element on its way out, after the scaling
     const Fr *load_mul;
     const Fr *store_sub;
+    u32 canon;      // 1 on the last pass of a transform whose output leaves the library (or is h): every element is brought back to [0, p)
 };
+
+// ---------------------------------------------------------------- lazy butterflies (Harvey)
+// Between the stages of a transform the elements are 256-bit representatives that are NOT reduced below p (field.cuh, "lazy
+// arithmetic"): a DIF pass keeps them in [0, 2p), a DIT pass in [0, 4p) (4p < 2^256 for Fr).  One conditional subtraction of 2p per
+// butterfly instead of three corrections by p, and the twiddle product drops its final conditional subtraction: ~25 of ~360 vector
+// instructions.  w == nullptr: the twiddle is 1.  Passes hand the elements on through HBM as they are (anything below 4p is a valid
+// input of a DIT butterfly and of any edge product); only NttPass::canon stores canonical values.
+MI_HD void ntt_bfly_dif(Fr &x0, Fr &x1, const Fr *w) {   // x0, x1 in [0, 2p) -> x0 + x1, (x0 - x1) w, both in [0, 2p)
+    const Fr u = fe_condsub_2p(fe_add_nored(x0, x1));
+    const Fr t = fe_sub_plus2p(x0, x1);                   // (0, 4p)
+    x1 = w ? fe_mul_lazy(t, *w) : fe_condsub_2p(t);
+    x0 = u;
+}
+MI_HD void ntt_bfly_dit(Fr &x0, Fr &x1, const Fr *w) {   // x0, x1 in [0, 4p) -> x0 + x1 w, x0 - x1 w, both in [0, 4p)
+    const Fr a = fe_condsub_2p(x0);
+    const Fr t = w ? fe_mul_lazy(x1, *w) : fe_condsub_2p(x1);   // [0, 2p)
+    x0 = fe_add_nored(a, t);
+    x1 = fe_sub_plus2p(a, t);
+}
+// the pointwise product of two lazily reduced elements (both below 4p): below 2p
+MI_HD Fr ntt_mul_lazy2(const Fr &x, const Fr &y) { return fe_mul_lazy(fe_condsub_2p(x), fe_condsub_2p(y)); }
 
 MI_HD u32 bitrev_u32(u32 x, u32 bits) {
 #if defined(__HIPCC__)
@@ -143,7 +165,7 @@ MI_HD void ntt_tile_load(const NttPass &p, const NttTables &t, const Fr *data, u
         else { col = e & ((1u << p.log_c) - 1); rho = e >> p.log_c; }
         u64 g = ntt_global_index(p, tile, rho, col);
         Fr v = g < p.n_valid ? data[g] : Fr::zero(), f;
-        if (ntt_edge_factor(p, t, rho, g, 0, f)) v = v * f;
+        if (ntt_edge_factor(p, t, rho, g, 0, f)) v = p.load_mul ? ntt_mul_lazy2(v, f) : fe_mul_lazy(v, f);   // (load_mul: the factor is data too, not a table constant)
         lds_put(lds, ntt_plane_slots(p), ntt_lds_slot(p, rho, col), v);
     }
 }
@@ -165,16 +187,10 @@ MI_HD void ntt_tile_stage(const NttPass &p, const NttTables &t, u32 stage, u32 t
         const u32 PL = ntt_plane_slots(p);
         Fr x = lds_get(lds, PL, s0), y = lds_get(lds, PL, s1);
         // twiddle w_(2d)^j = w_4096^(j * 2048/d)
-        const Fr &w = t.small[j << (11 - log_d)];
-        Fr a = p.dit ? y : x - y;   // one product site for both butterflies
-        if (j) a = a * w;
-        if (p.dit) {
-            lds_put(lds, PL, s0, x + a);
-            lds_put(lds, PL, s1, x - a);
-        } else {
-            lds_put(lds, PL, s0, x + y);
-            lds_put(lds, PL, s1, a);
-        }
+        const Fr *w = j ? &t.small[j << (11 - log_d)] : nullptr;
+        if (p.dit) ntt_bfly_dit(x, y, w); else ntt_bfly_dif(x, y, w);
+        lds_put(lds, PL, s0, x);
+        lds_put(lds, PL, s1, y);
     }
 }
 // phase 3: LDS -> global (+ DIF post-twiddle, inverse / coset post-scale)
@@ -186,8 +202,9 @@ MI_HD void ntt_tile_store(const NttPass &p, const NttTables &t, Fr *data, u64 ti
         else { col = e & ((1u << p.log_c) - 1); rho = e >> p.log_c; }
         u64 g = ntt_global_index(p, tile, rho, col);
         Fr v = lds_get(lds, ntt_plane_slots(p), ntt_lds_slot(p, rho, col)), f;
-        if (ntt_edge_factor(p, t, rho, g, 1, f)) v = v * f;
-        if (p.store_sub) v = v - p.store_sub[g];
+        if (ntt_edge_factor(p, t, rho, g, 1, f)) v = fe_mul_lazy(v, f);                       // below 2p
+        if (p.store_sub) v = fe_sub_plus2p(fe_condsub_2p(v), fe_condsub_2p(p.store_sub[g]));  // below 4p
+        if (p.canon) v = fe_canon(v);
         data[g] = v;
     }
 }

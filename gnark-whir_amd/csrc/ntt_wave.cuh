@@ -41,20 +41,14 @@ MI_D void wave_ntt128(Fr &x0, Fr &x1, u32 lane, bool dit, const Fr *small) {
         for (int log_d = 6; log_d >= 0; log_d--) {
             const u32 d = 1u << log_d;
             if (log_d < 6) wave_select_trade(x0, x1, lane, d);
-            const Fr u = x0 + x1;
-            Fr t = x0 - x1;
-            if (log_d) t = t * small[(lane & (d - 1)) << (11 - log_d)];   // d = 1: every twiddle is 1
-            x0 = u; x1 = t;
+            ntt_bfly_dif(x0, x1, log_d ? &small[(lane & (d - 1)) << (11 - log_d)] : nullptr);   // d = 1: every twiddle is 1
         }
     } else {
 #pragma unroll 1
         for (int log_d = 0; log_d <= 6; log_d++) {
             const u32 d = 1u << log_d;
             if (log_d) wave_select_trade(x0, x1, lane, d >> 1);
-            Fr y = x1;
-            if (log_d) y = y * small[(lane & (d - 1)) << (11 - log_d)];
-            const Fr u = x0 + y;
-            x1 = x0 - y; x0 = u;
+            ntt_bfly_dit(x0, x1, log_d ? &small[(lane & (d - 1)) << (11 - log_d)] : nullptr);
         }
     }
 }

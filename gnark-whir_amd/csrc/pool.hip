@@ -51,7 +51,7 @@ struct InputSet {          // W | a | b | c of one staged host job
     void *p = nullptr;
     size_t cap = 0;
     bool busy = false;
-    int abc_state = 0;     // under the pool mutex: 0 = a, b, c still on their way, 1 = resident, -1 = their upload failed
+    int abc_state = 0;     // under the pool mutex: how many of a, b, c are resident (0..3; a job without c jumps from 1 to 3); -1 = their upload failed
     std::string abc_err;
 };
 }  // namespace
@@ -114,21 +114,21 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
         if (rc_pok != MI_OK) pok_err = mi_last_error(ctx);
         if (j->gated) {
             InputSet &set = p->sets[j->set];
-            const std::function<bool()> abc = [&]() -> bool {   // blocks until a, b, c are resident (or their upload has failed)
+            const std::function<bool(int)> abc = [&](int k) -> bool {   // blocks until k of a, b, c are resident (or their upload has failed)
                 std::unique_lock<std::mutex> lk(p->m);
-                p->cv_abc.wait(lk, [&] { return set.abc_state != 0; });
+                p->cv_abc.wait(lk, [&] { return set.abc_state < 0 || set.abc_state >= k; });
                 return set.abc_state > 0;
             };
             bool arrived;
             {
                 std::lock_guard<std::mutex> lk(p->m);
-                arrived = set.abc_state == 1;   // the steady state: the uploader is a job ahead
+                arrived = set.abc_state == 3;   // the steady state: the uploader is a job ahead
             }
             rc = mi_groth16_prove_dev_gated(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats, abc, arrived);
             // Whatever the prove returned -- it can fail BEFORE it reaches the gate (witness size mismatch, a part of a sharded key, a
             // workspace that does not fit) -- the uploader may still be copying this job's a, b, c from the caller's buffers and will
             // still write j->h2d_ms: the job is not finished (its waiter may free the Job and the buffers) until the uploader is done with it.
-            (void)abc();
+            (void)abc(3);
         } else {
             rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
         }
@@ -230,10 +230,19 @@ static void uploader_main(mi_prover *p) {
             }
             if (idle) { hand_over(true); handed = true; }
         };
+        // a, b, c one at a time, each announced as soon as it is resident: a worker that holds the job already (gated) enqueues a's
+        // transforms while b is still on the bus, b's while c is (prove.hip: mi_compute_h_part).  A pageable copy holds this thread for
+        // its duration anyway, so synchronising the stream after each costs nothing (and no event ever sits between two copies).
+        auto arrived = [&](int k) {
+            { std::lock_guard<std::mutex> lk(p->m); set.abc_state = k; }
+            p->cv_abc.notify_all();
+        };
         maybe_hand_over();
-        if (cb) e = hipMemcpyAsync(base + wb, ha, cb, hipMemcpyHostToDevice, p->copy_stream);
+        if (cb) { e = hipMemcpyAsync(base + wb, ha, cb, hipMemcpyHostToDevice, p->copy_stream); if (e == hipSuccess) e = hipStreamSynchronize(p->copy_stream); }
+        if (e == hipSuccess) arrived(1);
         maybe_hand_over();
-        if (e == hipSuccess && cb) e = hipMemcpyAsync(base + wb + cb, hb, cb, hipMemcpyHostToDevice, p->copy_stream);
+        if (e == hipSuccess && cb) { e = hipMemcpyAsync(base + wb + cb, hb, cb, hipMemcpyHostToDevice, p->copy_stream); if (e == hipSuccess) e = hipStreamSynchronize(p->copy_stream); }
+        if (e == hipSuccess && hc) arrived(2);
         maybe_hand_over();
         if (e == hipSuccess && cb && hc) e = hipMemcpyAsync(base + wb + 2 * cb, hc, cb, hipMemcpyHostToDevice, p->copy_stream);   // hc == null: c = a o b on the device
         if (e == hipSuccess) e = hipStreamSynchronize(p->copy_stream);   // a, b, c are resident when abc_state says so
@@ -241,7 +250,7 @@ static void uploader_main(mi_prover *p) {
         {
             std::lock_guard<std::mutex> lk(p->m);
             j->h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            set.abc_state = e == hipSuccess ? 1 : -1;
+            set.abc_state = e == hipSuccess ? 3 : -1;
             p->uploading = false;
         }
         // everything has arrived (the stream was synchronised above): the job runs the plain device-pointer path; a failed upload

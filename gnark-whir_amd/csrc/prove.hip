@@ -442,7 +442,7 @@ struct HostInputs { const mi_fr *W, *a, *b, *c; };
 // Device inputs that are still ARRIVING (the prover pool's upload stage, pool.hip): W is resident when the call is made; abc() blocks
 // the host until a, b, c are resident too and returns true (false: their upload failed).  Host-side waits on purpose: events recorded
 // on the pool's copy stream between its pageable copies slowed those copies down (round 3: uploads of 50-70 ms instead of 19).
-struct AbcGate { const std::function<bool()> *abc; bool abc_arrived; /* a, b, c were complete already when the job was picked up */ };
+struct AbcGate { const std::function<bool(int)> *abc; /* abc(k): blocks until k of a, b, c are resident */ bool abc_arrived; /* they all were when the job was picked up */ };
 
 // W, a, b, c: device buffers (for host inputs: staging areas the uploads below fill).
 static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c,
@@ -514,9 +514,20 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
             // inputs on their way into HBM (pool upload stage): the wire MSMs start as soon as W is there; a, b, c (3/4 of the bytes)
             // finish arriving behind them, and computeH waits for exactly that
             start_wires(nullptr);   // W is resident (the pool synchronised its copy stream before handing the job over)
-            if (!(*gate->abc)()) MI_FAIL(ctx, MI_EHIP, "prove: the upload of a, b, c failed");
             MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
-            return enqueue_h_and_z();
+            // computeH one vector at a time, as the vectors arrive (the direct host-pointer path below does the same): a's transforms
+            // run while b is on the bus; h is ready ~2.5 ms after the last vector instead of a whole computeH later
+            const auto need = [&](int k) -> int32_t { if (!(*gate->abc)(k)) MI_FAIL(ctx, MI_EHIP, "prove: the upload of a, b, c failed"); return MI_OK; };
+            MI_TRY(need(1));
+            MI_TRY(mi_compute_h_part(ctx, pk->log_n, 0, a, n_constraints, (mi_fr *)h));
+            MI_TRY(need(2));
+            MI_TRY(mi_compute_h_part(ctx, pk->log_n, 1, b, n_constraints, (mi_fr *)h));
+            if (derive_c) MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, a, n_constraints, (mi_fr *)h, b));
+            else { MI_TRY(need(3)); MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, c, n_constraints, (mi_fr *)h)); }
+            MI_TRY(mi_compute_h_part(ctx, pk->log_n, 3, nullptr, n_constraints, (mi_fr *)h));
+            MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
+            h_recorded.set_value(ev[3]); h_promised = true;
+            return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);
         }
         if (!host) {
             // inputs already in HBM
@@ -618,7 +629,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
 }
 
 int32_t mi_groth16_prove_dev_gated(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wires, const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
-                                   const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, const std::function<bool()> &abc_ready, bool abc_arrived) {
+                                   const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, const std::function<bool(int)> &abc_ready, bool abc_arrived) {
     const AbcGate gate{&abc_ready, abc_arrived};
     return prove_common(ctx, pk, W, n_wires, a, b, c, n_constraints, r, s, out, stats, nullptr, &gate);
 }

@@ -59,11 +59,12 @@ int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, hip
 int32_t mi_prove_enqueue_z_msm(mi_ctx *ctx, mi_pk *pk, const mi_fr *h_dev, hipEvent_t ev_h, bool defer_reduce = false);
 
 // mi_groth16_prove_dev over inputs that are still arriving in HBM (the prover pool's upload stage): W is resident; the wire MSMs are
-// enqueued at once; abc_ready() must block until a, b, c are resident too (false = their upload failed); computeH is enqueued after it.
-// abc_arrived: they already were when the job was picked up (the steady state).  Same proof bytes.
+// enqueued at once; abc_ready(k) must block until k of a, b, c (in that order) are resident (false = their upload failed): computeH is
+// enqueued one vector at a time behind them (k = 3 is never asked for when c is null).  abc_arrived: they all were when the job was
+// picked up (the steady state).  Same proof bytes.
 int32_t mi_groth16_prove_dev_gated(mi_ctx *ctx, mi_pk *pk, const mi_fr *W_dev, size_t n_wires, const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev,
                                    size_t n_constraints, const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats,
-                                   const std::function<bool()> &abc_ready, bool abc_arrived);
+                                   const std::function<bool(int)> &abc_ready, bool abc_arrived);
 
 // Blinding and assembly of Ar, Bs, Krs from the five MSM sums, exactly as gnark's prove.go composes them (row a9); host
 // code over O(1) points.  start() launches the multiples of delta on host threads while the GPU works; have_a_b1() needs

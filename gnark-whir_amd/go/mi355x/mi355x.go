@@ -184,13 +184,15 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 			if len(vals) > 0 { // an empty commitment is the point at infinity (the zero value already there)
 				pk.mu.Lock()
 				ppk, err := pk.pedersenKey(i)
-				if err == nil {
-					err = status(pk.ctx, C.mi_pedersen_commit(pk.ctx, ppk, (*C.mi_fr)(unsafe.Pointer(&vals[0])), C.size_t(len(vals)),
-						(*C.mi_g1_affine)(unsafe.Pointer(&proof.Commitments[i]))))
-				}
 				pk.mu.Unlock()
 				if err != nil {
 					return err
+				}
+				// mi_prover_commit: synchronous, safe from any goroutine (the pool serialises the commitments of all callers
+				// on a context of its own, ahead of the proofs in flight)
+				if rc := C.mi_prover_commit(pk.pool, ppk, (*C.mi_fr)(unsafe.Pointer(&vals[0])), C.size_t(len(vals)),
+					(*C.mi_g1_affine)(unsafe.Pointer(&proof.Commitments[i]))); rc != C.MI_OK {
+					return fmt.Errorf("mi355x: mi_prover_commit rc=%d: %s", int(rc), C.GoString(C.mi_prover_last_error(pk.pool)))
 				}
 			}
 			opt.HashToFieldFn.Write(constraint.SerializeCommitment(proof.Commitments[i].Marshal(), hashed, (fr.Bits-1)/8+1))
@@ -215,20 +217,19 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 	W, a, b, c := []fr.Element(solution.W), []fr.Element(solution.A), []fr.Element(solution.B), []fr.Element(solution.C)
 
 	// CommitmentPok as prove.go builds it: challenge = fr.Hash(commitment WIRE VALUES, "G16-BSB22"), then
-	// pedersen.BatchProve = sum_i challenge^i * ProveKnowledge_i; both MSMs on the device (mi_pedersen_prove_knowledge),
-	// the fold over len(commitmentInfo) points on the host (mi_pedersen_fold).
+	// pedersen.BatchProve = sum_i challenge^i * ProveKnowledge_i.  The hash stays here; the MSMs over BasisExpSigma and the fold
+	// ride in the proof's pool job (mi_prover_submit_bsb22), beside its five MSMs.
+	var challenge fr.Element
 	if len(commitmentInfo) > 0 {
 		commitmentsSerialized := make([]byte, fr.Bytes*len(commitmentInfo))
 		for i := range commitmentInfo {
 			copy(commitmentsSerialized[fr.Bytes*i:], W[commitmentInfo[i].CommitmentIndex].Marshal())
 		}
-		challenge, err := fr.Hash(commitmentsSerialized, []byte("G16-BSB22"), 1)
+		ch, err := fr.Hash(commitmentsSerialized, []byte("G16-BSB22"), 1)
 		if err != nil {
 			return nil, err
 		}
-		if proof.CommitmentPok, err = pk.batchProve(privateCommittedValues, challenge[0]); err != nil {
-			return nil, err
-		}
+		challenge = ch[0]
 	}
 
 	// same sampling order as prove.go so a test that swaps rand.Reader gets byte-identical proofs
@@ -243,31 +244,78 @@ func Prove(r1cs *cs.R1CS, pk *ProvingKey, fullWitness witness.Witness, opts ...b
 	// submit + wait on the pool: this goroutine blocks in cgo (the Go scheduler parks it on its own OS thread) while the
 	// proofs of other goroutines overlap with it on the GPU.  The output lives in C memory: the library writes it from a
 	// worker thread after this cgo call has returned, which Go memory passed by pointer must not be used for.
-	out := (*C.mi_proof_out)(C.malloc(C.size_t(unsafe.Sizeof(C.mi_proof_out{}))))
+	// out and pok live in C memory: the library writes them from a worker thread after this cgo call has returned
+	out := (*C.mi_proof_out)(C.calloc(1, C.size_t(unsafe.Sizeof(C.mi_proof_out{}))))
+	pok := (*C.mi_g1_affine)(C.calloc(1, C.size_t(unsafe.Sizeof(C.mi_g1_affine{}))))
 	defer C.free(unsafe.Pointer(out))
-	var pin runtime.Pinner // W, a, b, c are read by the worker thread until mi_prover_wait returns
+	defer C.free(unsafe.Pointer(pok))
+	var pin runtime.Pinner // W, a, b and the committed values are read by library threads until mi_prover_wait returns
 	if len(W) == 0 || len(a) == 0 {
 		return nil, errors.New("mi355x: empty solution")
 	}
-	pin.Pin(&W[0]); pin.Pin(&a[0]); pin.Pin(&b[0]); pin.Pin(&c[0])
+	pin.Pin(&W[0]); pin.Pin(&a[0]); pin.Pin(&b[0])
 	defer pin.Unpin()
+	// the mi_bsb22_input array lives in C memory too (it holds pointers to pinned Go arrays: the withKeyDesc rule)
+	nb := 0
+	for i := range privateCommittedValues {
+		if len(privateCommittedValues[i]) > 0 {
+			nb++
+		}
+	}
+	var bsb *C.mi_bsb22_input
+	if nb > 0 {
+		if nb != len(commitmentInfo) {
+			return nil, errors.New("mi355x: empty commitments between non-empty ones are not supported") // (gnark: every commitment has committed wires)
+		}
+		bsb = (*C.mi_bsb22_input)(C.calloc(C.size_t(nb), C.size_t(unsafe.Sizeof(C.mi_bsb22_input{}))))
+		defer C.free(unsafe.Pointer(bsb))
+		arr := unsafe.Slice(bsb, nb)
+		pk.mu.Lock()
+		for i := range privateCommittedValues {
+			ppk, err := pk.pedersenKey(i)
+			if err != nil {
+				pk.mu.Unlock()
+				return nil, err
+			}
+			pin.Pin(&privateCommittedValues[i][0])
+			arr[i].key, arr[i].values, arr[i].n = ppk, (*C.mi_fr)(unsafe.Pointer(&privateCommittedValues[i][0])), C.size_t(len(privateCommittedValues[i]))
+		}
+		pk.mu.Unlock()
+	}
+	// c is NOT passed: solution.C = solution.A o solution.B row by row for every witness the solver accepts, and the library forms it
+	// on the device (a quarter of the proof's PCIe bytes; mi355x_groth16.h, mi_groth16_prove).  `c` stays referenced for callers that
+	// set PassC (e.g. a test that feeds an unsatisfied system on purpose).
+	var cptr *C.mi_fr
+	if PassC {
+		pin.Pin(&c[0])
+		cptr = (*C.mi_fr)(unsafe.Pointer(&c[0]))
+	}
 	var ticket C.uint64_t
-	rc := C.mi_prover_submit(pk.pool, pk.dev,
+	rc := C.mi_prover_submit_bsb22(pk.pool, pk.dev,
 		(*C.mi_fr)(unsafe.Pointer(&W[0])), C.size_t(len(W)),
-		(*C.mi_fr)(unsafe.Pointer(&a[0])), (*C.mi_fr)(unsafe.Pointer(&b[0])), (*C.mi_fr)(unsafe.Pointer(&c[0])), C.size_t(len(a)),
-		(*C.mi_fr)(unsafe.Pointer(&r)), (*C.mi_fr)(unsafe.Pointer(&s)), out, nil, &ticket)
+		(*C.mi_fr)(unsafe.Pointer(&a[0])), (*C.mi_fr)(unsafe.Pointer(&b[0])), cptr, C.size_t(len(a)),
+		(*C.mi_fr)(unsafe.Pointer(&r)), (*C.mi_fr)(unsafe.Pointer(&s)), bsb, C.uint32_t(nb), (*C.mi_fr)(unsafe.Pointer(&challenge)),
+		out, pok, nil, &ticket)
 	if rc != C.MI_OK {
-		return nil, fmt.Errorf("mi355x: mi_prover_submit rc=%d", int(rc))
+		return nil, fmt.Errorf("mi355x: mi_prover_submit_bsb22 rc=%d", int(rc))
 	}
 	if rc := C.mi_prover_wait(pk.pool, ticket); rc != C.MI_OK {
 		return nil, fmt.Errorf("mi355x: rc=%d: %s", int(rc), C.GoString(C.mi_prover_last_error(pk.pool)))
 	}
 	runtime.KeepAlive(W)
+	runtime.KeepAlive(c)
 	proof.Ar = *(*bn254.G1Affine)(unsafe.Pointer(&out.ar))
 	proof.Bs = *(*bn254.G2Affine)(unsafe.Pointer(&out.bs))
 	proof.Krs = *(*bn254.G1Affine)(unsafe.Pointer(&out.krs))
+	if nb > 0 {
+		proof.CommitmentPok = *(*bn254.G1Affine)(unsafe.Pointer(pok))
+	}
 	return proof, nil
 }
+
+// PassC makes Prove upload solution.C as well instead of letting the device form it as A o B (the default; identical proofs for every
+// witness the solver accepts).
+var PassC = false
 
 // pedersenKey uploads CommitmentKeys[i].Basis / BasisExpSigma once (mi_pedersen_pk_load).
 func (pk *ProvingKey) pedersenKey(i int) (*C.mi_pedersen_pk, error) {

@@ -257,7 +257,7 @@ extern "C" int emu_ntt_fused(void *data_v, uint32_t log_n, uint32_t flags, uint3
         if (step == pl.n_pass - 1 && store_scale) { if (p.scale) return -1; p.scale = store_scale; }
         p.n_valid = step == 0 ? n_valid : (1u << log_n);
         if (step == 0) p.load_mul = (const Fr *)load_mul;
-        if (step == pl.n_pass - 1) p.store_sub = (const Fr *)store_sub;
+        if (step == pl.n_pass - 1) { p.store_sub = (const Fr *)store_sub; p.canon = 1; }   // (the elements are lazily reduced until the last store: ntt_tile.cuh)
         u32 tiles = 1u << (log_n - p.log_r - p.log_c);
         std::vector<U4> lds((size_t)2 << (p.log_r + p.log_c));
         for (u32 tile = 0; tile < tiles; tile++) {
