@@ -519,3 +519,21 @@ def test_batch_affine_level1_rounds_agree_with_oracle(ctx, rounds):
         assert _jac_eq(ctx.msm_g1(same, ssc), want_same), rounds
     finally:
         assert lib.mi_debug_set_msm_batch_affine(ctx.h, 0) == 0 and lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
+
+
+def test_published_alt_bn128_vectors_through_the_hip_path(ctx):
+    """EIP-196 ecAdd / ecMul and EIP-197's G2 generator (the vectors tests/test_oracle.py pins both oracles with) through the device
+    code: point addition kernels, the MSMs (level-1 mixed additions, doubling fallback, bucket reduce), the batch scalar multiplication"""
+    from test_oracle import EIP196_ADD, EIP196_MUL, EIP196_DOUBLE_G, EIP196_TRIPLE_G, EIP197_G2
+    B = load_binding()
+    a, b, c = EIP196_ADD
+    assert g1_pts(ctx.ec_add(g1_arr([a, P.G1_GEN, P.G1_GEN]), g1_arr([b, P.G1_GEN, EIP196_DOUBLE_G]))) == [c, EIP196_DOUBLE_G, EIP196_TRIPLE_G]
+    assert g1_from_jac(ctx.msm_g1(g1_arr([a, b]), fr_arr([1, 1]))) == c
+    pt, k, want = EIP196_MUL
+    assert g1_from_jac(ctx.msm_g1(g1_arr([pt]), fr_arr([k]))) == want
+    assert g1_pts(ctx.batch_scalar_mul(g1_arr([pt])[0], fr_arr([k, 1])))[0] == want
+    assert g1_pts(ctx.batch_scalar_mul(g1_arr([P.G1_GEN])[0], fr_arr([2, 3, P.R_MOD - 1]))) == [EIP196_DOUBLE_G, EIP196_TRIPLE_G, P.g1_neg(P.G1_GEN)]
+    # r G = infinity through an MSM that is all one point: (r - 1) G + G, on both curves
+    assert g1_from_jac(ctx.msm_g1(g1_arr([P.G1_GEN, P.G1_GEN]), fr_arr([P.R_MOD - 1, 1]))) is None
+    assert g2_from_jac(ctx.msm_g2(g2_arr([EIP197_G2, EIP197_G2]), fr_arr([P.R_MOD - 1, 1]))) is None
+    assert g2_pts(ctx.batch_scalar_mul(g2_arr([EIP197_G2])[0], fr_arr([P.R_MOD - 1]), g2=True)) == [P.g2_neg(EIP197_G2)]
