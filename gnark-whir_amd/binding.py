@@ -27,7 +27,7 @@ EXPORTS = [
     "mi_debug_set_prove_fixed_base", "mi_debug_set_prove_schedule", "mi_debug_set_msm_batch_affine", "mi_debug_set_msm_group_bits", "mi_debug_inject_hip_failure", "mi_debug_set_ntt_plan", "mi_debug_set_ntt_threads", "mi_debug_set_ntt_wave_stages",
     "mi_debug_set_msm_plan", "mi_debug_set_msm_chunk", "mi_debug_set_msm_one_pass_sort", "mi_debug_set_msm_bound_levels", "mi_debug_set_msm_limb29", "mi_debug_set_msm_l1_waves", "mi_debug_set_msm_precompute_batched", "mi_debug_set_ntt_fuse_pair",
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
-    "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22",
+    "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22", "mi_prover_trim", "mi_ctx_trim",
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_create_rank_ex", "mi_group_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
     "mi_group_last_error", "mi_group_transport", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
     "mi_groth16_prove_sharded", "mi_groth16_prove_sharded_dev", "mi_pk_load_sharded_dev", "mi_msm_g1_sharded", "mi_msm_g2_sharded",
@@ -346,6 +346,10 @@ class Context:
         self._ck(f(self.h, pk, _p(values), C.c_size_t(values.shape[0]), _p(out)))
         return out
 
+    def trim(self):
+        """mi_ctx_trim: every grow-only workspace of this (idle) context goes back to the device"""
+        self._ck(self.lib.mi_ctx_trim(self.h))
+
     def stats(self):
         st = Stats(); self._ck(self.lib.mi_get_stats(self.h, C.byref(st))); return st.as_dict()
 
@@ -428,6 +432,11 @@ class Prover:
             raise MiError(f"mi_prover_submit_bsb22: rc={rc}")
         self._pending[t.value] = (out, st, {"keep": (W, a, b, c, vals, arr, challenge), "pok": pok})
         return t.value
+
+    def trim(self):
+        rc = self.lib.mi_prover_trim(self.h)
+        if rc != 0:
+            raise MiError(f"mi_prover_trim rc={rc}: {self.lib.mi_prover_last_error(self.h).decode()}")
 
     def close(self):
         if self.h:

@@ -56,6 +56,20 @@ int32_t mi_shutdown(mi_ctx *ctx) {
     delete ctx;
     return MI_OK;
 }
+// Gives the grow-only workspaces of an IDLE context back to the device: scratch buffers, every MSM slot's sort / partial-sum / bucket
+// arrays, the NTT tables (rebuilt in a few ms by the next transform of a size).  Streams, events and pinned result buffers stay.  The
+// next call grows what it needs again (hipMalloc, as on first use).  The caller guarantees that no call is running on ctx.
+int32_t mi_ctx_trim(mi_ctx *ctx) {
+    if (!ctx) return MI_EINVAL;
+    MI_CHECK_HIP(ctx, hipSetDevice(ctx->dev));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    for (auto &sl : ctx->msm) if (sl.stream) MI_CHECK_HIP(ctx, hipStreamSynchronize(sl.stream));
+    for (auto &b : ctx->ws) if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    for (auto &sl : ctx->msm) for (auto &b : sl.buf) if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    mi_ntt_state_trim(ctx);
+    return MI_OK;
+}
 const char *mi_last_error(mi_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 int32_t mi_set_stream(mi_ctx *ctx, void *hip_stream) {
     if (!ctx) return MI_EINVAL;

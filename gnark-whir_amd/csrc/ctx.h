@@ -121,6 +121,7 @@ int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *sr
 void mi_ntt_state_init(mi_ctx *ctx);
 size_t mi_ntt_table_bytes(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);
+void mi_ntt_state_trim(mi_ctx *ctx);   // frees every table and marks them unbuilt (mi_ctx_trim)
 int32_t mi_msm_state_init(mi_ctx *ctx);   // MI_OK or the first failing HIP call; partial state is freed by mi_msm_state_free
 // Stream priority schemes (3 hardware levels; comment in msm.hip).  A context on its own ranks computeH high, the wire MSMs
 // normal and Z low.  The contexts of a prover pool are staggered on top of that: the first runs nearly as if alone, the

@@ -71,6 +71,12 @@ void mi_ntt_state_free(mi_ctx *ctx) {
     for (Fr **p : all) if (*p) { (void)hipFree(*p); *p = nullptr; }
 }
 
+// mi_ctx_trim: every table goes; the markers say "nothing built", the plan knobs stay
+void mi_ntt_state_trim(mi_ctx *ctx) {
+    mi_ntt_state_free(ctx);
+    NttState *st = state_of(ctx);
+    st->log_n = 0xffffffffu; st->d_log_n = 0xffffffffu; st->d_log_r0 = 0; st->d_npass = 0;
+}
 // bytes of device memory the context's NTT tables take (mi_get_mem_ledger)
 size_t mi_ntt_table_bytes(mi_ctx *ctx) {
     const NttState *st = state_of(ctx);

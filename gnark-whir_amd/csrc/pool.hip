@@ -384,6 +384,23 @@ int32_t mi_prover_commit(mi_prover *p, mi_pedersen_pk *key, const mi_fr *values,
     return rc;
 }
 
+// mi_ctx_trim for every context of an IDLE pool (nothing submitted and not yet waited for) plus its device input sets
+int32_t mi_prover_trim(mi_prover *p) {
+    if (!p) return MI_EINVAL;
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        if (!p->upq.empty() || !p->queue.empty() || p->busy || p->uploading) { p->err = "prover: trim needs an idle pool"; return MI_EINVAL; }
+        for (InputSet &s : p->sets) if (s.busy) { p->err = "prover: trim needs an idle pool"; return MI_EINVAL; }
+    }
+    (void)hipSetDevice(p->dev);
+    int32_t rc = MI_OK;
+    for (mi_ctx *c : p->ctx) { const int32_t r = mi_ctx_trim(c); if (r != MI_OK && rc == MI_OK) rc = r; }
+    if (p->commit_ctx) { const int32_t r = mi_ctx_trim(p->commit_ctx); if (r != MI_OK && rc == MI_OK) rc = r; }
+    (void)hipStreamSynchronize(p->copy_stream);
+    for (InputSet &s : p->sets) if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+    return rc;
+}
+
 int32_t mi_prover_wait(mi_prover *p, uint64_t ticket) {
     if (!p) return MI_EINVAL;
     std::unique_lock<std::mutex> lk(p->m);

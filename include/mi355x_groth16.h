@@ -214,6 +214,11 @@ typedef struct mi_mem_ledger {
     uint64_t ctx_other;        /* staging areas for host inputs and the rest */
 } mi_mem_ledger;
 int32_t mi_get_mem_ledger(mi_ctx *ctx, const mi_pk *pk, mi_mem_ledger *out);
+/* Workspaces only ever grow (no hipMalloc in steady state).  mi_ctx_trim gives them back: every scratch buffer, MSM slot array and NTT
+ * table of an IDLE context is freed (streams, events and keys stay); the next call grows what it needs again.  For a service that has
+ * proved an N = 2^26 circuit and goes back to 2^23, or before loading a second large key.  mi_prover_trim does the same for every
+ * context and input set of an idle pool (MI_EINVAL while jobs are queued or running). */
+int32_t mi_ctx_trim(mi_ctx *ctx);
 
 /* ---- prover pool: several proofs in flight on one device.
  * The reference proves one circuit per groth16.Prove call (mt.go:496) and a prover service issues those calls from many
@@ -242,6 +247,7 @@ int32_t mi_prover_submit_dev(mi_prover *p, mi_pk *pk, const mi_fr *W_dev, size_t
                              const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev, size_t n_constraints,
                              const mi_fr *r, const mi_fr *s, mi_proof_out *out, mi_stats *stats, uint64_t *ticket);
 int32_t mi_prover_wait(mi_prover *p, uint64_t ticket);
+int32_t mi_prover_trim(mi_prover *p);
 /* The proof the WHIR circuit really produces carries one BSB22 commitment (/root/reference/utilities/utilities.go:189
  * logderivlookup.New and mtUtilities.go:452 uints.New force it: SURVEY 3.3 steps 1 and 3, row a10).  Through the pool:
  *   mi_prover_commit        pedersen Commit INSIDE the solve (the hint override): synchronous, callable from any thread, one

@@ -276,6 +276,11 @@ def test_full_size_prove_equals_composition_of_primitives(ctx, log_n):
     by one on the same device arrays) plus O(1) point operations done by the oracle."""
     B = load_binding()
     N = 1 << log_n
+    # the module's context has run every earlier test: its grow-only workspaces go back first (mi_ctx_trim), so that the sizes that
+    # want most of the GPU do not inherit them (round 3: an out-of-memory at 2^26 after 70 tests' worth of workspaces)
+    ctx.trim()
+    led = ctx.mem_ledger()
+    assert sum(v for k, v in led.items() if k.startswith("ctx_")) == 0, led
     nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
     rng = np.random.default_rng(7)
     inf_a = (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8); inf_b = (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
@@ -537,3 +542,35 @@ def test_published_alt_bn128_vectors_through_the_hip_path(ctx):
     assert g1_from_jac(ctx.msm_g1(g1_arr([P.G1_GEN, P.G1_GEN]), fr_arr([P.R_MOD - 1, 1]))) is None
     assert g2_from_jac(ctx.msm_g2(g2_arr([EIP197_G2, EIP197_G2]), fr_arr([P.R_MOD - 1, 1]))) is None
     assert g2_pts(ctx.batch_scalar_mul(g2_arr([EIP197_G2])[0], fr_arr([P.R_MOD - 1]), g2=True)) == [P.g2_neg(EIP197_G2)]
+
+
+def test_trim_gives_the_workspaces_back_and_the_next_proof_is_the_same(ctx):
+    """mi_ctx_trim / mi_prover_trim: an idle context (pool) frees its grow-only workspaces; proving goes on with the same bytes"""
+    B = load_binding()
+    log_n = 14
+    N = 1 << log_n
+    pk = synthetic_pk(log_n, N - 50, 33, 6100, n_committed=9)
+    W = cref.gen_scalars(N - 50, 1, 1); a = cref.gen_scalars(N - 10, 2, 1); b = cref.gen_scalars(N - 10, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    pkh = ctx.pk_load(pk)
+    assert B.proof_write(ctx.prove(pkh, W, a, b, c, r, s)[0]["raw"]) == want
+    before = ctx.mem_ledger(pkh)
+    assert before["ctx_msm"] > 0 and before["ctx_ntt_vectors"] > 0
+    ctx.trim()
+    after = ctx.mem_ledger(pkh)
+    assert all(after[k] == 0 for k in after if k.startswith("ctx_")), after
+    assert after["key_bases"] == before["key_bases"] and after["key_tables"] == before["key_tables"]   # keys are not workspaces
+    assert B.proof_write(ctx.prove(pkh, W, a, b, c, r, s)[0]["raw"]) == want
+    assert np.array_equal(ctx.ntt(a[:1 << 12], 12, 3), cref.ntt(a[:1 << 12], 12, 3))
+    pool = B.Prover(0, 2)
+    t = pool.submit(pkh, W, a, b, None, r, s)
+    with pytest.raises(B.MiError, match="idle"):
+        pool.trim()   # (a job is queued or running; if it has finished already the trim simply succeeds: then raise by hand)
+        raise B.MiError("idle: the job had finished")
+    assert B.proof_write(pool.wait(t)[0]["raw"]) == want
+    pool.trim()
+    assert all(v == 0 for k, v in pool.ctx(0).mem_ledger().items() if k.startswith("ctx_"))
+    assert B.proof_write(pool.wait(pool.submit(pkh, W, a, b, c, r, s))[0]["raw"]) == want
+    pool.close()
+    ctx.pk_free(pkh)
