@@ -33,6 +33,8 @@ EXPORTS = [
     "mi_groth16_prove_sharded", "mi_groth16_prove_sharded_dev", "mi_pk_load_sharded_dev", "mi_msm_g1_sharded", "mi_msm_g2_sharded",
     "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
     "mi_pk_raw_inspect", "mi_pk_load_raw",
+    "mi_whir_proof_decode", "mi_whir_proof_free", "mi_whir_proof_elements", "mi_whir_proof_statement_values", "mi_whir_element_shape", "mi_whir_parse_paths",
+    "mi_whir_reverse", "mi_whir_prefix_decode_path", "mi_whir_limbs_to_fr", "mi_whir_interner_decode", "mi_whir_matrix_cells", "mi_whir_config_parse", "mi_whir_config_free",
 ]
 
 
