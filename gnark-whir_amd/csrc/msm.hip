@@ -319,15 +319,26 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     // that ranks Z below the rest measured within 1 % of that; all-equal, high or normal, did not).
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    int idx = 0;
-    for (auto &sl : ctx->msm) {
+    // The runtime maps streams onto a few hardware queues in creation order, and two streams on one queue run one after the other: the
+    // order in which the slots' streams are created decides WHICH two MSMs of a proof share a queue (rocprofv3: with the natural order
+    // K (slot 3) queued behind B2's whole G2 chain (slot 2) and ended a single proof).  MI_MSM_STREAM_ORDER overrides it (experiments).
+    int order[MI_MSM_SLOTS] = {0, 1, 2, 3, 4, 5};
+    if (const char *e = getenv("MI_MSM_STREAM_ORDER")) {
+        int got[MI_MSM_SLOTS], n = 0; bool seen[MI_MSM_SLOTS] = {};
+        for (const char *q = e; *q && n < MI_MSM_SLOTS; q++) if (*q >= '0' && *q < '0' + MI_MSM_SLOTS && !seen[*q - '0']) { seen[*q - '0'] = true; got[n++] = *q - '0'; }
+        if (n == MI_MSM_SLOTS) for (int i = 0; i < n; i++) order[i] = got[i];
+    }
+    for (int k = 0; k < MI_MSM_SLOTS; k++) {
+        const int idx = order[k];
+        MsmSlot &sl = ctx->msm[idx];
         int pw = 0, pz = prio_lo;   // wires, Z: MI_PRIO_SOLO, MI_PRIO_POOL_SECOND
         if (ctx->prio_scheme == MI_PRIO_POOL_FIRST) { pw = prio_hi; pz = 0; }
         if (ctx->prio_scheme == MI_PRIO_POOL_REST) pw = pz = prio_lo;
         // every failure is reported: a null stream / event / host_wsum would otherwise surface much later as a memcpy into
         // null (msm_accum_enqueue).  The caller (mi_init_prio) unwinds through mi_shutdown, which frees what was created.
         MI_CHECK_HIP(ctx, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, idx == 4 ? pz : pw));
-        idx++;
+    }
+    for (auto &sl : ctx->msm) {
         for (auto &e : sl.ev) MI_CHECK_HIP(ctx, hipEventCreate(&e));
         MI_CHECK_HIP(ctx, hipHostMalloc(&sl.host_wsum, 128 * 256 + 64));
     }
