@@ -371,6 +371,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=0,
                     help="proofs kept in flight per GPU by the prover pool (mi_prover_*); 1 = strictly one proof at a time; "
                          "0 = 3 up to N=2^24, 1 above (a context's workspaces take about 1.2 KB x N of HBM)")
+    ap.add_argument("--callers", type=int, default=0, help="caller threads that issue the steps (each: Commit, submit, wait, WriteTo); 0 = in_flight + 1")
     ap.add_argument("--msm-plan", default="", help="tuning: c,L1,L2,seg,G for mi_debug_set_msm_plan on every context (0 = automatic)")
     ap.add_argument("--fixed-base", default="", help="tuning: c_ak,c_b,c_z for mi_debug_set_prove_fixed_base before the key is loaded (0 = automatic, 1 = off)")
     ap.add_argument("--ntt-plan", default="", help="tuning: log_e,max_contig,max_strided[,threads] for mi_debug_set_ntt_plan / _threads on every context")
@@ -560,7 +561,7 @@ def main():
     if not want_cpu:
         ch = None
     from concurrent.futures import ThreadPoolExecutor
-    callers = pool.in_flight + 1
+    callers = args.callers if args.callers > 0 else pool.in_flight + 1
     ex = ThreadPoolExecutor(callers)
     list(ex.map(lambda _: one_step(), range(max(args.warmup, callers))))   # the W warm-up steps, through the same path
 

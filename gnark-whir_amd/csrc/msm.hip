@@ -435,8 +435,12 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
                                 (char *)sl.buf[B_BA_TOT].p + ba_tot, time_first ? sl.ev[1] : nullptr);
         } else if (rp_path) {
             MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
+            // which build of the G1 level-1 kernel: three waves per SIMD (168 VGPRs: a SIMD's register file is full, and a freed wave slot
+            // is too small for any 256-VGPR G2 workgroup, which then waits for the END of this launch) or two (196: one freed slot admits one)
+            static const int z_waves = getenv("MI_G1_Z_WAVES") ? atoi(getenv("MI_G1_Z_WAVES")) : 0;   // experiment: the Z MSM's launch alone
+            const bool two = knobs_of(ctx)->l1_waves == 2 || (z_waves == 2 && &sl == &ctx->msm[4]);
             ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p,
-                                (rp_partials ? 1u : 0u) | (knobs_of(ctx)->l1_waves == 2 ? 2u : 0u), time_first ? sl.ev[1] : nullptr);
+                                (rp_partials ? 1u : 0u) | (two ? 2u : 0u), time_first ? sl.ev[1] : nullptr);
         } else if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else if (rp_partials) ops.accum_xyzz_rp(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);

@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <deque>
+#include <future>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -109,8 +110,15 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
         std::vector<mi_g1_affine> poks(nb);
         std::string pok_err;
         for (size_t i = 0; i + 1 < nb && rc_pok == MI_OK; i++) rc_pok = mi_pedersen_prove_knowledge(ctx, j->bsb[i].key, j->bsb[i].values, j->bsb[i].n, &poks[i]);
+        // (enqueued from a helper thread while this one enqueues the proof: the PoK's sort waits once on the host for its count pass, and
+        //  the values' pageable copy holds its thread -- neither should delay the proof's own kernels; slot 5 and ws[19] are the PoK's alone)
         bool pok_pending = false;
-        if (nb && rc_pok == MI_OK) { rc_pok = mi_pedersen_pok_enqueue(ctx, j->bsb[nb - 1].key, j->bsb[nb - 1].values, j->bsb[nb - 1].n); pok_pending = rc_pok == MI_OK; }
+        std::future<int32_t> f_pok;
+        if (nb && rc_pok == MI_OK) {
+            mi_pedersen_pk *key = j->bsb[nb - 1].key; const mi_fr *vals = j->bsb[nb - 1].values; const size_t nv = j->bsb[nb - 1].n; const int dev = p->dev;
+            auto enq = [=]() -> int32_t { try { (void)hipSetDevice(dev); return mi_pedersen_pok_enqueue(ctx, key, vals, nv); } catch (...) { return MI_ENOMEM; } };
+            try { f_pok = std::async(std::launch::async, enq); } catch (...) { rc_pok = enq(); pok_pending = rc_pok == MI_OK; }
+        }
         if (rc_pok != MI_OK) pok_err = mi_last_error(ctx);
         if (j->gated) {
             InputSet &set = p->sets[j->set];
@@ -133,6 +141,7 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
             rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
         }
         std::string prove_err = rc != MI_OK ? mi_last_error(ctx) : "";
+        if (f_pok.valid()) { rc_pok = f_pok.get(); pok_pending = rc_pok == MI_OK; if (rc_pok != MI_OK) pok_err = "prover: enqueueing the ProveKnowledge MSM failed"; }
         if (pok_pending) {   // collected whatever the proof did: slot 5 must be idle for the next job
             const int32_t r2 = mi_pedersen_pok_collect(ctx, &poks[nb - 1]);
             if (r2 != MI_OK && rc_pok == MI_OK) { rc_pok = r2; pok_err = mi_last_error(ctx); }

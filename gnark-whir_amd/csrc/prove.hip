@@ -198,14 +198,42 @@ static XYZZ<F> host_scalar_mul(const Affine<F> &p, const Fr &k_canon) { return x
 struct mi_pedersen_pk {
     void *basis = nullptr, *basis_exp_sigma = nullptr;
     size_t n = 0;
+    // fixed-base window tables of both arrays (as for pk.G1.*: ONE bucket set for all windows, the level-1 additions in 29-bit limbs over
+    // the R' form) when the key has >= 2^15 points and they fit: a commitment over 2^18 WHIR-mix values is then 15 windows into 2^16 buckets
+    // instead of 19 windows x 2^13 -- the bucket reduce of the generic plan was most of what a Pedersen MSM cost a busy GPU (r4: 3.5 % of
+    // the proofs/s at 2^18 committed wires, 8.6 % at 2^20)
+    void *pre_basis = nullptr, *pre_sigma = nullptr;
+    u32 c_tab = 0;
 };
+static constexpr u32 PEDERSEN_TABLE_C = 17;
+// best effort: without room (or below 2^15 points) the key stays on the generic path
+static void pedersen_build_tables(mi_ctx *ctx, mi_pedersen_pk *pk) {
+    static const bool off = getenv("MI_PEDERSEN_TABLES") && atoi(getenv("MI_PEDERSEN_TABLES")) == 0;   // A/B switch
+    if (off || pk->n < ((size_t)1 << 15) || !mi_msm_limb29_enabled(ctx)) return;
+    const u32 c = PEDERSEN_TABLE_C;
+    const size_t nwin = (256 + c - 1) / c, bytes = nwin * pk->n * sizeof(G1Aff);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || 2 * bytes > free_b / 4) { (void)hipGetLastError(); return; }
+    void *t[2] = {nullptr, nullptr};
+    const void *src[2] = {pk->basis, pk->basis_exp_sigma};
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; k++) {
+        ok = hipMalloc(&t[k], bytes) == hipSuccess && mi_msm_precompute(ctx, 1, src[k], t[k], pk->n, c) == MI_OK;
+        if (ok) mi_msm_ops(1).to_rprime(ctx->stream, t[k], t[k], nwin * pk->n);
+    }
+    if (ok) ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); for (void *q : t) if (q) (void)hipFree(q); return; }
+    pk->pre_basis = t[0]; pk->pre_sigma = t[1]; pk->c_tab = c;
+}
 // One Pedersen MSM on slot 5 of ctx (its own stream: it runs beside the five MSMs of a proof), in two halves so that a prover-pool job
 // can enqueue its proof's ProveKnowledge MSM, prove, and collect (pool.hip); host values in, affine point out.
-static int32_t pedersen_enqueue(mi_ctx *ctx, const void *bases_dev, size_t key_n, const mi_fr *values, size_t n) {
+static int32_t pedersen_enqueue(mi_ctx *ctx, const void *bases_dev, const void *tables_dev, u32 c_tab, size_t key_n, const mi_fr *values, size_t n) {
     if (!ctx || (!values && n)) return MI_EINVAL;
     if (n > key_n) MI_FAIL(ctx, MI_EINVAL, "pedersen: more values than basis points");   // gnark: "must have as many values as basis elements"
     MI_TRY(mi_reserve(ctx, ctx->ws[19], n * sizeof(mi_fr) + 64));
     if (n) MI_CHECK_HIP(ctx, hipMemcpyAsync(ctx->ws[19].p, values, n * sizeof(mi_fr), hipMemcpyHostToDevice, ctx->msm[5].stream));
+    // the tables are laid out [window][key_n]: they serve exactly the full-length call (gnark's: as many values as basis elements)
+    if (tables_dev && n == key_n) return mi_msm_enqueue(ctx, 5, -1, 1, tables_dev, ctx->ws[19].p, n, MI_MSM_PTS_RPRIME, nullptr, false, c_tab);
     return mi_msm_enqueue(ctx, 5, -1, 1, bases_dev, ctx->ws[19].p, n, 0, nullptr, false);
 }
 static int32_t pedersen_collect(mi_ctx *ctx, mi_g1_affine *out) {
@@ -215,14 +243,14 @@ static int32_t pedersen_collect(mi_ctx *ctx, mi_g1_affine *out) {
     if (out) std::memcpy(out, &a, sizeof(a));
     return MI_OK;
 }
-static int32_t pedersen_msm(mi_ctx *ctx, const void *bases_dev, size_t key_n, const mi_fr *values, size_t n, mi_g1_affine *out) {
+static int32_t pedersen_msm(mi_ctx *ctx, const mi_pedersen_pk *pk, bool sigma, const mi_fr *values, size_t n, mi_g1_affine *out) {
     if (!out) return MI_EINVAL;
-    MI_TRY(pedersen_enqueue(ctx, bases_dev, key_n, values, n));
+    MI_TRY(pedersen_enqueue(ctx, sigma ? pk->basis_exp_sigma : pk->basis, sigma ? pk->pre_sigma : pk->pre_basis, pk->c_tab, pk->n, values, n));
     return pedersen_collect(ctx, out);
 }
 int32_t mi_pedersen_pok_enqueue(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n) {
     if (!pk) return MI_EINVAL;
-    return pedersen_enqueue(ctx, pk->basis_exp_sigma, pk->n, values, n);
+    return pedersen_enqueue(ctx, pk->basis_exp_sigma, pk->pre_sigma, pk->c_tab, pk->n, values, n);
 }
 int32_t mi_pedersen_pok_collect(mi_ctx *ctx, mi_g1_affine *pok) { return pedersen_collect(ctx, pok); }
 
@@ -237,6 +265,7 @@ int32_t mi_pedersen_pk_load(mi_ctx *ctx, const mi_g1_affine *basis, const mi_g1_
     if (rc == MI_OK) rc = upload(ctx, &pk->basis_exp_sigma, basis_exp_sigma, n * 64);
     if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pedersen key upload failed"; rc = MI_EHIP; }
     if (rc != MI_OK) { mi_pedersen_pk_free(ctx, pk); return rc; }
+    pedersen_build_tables(ctx, pk);
     *out = pk;
     return MI_OK;
 }
@@ -245,24 +274,24 @@ int32_t mi_pedersen_pk_adopt(mi_ctx *ctx, void *basis_dev, void *basis_exp_sigma
     mi_pedersen_pk *pk = new (std::nothrow) mi_pedersen_pk();
     if (!pk) return MI_ENOMEM;
     pk->basis = basis_dev; pk->basis_exp_sigma = basis_exp_sigma_dev; pk->n = n;
+    pedersen_build_tables(ctx, pk);
     *out = pk;
     return MI_OK;
 }
 int32_t mi_pedersen_pk_free(mi_ctx *ctx, mi_pedersen_pk *pk) {
     if (!ctx || !pk) return MI_EINVAL;
     (void)hipStreamSynchronize(ctx->stream);
-    if (pk->basis) (void)hipFree(pk->basis);
-    if (pk->basis_exp_sigma) (void)hipFree(pk->basis_exp_sigma);
+    for (void *q : {pk->basis, pk->basis_exp_sigma, pk->pre_basis, pk->pre_sigma}) if (q) (void)hipFree(q);
     delete pk;
     return MI_OK;
 }
 int32_t mi_pedersen_commit(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n, mi_g1_affine *commitment) {
     if (!pk) return MI_EINVAL;
-    return pedersen_msm(ctx, pk->basis, pk->n, values, n, commitment);
+    return pedersen_msm(ctx, pk, false, values, n, commitment);
 }
 int32_t mi_pedersen_prove_knowledge(mi_ctx *ctx, mi_pedersen_pk *pk, const mi_fr *values, size_t n, mi_g1_affine *pok) {
     if (!pk) return MI_EINVAL;
-    return pedersen_msm(ctx, pk->basis_exp_sigma, pk->n, values, n, pok);
+    return pedersen_msm(ctx, pk, true, values, n, pok);
 }
 // sum_i challenge^i * points[i] on the host (a handful of points: one per commitment)
 int32_t mi_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *challenge, mi_g1_affine *out) {
@@ -273,10 +302,11 @@ int32_t mi_pedersen_fold(const mi_g1_affine *points, size_t n, const mi_fr *chal
     for (size_t i = 0; i < n; i++) {
         G1Aff p;
         std::memcpy(&p, &points[i], sizeof(p));
-        G1X t = host_scalar_mul<Fp>(p, fe_from_mont(pw));
+        G1X t = i ? host_scalar_mul<Fp>(p, fe_from_mont(pw)) : G1X::from_affine(p);   // challenge^0 = 1: no 256-bit ladder for the first (usually only) point
         xyzz_add(acc, t);
         pw = pw * ch;
     }
+    if (n == 1) { std::memcpy(out, &points[0], sizeof(*out)); return MI_OK; }   // one commitment: the fold is the point itself, bit for bit
     G1Aff a = xyzz_to_affine(acc);
     std::memcpy(out, &a, sizeof(a));
     return MI_OK;

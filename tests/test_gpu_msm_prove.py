@@ -574,3 +574,16 @@ def test_trim_gives_the_workspaces_back_and_the_next_proof_is_the_same(ctx):
     assert B.proof_write(pool.wait(pool.submit(pkh, W, a, b, c, r, s))[0]["raw"]) == want
     pool.close()
     ctx.pk_free(pkh)
+
+
+@pytest.mark.parametrize("n,dist", [(1 << 15, 1), (70001, 0), (200000, 1)])
+def test_pedersen_full_length_commitments_use_the_window_tables_and_match_oracle(ctx, n, dist):
+    """a Pedersen key of >= 2^15 points carries fixed-base window tables of Basis and BasisExpSigma; the full-length call (gnark's: as
+    many values as basis elements) goes through them, a shorter one through the plain bases: both equal the oracle"""
+    basis = cref.gen_g1(n, 510 + n); bes = cref.gen_g1(n, 610 + n); vals = cref.gen_scalars(n, 710 + n, dist)
+    vals[0] = 0; vals[1] = fr_arr([1])[0]; vals[2] = fr_arr([P.R_MOD - 1])[0]; basis[5] = 0; bes[7] = bes[6]; vals[7] = vals[6]
+    pk = ctx.pedersen_pk_load(basis, bes)
+    assert np.array_equal(ctx.pedersen_commit(pk, vals), cref.pedersen_msm(basis, vals))
+    assert np.array_equal(ctx.pedersen_commit(pk, vals, knowledge=True), cref.pedersen_msm(bes, vals))
+    assert np.array_equal(ctx.pedersen_commit(pk, vals[:n - 3]), cref.pedersen_msm(basis[:n - 3], vals[:n - 3]))
+    ctx.pedersen_pk_free(pk)

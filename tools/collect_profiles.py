@@ -1,38 +1,66 @@
-"""Turns the raw outputs of the round's final measurement run (gpurun_out/r3_*) into the committed summaries under profiles/.
-usage: python tools/collect_profiles.py"""
+"""Turns the raw outputs of the round's final measurement run (gpurun_out/r4_*, tools/final_measure.sh) into the committed summaries under
+profiles/.  usage: python tools/collect_profiles.py"""
+import glob
+import hashlib
 import json
+import os
 import sqlite3
 import subprocess
 import sys
 from collections import defaultdict
 
 G = "gpurun_out/"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def line(path):
     return [x for x in open(path) if x.startswith("{")][-1]
 
 
-for src, dst in ((G + "r3_bench_final.log", "profiles/r03_bench_line_final.json"), (G + "r3_prof_def.log", "profiles/r03_bench_line_profiled_default.json"),
-                 (G + "r3_prof_if1.log", "profiles/r03_bench_line_profiled_inflight1.json"), (G + "r3_bench26_final.log", "profiles/r03_bench_line_N2p26.json")):
+def db(d):
+    return glob.glob(G + d + "/**/*_results.db", recursive=True)[0]
+
+
+def sha16(path):
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+for src, dst in ((G + "r4_bench_final.log", "profiles/r04_bench_line_final.json"), (G + "r4_prof_def.log", "profiles/r04_bench_line_profiled_default.json"),
+                 (G + "r4_prof_if1.log", "profiles/r04_bench_line_profiled_inflight1.json"), (G + "r4_bench26_final.log", "profiles/r04_bench_line_N2p26.json"),
+                 (G + "r4_rehearse2.log", "profiles/r04_bench_line_rehearsal_2ranks_one_gpu.json")):
+    if not os.path.exists(src):
+        print("missing", src); continue
     l = line(src); open(dst, "w").write(l); d = json.loads(l)
-    print(dst, {k: round(d[k], 3) if isinstance(d[k], float) else d[k] for k in ("value", "ms_per_step", "single_proof_latency_ms", "value_host_inputs", "hbm_in_use_gb")},
+    print(dst, {k: round(d[k], 3) if isinstance(d.get(k), float) else d.get(k) for k in ("value", "ms_per_step", "value_hbm_resident_inputs", "single_proof_latency_ms", "single_proof_latency_host_inputs_ms", "hbm_in_use_gb")},
           "launch_ms", round(d["roofline"]["launch_ms"], 2), "frac", round(d["roofline"]["frac"], 4), "ntt frac", round(d["roofline_ntt"]["frac"], 4))
-subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "stats", G + "r3_prof_def/d_results.db", "profiles/r03_kernel_stats_default.csv"], stdout=subprocess.DEVNULL)
-subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "stats", G + "r3_prof_if1/i_results.db", "profiles/r03_kernel_stats_inflight1.csv"], stdout=subprocess.DEVNULL)
-out = {}
-for name, db in (("FETCH_SIZE", G + "r3_pmc_fetch/f_results.db"), ("WRITE_SIZE", G + "r3_pmc_write/w_results.db")):
-    c = sqlite3.connect(db)
-    agg = defaultdict(lambda: [set(), 0.0])
-    for k, did, v in c.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=?", (name,)):
-        k = k.split("(")[0]; agg[k][0].add(did); agg[k][1] += v
-    out[name] = {k: {"launches": len(v[0]), "kb_total": v[1], "kb_per_launch": v[1] / len(v[0])} for k, v in agg.items()}
-out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline "
-                "--no-host-inputs --sharded-msm-log-n 0 --sharded-prove-log-n 0`, N=2^23, final round-3 code; KB as rocprofv3 reports them, summed over the counter's dimensions; FETCH_SIZE raw "
-                "(k_bench_gather: 33.5 M random 64-B gathers read 2.10 GB raw, so 64-B gathers need no correction; 16-B-per-lane streams need x2)")
-json.dump(out, open("profiles/r03_pmc_bench_traffic.json", "w"), indent=1)
-for k in ("k_msm_accum_affine29", "k_ntt_pass_wave", "k_bench_gather"):
-    print(k, "fetch MB/launch", round(out["FETCH_SIZE"][k]["kb_per_launch"] / 1e3, 1), "write", round(out["WRITE_SIZE"].get(k, {"kb_per_launch": 0})["kb_per_launch"] / 1e3, 1))
-c = sqlite3.connect(G + "r3_prof_if1/i_results.db")
-for n, k, a in c.execute("select name, count(*), avg(end-start) from kernels where name like 'k_msm_accum_affine29%' or name like 'k_ntt_pass_wave%' group by name"):
-    print("in-flight 1 rocprof average:", n[:30], k, round(a / 1e6, 3), "ms")
+for d_, out in (("r4_prof_def", "profiles/r04_kernel_stats_default.csv"), ("r4_prof_if1", "profiles/r04_kernel_stats_inflight1.csv")):
+    if os.path.isdir(G + d_):
+        subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "stats", db(d_), out], stdout=subprocess.DEVNULL)
+if os.path.isdir(G + "r4_pmc_fetch") and os.path.isdir(G + "r4_pmc_write"):
+    out = {}
+    for name, d_ in (("FETCH_SIZE", "r4_pmc_fetch"), ("WRITE_SIZE", "r4_pmc_write")):
+        c = sqlite3.connect(db(d_))
+        agg = defaultdict(lambda: [set(), 0.0])
+        for k, did, v in c.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=?", (name,)):
+            k = k.split("(")[0]; agg[k][0].add(did); agg[k][1] += v
+        out[name] = {k: {"launches": len(v[0]), "kb_total": v[1], "kb_per_launch": v[1] / len(v[0])} for k, v in agg.items()}
+    csrc = os.path.join(ROOT, "gnark-whir_amd", "csrc")
+    out["_sources"] = {f: sha16(os.path.join(csrc, f)) for f in ("msm.hip", "msm_g1.hip", "msm_core.cuh", "msm2_core.cuh", "curve29.cuh", "field29.cuh", "ntt.hip", "ntt_tile.cuh", "ntt_wave.cuh", "field.cuh")}
+    out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-resident "
+                    "--sharded-msm-log-n 0 --sharded-prove-log-n 0`, N=2^23, final round-4 code (_sources: sha256[:16] of the kernel sources the passes ran on; bench.py withholds "
+                    "`traffic` when they differ); KB as rocprofv3 reports them, summed over the counter's dimensions; FETCH_SIZE raw (64-B gathers need no correction; 16-B-per-lane streams need x2)")
+    json.dump(out, open("profiles/r04_pmc_bench_traffic.json", "w"), indent=1)
+    for k in ("k_msm_accum_affine29", "k_ntt_pass_wave", "k_msm2_count", "k_msm2_scatter2"):
+        print(k, "fetch MB/launch", round(out["FETCH_SIZE"][k]["kb_per_launch"] / 1e3, 1), "write", round(out["WRITE_SIZE"].get(k, {"kb_per_launch": 0})["kb_per_launch"] / 1e3, 1))
+if os.path.isdir(G + "r4_pmc_valu"):
+    subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "pmc", db("r4_pmc_valu"), "profiles/r04_pmc_valu_proofs.csv"], stdout=subprocess.DEVNULL)
+rows = []
+for nc in (0, 65536, 262144, 1048576):
+    p = G + f"r4_nc_{nc}.log"
+    if os.path.exists(p):
+        d = json.loads(line(p))
+        rows.append(f"n_committed {nc:8d}: value {d['value']:.2f} proofs/s ({d['proof_bytes']} B), HBM-resident {d['value_hbm_resident_inputs']:.2f}, "
+                    f"single proof from host {d['single_proof_latency_host_inputs_ms']:.2f} ms, Commit alone {d['pedersen_commit_latency_ms'] or 0:.2f} ms")
+if rows:
+    open("profiles/r04_n_committed.txt", "w").write("bench.py --no-cpu-baseline --sharded-msm-log-n 0 --sharded-prove-log-n 0 --n-committed X   (N = 2^23, one box, same run set)\n" + "\n".join(rows) + "\n")
+    print("\n".join(rows))

@@ -45,4 +45,27 @@ def full():
     pool.commit(ped, values)
     return pool.wait(pool.submit_bsb22(pkh, Wh, ah, bh, None, rs[0], rs[1], [(ped, values)], rs[2]))[1]
 show("commit + host W a b, pool bsb22", full)
-os.environ["X"] = "1"
+# ---- throughput: where do the commitment's 3.5 % go?  20 steps from 4 caller threads, variants
+from concurrent.futures import ThreadPoolExecutor
+ex = ThreadPoolExecutor(4)
+def tput(name, step, reps=3):
+    best = 0
+    for _ in range(reps):
+        list(ex.map(lambda _: step(), range(4)))
+        ctx.sync(); t0 = time.perf_counter()
+        list(ex.map(lambda _: step(), range(24)))
+        ctx.sync(); best = max(best, 24 / (time.perf_counter() - t0))
+    print(f"throughput {name:52s} {best:6.2f} proofs/s", flush=True)
+plain = lambda: pool.wait(pool.submit(pkh, Wh, ah, bh, None, rs[0], rs[1]))
+bsb = lambda: pool.wait(pool.submit_bsb22(pkh, Wh, ah, bh, None, rs[0], rs[1], [(ped, values)], rs[2]))
+def commit_plain():
+    pool.commit(ped, values); return plain()
+def commit_bsb():
+    pool.commit(ped, values); return bsb()
+dev = lambda: pool.wait(pool.submit(pkh, W.ptr, a.ptr, b.ptr, c.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints))
+for _ in range(2):
+    tput("device inputs, plain", dev)
+    tput("host inputs, plain submit", plain)
+    tput("host inputs, submit_bsb22 (PoK in the job)", bsb)
+    tput("host inputs, Commit + plain submit", commit_plain)
+    tput("host inputs, Commit + submit_bsb22 (the bench step)", commit_bsb)
