@@ -38,6 +38,7 @@ struct NttState {
     u32 wave_stages = 1;   // passes of radix >= 2^7 run their last / first seven stages in registers (k_ntt_pass_wave); 0 = all through LDS
     u32 fuse_pair = 1;     // computeH: inverse last pass + coset first pass of a and b as one launch (k_ntt_contig_pair)
     u32 fuse_triple = 1;   // computeH: coset last pass of a and of b + the product a b + the last transform's first pass as one launch (k_ntt_strided_triple)
+    u32 fuse_last = 1;     // computeH: the last pass of den FFTInverse(c) + the last transform's last pass (which subtracts it) as one launch (k_ntt_contig_last_sub)
 };
 // Tile / radix knobs for a transform of 2^log_n: the caller's (mi_debug_set_ntt_plan) or, untouched, the measured best per size
 // (tools/ntt_probe.py sweep, profiles/r02_tune_ntt_sweep.json): 2^9 tiles and radices 2^7 2^7 2^9 up to 2^23; 2^10 tiles and
@@ -54,6 +55,7 @@ __global__ void k_ntt_pass_wave(Fr *dst, const Fr *src, NttPass p, NttTables t);
 __global__ void k_ntt_contig_pair(Fr *data, NttPass pi, NttTables ti, NttPass pf, NttTables tf);
 __global__ void k_ntt_strided_triple(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl);
 __global__ void k_ntt_strided_triple8(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl);
+__global__ void k_ntt_contig_last_sub(Fr *A, const Fr *Cin, NttPass pa, NttTables ta, NttPass pc, NttTables tc);
 void mi_ntt_state_init(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= sizeof(ctx->ntt_state), "NttState lives in ctx->ntt_state");
     new (ctx->ntt_state) NttState();
@@ -63,6 +65,7 @@ void mi_ntt_state_init(mi_ctx *ctx) {
     (void)hipFuncSetAttribute((const void *)k_ntt_contig_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
@@ -296,6 +299,60 @@ __global__ void __launch_bounds__(256) k_ntt_strided_triple8(Fr *a, const Fr *b,
     ntt_tile_store(pl, tl, a, tile, threadIdx.x, blockDim.x, lds);
 }
 
+// computeH's LAST seam: the last (contiguous, DIF) pass of den FFTInverse(c) and the last pass of the last transform work on the same
+// contiguous tiles, and the second subtracts the first's output element by element.  One launch: c's tile goes through its stages and its
+// den / N scaling and stays in REGISTERS (a thread keeps the elements it would have stored), the main tile follows through the same LDS,
+// and the store subtracts, canonicalises and writes h.  c's last store and the store_sub read (0.54 GB at N = 2^23) and one launch go.
+// pa / ta: the last transform's last pass as ntt_run would have launched it (store_sub unset), pc / tc: c's.  Equal tile shapes, radix >= 2^7,
+// at most four elements per thread.
+__device__ __forceinline__ void ntt_wave_pass_to_lds(const NttPass &p, const NttTables &t, const Fr *src, u64 tile, U4 *lds) {
+    const u32 PL = ntt_plane_slots(p);
+    ntt_tile_load(p, t, src, tile, threadIdx.x, blockDim.x, lds);
+    __syncthreads();
+    for (u32 s = 0; s + 7 < p.log_r; s++) {   // DIF distances R/2 ... 128
+        ntt_tile_stage(p, t, s, threadIdx.x, blockDim.x, lds);
+        __syncthreads();
+    }
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const u32 nsub = 1u << (p.log_r + p.log_c - 7);
+    for (u32 sb = wave; sb < nsub; sb += nwaves) {
+        const u32 col = sb & ((1u << p.log_c) - 1), base = (sb >> p.log_c) << 7;
+        Fr x0 = lds_get(lds, PL, ntt_lds_slot(p, base + lane, col)), x1 = lds_get(lds, PL, ntt_lds_slot(p, base + lane + 64, col));
+        wave_ntt128(x0, x1, lane, false, t.small);
+        lds_put(lds, PL, ntt_lds_slot(p, base + 2 * lane, col), x0);
+        lds_put(lds, PL, ntt_lds_slot(p, base + 2 * lane + 1, col), x1);
+    }
+    __syncthreads();
+}
+__global__ void __launch_bounds__(256) k_ntt_contig_last_sub(Fr *A, const Fr *Cin, NttPass pa, NttTables ta, NttPass pc, NttTables tc) {
+    extern __shared__ U4 lds[];
+    const u64 tile = blockIdx.x;
+    const u32 E = 1u << (pa.log_r + pa.log_c), PL = ntt_plane_slots(pa);
+    Fr keep[4];
+    ntt_wave_pass_to_lds(pc, tc, Cin, tile, lds);
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {   // (constant trip count: keep[] stays in registers)
+        const u32 e = threadIdx.x + k * blockDim.x;
+        if (e >= E) break;
+        const u32 rho = e & ((1u << pc.log_r) - 1), col = e >> pc.log_r;   // contiguous pass: the order that is contiguous in global memory
+        Fr v = lds_get(lds, PL, ntt_lds_slot(pc, rho, col)), f;
+        if (ntt_edge_factor(pc, tc, rho, ntt_global_index(pc, tile, rho, col), 1, f)) v = fe_mul_lazy(v, f);
+        keep[k] = v;
+    }
+    __syncthreads();   // every thread has read c's tile
+    ntt_wave_pass_to_lds(pa, ta, A, tile, lds);
+#pragma unroll
+    for (u32 k = 0; k < 4; k++) {
+        const u32 e = threadIdx.x + k * blockDim.x;
+        if (e >= E) break;
+        const u32 rho = e & ((1u << pa.log_r) - 1), col = e >> pa.log_r;
+        const u64 g = ntt_global_index(pa, tile, rho, col);
+        Fr v = lds_get(lds, PL, ntt_lds_slot(pa, rho, col)), f;
+        if (ntt_edge_factor(pa, ta, rho, g, 1, f)) v = fe_mul_lazy(v, f);
+        A[g] = fe_canon(fe_sub_plus2p(fe_condsub_2p(v), fe_condsub_2p(keep[k])));
+    }
+}
+
 // direct factor tables (NttPass::tw_direct / sc_direct), one thread per entry, square-and-multiply
 __global__ void k_tw_layout(Fr *out, u32 log_n, u32 log_r, Fr w) {   // the M = N pass: element g = (rho << log_s) | lo
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -506,7 +563,8 @@ int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t 
 //   part 3                               the strided triple (or the coset FFTs' last passes) and the last transform -> h_out
 // The same launches as the one-call form, in an order that differs only between independent vectors: identical h.
 struct ComputeHPlan {
-    bool pair, triple;
+    bool pair, triple, last;   // last: c's last pass and the last transform's last pass run fused (decided from the plan alone: both are the
+                               // contiguous pass of a plain DIF transform, equal shapes by construction)
     NttPass pc, plast;
     NttTables tc, tlast;
 };
@@ -521,6 +579,11 @@ static int32_t compute_h_plan(mi_ctx *ctx, uint32_t log_n, Fr *A, ComputeHPlan &
     // The coset FFT's LAST pass (of a and of b), the product and the last transform's FIRST pass share their strided tiles: one
     // launch (k_ntt_strided_triple / k_ntt_strided_triple8) when that pass has radix 2^7 or 2^8 and the tile shape fits
     cp.triple = st->fuse_triple && st->wave_stages && pl.n_pass >= 2 && (pl.log_r[0] == 7 || pl.log_r[0] == 8);
+    {
+        const u32 lr = pl.log_r[pl.n_pass - 1];
+        const u32 room = kn.log_e > lr ? kn.log_e - lr : 0, avail = log_n - lr, lc = room < avail ? room : avail;
+        cp.last = st->fuse_last && st->wave_stages && pl.n_pass >= 2 && lr >= 7 && (1u << (lr + lc)) <= 4 * 256;
+    }
     cp.pc = NttPass{}; cp.plast = NttPass{}; cp.tc = NttTables{}; cp.tlast = NttTables{};
     if (cp.triple) {   // capture the two passes without launching anything, and check the tile shape before committing to the fused form
         MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, 2 | 4, &cp.pc, &cp.tc));
@@ -565,11 +628,33 @@ int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *sr
         NttTables tx{};
         return ntt_run(ctx, v, v, (u32)n, log_n, MI_NTT_DIT | MI_NTT_COSET, 2, nullptr, nullptr, first_skip | (cp.triple ? 2u : 0u), &px, &tx);
     }
-    if (part == 2)   // c <- den FFTInverse(c, DIF) (one constant den / N on the way out), bit-reversed like h
-        return ntt_run(ctx, C, (const Fr *)src, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4, (const Fr *)src2);
+    if (part == 2) {   // c <- den FFTInverse(c, DIF) (one constant den / N on the way out), bit-reversed like h; its last pass waits for part 3 when fused
+        NttPass px{};
+        NttTables tx{};
+        return ntt_run(ctx, C, (const Fr *)src, (u32)n_constraints, log_n, MI_NTT_INVERSE, 4, (const Fr *)src2, nullptr, cp.last ? 2u : 0u, &px, &tx);
+    }
     // 3. h <- den FFTInverse(a b, DIF, OnCoset) - c, left bit-reversed like gnark: the product a b is taken on the way into the
     //    first pass, the subtraction on the way out of the last (no pointwise kernel, no extra round trip through HBM)
-    if (!cp.triple) return ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C);
+    // the last launch when fused: both last passes captured (nothing launched), one kernel does them and the subtraction
+    auto last_fused = [&]() -> int32_t {
+        NttPass pa{}, pcl{};
+        NttTables ta{}, tcl{};
+        MI_TRY(ntt_run(ctx, C, C, (u32)n, log_n, MI_NTT_INVERSE, 4, nullptr, nullptr, 2 | 4, &pcl, &tcl));
+        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, nullptr, 2 | 4, &pa, &ta));
+        if (pa.log_r != pcl.log_r || pa.log_c != pcl.log_c || pa.log_s || pcl.log_s || pa.dit || pcl.dit || pa.lds_pad != pcl.lds_pad)
+            MI_FAIL(ctx, MI_EINVAL, "internal: the two last passes of computeH do not match");
+        hipLaunchKernelGGL(k_ntt_contig_last_sub, dim3(1u << (log_n - pa.log_r - pa.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pa), ctx->stream, A, (const Fr *)C, pa, ta, pcl, tcl);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+        ctx->stats.ntt_launches++;
+        return MI_OK;
+    };
+    if (!cp.triple) {
+        if (!cp.last) return ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, C);
+        NttPass px{};
+        NttTables tx{};
+        MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, B, nullptr, 2, &px, &tx));
+        return last_fused();
+    }
     // radix 2^7: one wave per 128-row sub-block of the tile, 64 * 2^log_c threads (256 at the default 2^9-element tiles); radix 2^8: 256 threads
     const NttPass &pc = cp.pc;
     if (pc.log_r == 7)
@@ -580,7 +665,11 @@ int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *sr
                            A, (const Fr *)B, pc, cp.tc, cp.plast, cp.tlast);
     MI_CHECK_HIP(ctx, hipGetLastError());
     ctx->stats.ntt_launches++;
-    return ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, C, 1);
+    if (!cp.last) return ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, C, 1);
+    NttPass px{};
+    NttTables tx{};
+    MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, nullptr, 1 | 2, &px, &tx));
+    return last_fused();
 }
 int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,
                               size_t n_constraints, mi_fr *h_out) {
@@ -609,9 +698,10 @@ int32_t mi_debug_set_ntt_wave_stages(mi_ctx *ctx, uint32_t on, uint32_t direct_m
     return MI_OK;
 }
 int32_t mi_debug_set_ntt_fuse_pair(mi_ctx *ctx, uint32_t on) {
-    if (!ctx || on > 3) return MI_EINVAL;
+    if (!ctx || on > 7) return MI_EINVAL;
     state_of(ctx)->fuse_pair = on & 1u;          // bit 0: the contiguous pair (k_ntt_contig_pair)
     state_of(ctx)->fuse_triple = (on >> 1) & 1u;  // bit 1: the strided triple (k_ntt_strided_triple)
+    state_of(ctx)->fuse_last = (on >> 2) & 1u;    // bit 2: c's last pass + the last transform's last pass (k_ntt_contig_last_sub)
     return MI_OK;
 }
 int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads) {

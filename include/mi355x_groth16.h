@@ -464,10 +464,11 @@ int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads);
 /* on = 1 (default): passes of radix >= 2^7 run seven of their stages in registers (wavefront butterflies); 0: every stage through
  * LDS.  direct_min_log_n: computeH builds its data-layout twiddle / coset tables from this size on (default 12; 29 = never). */
 int32_t mi_debug_set_ntt_wave_stages(mi_ctx *ctx, uint32_t on, uint32_t direct_min_log_n);
-/* Fused launches of computeH, a bit mask (default 3 = both).  Bit 0: the contiguous last pass of FFTInverse(a | b) and the contiguous
+/* Fused launches of computeH, a bit mask (default 7 = all).  Bit 0: the contiguous last pass of FFTInverse(a | b) and the contiguous
  * first pass of the coset FFT that follows run as one launch on the same tiles (csrc/ntt.hip k_ntt_contig_pair).  Bit 1: the strided
  * last pass of the coset FFT of a and of b, the product a b and the strided first pass of the last transform run as one launch
- * (k_ntt_strided_triple; plans whose first radix is 2^7).  Same h whatever the mask; parity tests run all four. */
+ * (k_ntt_strided_triple; plans whose first radix is 2^7 or 2^8).  Bit 2: the last pass of den FFTInverse(c) and the last pass of the last
+ * transform, which subtracts it, run as one launch (k_ntt_contig_last_sub).  Same h whatever the mask; parity tests run the combinations. */
 int32_t mi_debug_set_ntt_fuse_pair(mi_ctx *ctx, uint32_t on);
 int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G);
 int32_t mi_debug_set_msm_chunk(mi_ctx *ctx, uint32_t chunk);   /* fixed-base sort: entries per pass-2 chunk */

@@ -207,10 +207,12 @@ def test_compute_h_with_and_without_the_fused_launches(ctx, log_n, plan):
     try:
         if plan:
             assert ctx.lib.mi_debug_set_ntt_plan(ctx.h, *plan) == 0
-        for on in (3, 0, 1, 2, 3):
+        for on in (7, 0, 1, 2, 3, 4, 5, 6, 7):   # bit 2 (r4): c's last pass + the last transform's last pass, which subtracts it, as one launch
             assert ctx.lib.mi_debug_set_ntt_fuse_pair(ctx.h, on) == 0
             assert np.array_equal(ctx.compute_h(log_n, a, b, c), want), (on, log_n)
+            if on in (7, 4):   # c = NULL: formed on the device as a o b, against the oracle given that c
+                assert np.array_equal(ctx.compute_h(log_n, a, b, None), cref.compute_h(log_n, a, b, cref.field_op(0, 2, a, b))), (on, log_n, "derived c")
     finally:
-        assert ctx.lib.mi_debug_set_ntt_fuse_pair(ctx.h, 3) == 0
+        assert ctx.lib.mi_debug_set_ntt_fuse_pair(ctx.h, 7) == 0
         if plan:
             assert ctx.lib.mi_debug_set_ntt_plan(ctx.h, 9, 9, 7) == 0
