@@ -708,8 +708,9 @@ def main():
                     per = lambda kn: (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0
                     n_pair = 2 if "k_ntt_contig_pair" in pmc["FETCH_SIZE"] else 0
                     n_triple = 1 if "k_ntt_strided_triple" in pmc["FETCH_SIZE"] else 0
-                    traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair - n_triple) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0) +
-                                   (per("k_ntt_strided_triple") if n_triple else 0.0)) / 6.0
+                    n_last = 1 if "k_ntt_contig_last_sub" in pmc["FETCH_SIZE"] else 0
+                    traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair - n_triple - n_last) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0) +
+                                   (per("k_ntt_strided_triple") if n_triple else 0.0) + (per("k_ntt_contig_last_sub") if n_last else 0.0)) / 6.0
                 else:
                     pmc_src += "; STALE for the NTT kernels: traffic withheld"
             except Exception:
@@ -766,7 +767,7 @@ def main():
                          "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
             # time = computeH alone on the GPU / its 6 transforms (gnark's 7th, the coset FFT of c, is never needed: DESIGN.md 4)
-            "roofline_ntt": {"kernel": "k_ntt_pass_wave + k_ntt_contig_pair + k_ntt_strided_triple (all passes of one size-N transform)", "bound": "hbm",
+            "roofline_ntt": {"kernel": "k_ntt_pass_wave + k_ntt_contig_pair + k_ntt_strided_triple + k_ntt_contig_last_sub (all passes of one size-N transform)", "bound": "hbm",
                              "achieved": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9 / 8000.0, "traffic": traffic_ntt,
                              "traffic_source": pmc_src + ": (2 x FETCH_SIZE + WRITE_SIZE) per pass launch x pass launches per transform",

@@ -14,8 +14,9 @@ case "$1" in
     timeout -k 10 400 rocprofv3 --kernel-trace -d $O/r4_prof_def -o d -- python3 bench.py $Q --no-hbm-resident > $O/r4_prof_def.log 2>&1; tail -c 200 $O/r4_prof_def.log ;;
 2)  rm -rf $O/r4_prof_if1 $O/r4_pmc_fetch $O/r4_pmc_write
     timeout -k 10 300 rocprofv3 --kernel-trace -d $O/r4_prof_if1 -o i -- python3 bench.py --in-flight 1 --steps 10 $Q --no-hbm-resident > $O/r4_prof_if1.log 2>&1
-    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/r4_pmc_fetch -o f -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 $Q --no-hbm-resident > $O/r4_pmc_fetch.log 2>&1
-    timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/r4_pmc_write -o w -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 $Q --no-hbm-resident > $O/r4_pmc_write.log 2>&1
+    # (--n-committed 0: the per-launch averages of k_msm_accum_affine29 must be those of the proof's four MSMs, not mixed with the two small Pedersen launches)
+    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/r4_pmc_fetch -o f -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 $Q --no-hbm-resident --n-committed 0 > $O/r4_pmc_fetch.log 2>&1
+    timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/r4_pmc_write -o w -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 $Q --no-hbm-resident --n-committed 0 > $O/r4_pmc_write.log 2>&1
     tail -c 200 $O/r4_pmc_write.log ;;
 3)  rm -rf $O/r4_pmc_valu
     timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU -d $O/r4_pmc_valu -o v -- python3 tools/prof_proof.py 23 4 > $O/r4_pmc_valu.log 2>&1; tail -1 $O/r4_pmc_valu.log | cut -c1-200 ;;
