@@ -241,8 +241,7 @@ static int32_t run_xfers_shm(mi_group *g, const std::vector<Xfer> &list, const s
     G_HIP(g, hipStreamSynchronize(xs[0]));   // what this rank sends is complete; what it receives into is no longer read
     struct St { size_t sent = 0, rcvd = 0; };
     std::vector<St> st(list.size());
-    // per pair: index of the first transfer of the list that is not finished on this side
-    const Deadline dl(L.timeout_ms);
+    Deadline dl(L.timeout_ms);   // the time this rank may WAIT for its peers without any chunk moving (renewed by every chunk)
     unsigned spins = 0;
     for (;;) {
         bool all_done = true, progress = false;
@@ -285,7 +284,7 @@ static int32_t run_xfers_shm(mi_group *g, const std::vector<Xfer> &list, const s
             }
         }
         if (all_done) return MI_OK;
-        if (progress) { spins = 0; continue; }
+        if (progress) { spins = 0; dl = Deadline(L.timeout_ms); continue; }
         if (L.h->poisoned.load(std::memory_order_acquire)) { g->broken = true; G_FAIL(g, MI_EHIP, "group: another rank reported a transport failure"); }
         if (dl.passed()) return shm_fail(g, "group: a peer did not take part in the exchange (timeout; did its process end?)");
         shm_pause(spins);
