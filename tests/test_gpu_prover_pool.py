@@ -243,3 +243,48 @@ def test_host_job_that_fails_before_its_gate_waits_for_its_uploads():
     assert B.proof_write(pool.wait(pool.submit(pkh, W, a, b, c, r, s))[0]["raw"]) == cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
     c0.pk_free(pkh)
     pool.close()
+
+
+@pytest.mark.parametrize("n_commitments,n_values", [(1, 3000), (2, 40000), (1, 1 << 15)])
+def test_bsb22_through_the_pool_matches_oracle(n_commitments, n_values):
+    """the proof the WHIR circuit really produces, through the pool (mi_prover_commit inside the "solve", mi_prover_submit_bsb22 after it):
+    commitments, the folded proof of knowledge and Proof.WriteTo's 164 + 32 n bytes equal the oracle's; several jobs in flight; c = NULL"""
+    B = load_binding()
+    log_n = 13
+    n = 1 << log_n
+    nb_wires, nb_public, n_constraints = n - 13, 41, n - 5
+    pk = synthetic_pk(log_n, nb_wires, nb_public, 5100 + n_commitments, n_committed=50)
+    W = cref.gen_scalars(nb_wires, 11, 1)
+    a = cref.gen_scalars(n_constraints, 21, 1); b = cref.gen_scalars(n_constraints, 31, 0); c = cref.field_op(0, 2, a, b)
+    keys = [(cref.gen_g1(n_values, 800 + i), cref.gen_g1(n_values, 900 + i)) for i in range(n_commitments)]
+    vals = [cref.gen_scalars(n_values, 1000 + i, 1) for i in range(n_commitments)]
+    challenge = cref.gen_scalars(1, 77, 0)[0]
+    pool = B.Prover(0, 2)
+    c0 = pool.ctx(0)
+    pkh = c0.pk_load(pk)
+    peds = [c0.pedersen_pk_load(bs, sg) for bs, sg in keys]
+    want_cm = np.stack([cref.pedersen_msm(bs, v) for (bs, _), v in zip(keys, vals)])
+    want_pok = cref.pedersen_fold(np.stack([cref.pedersen_msm(sg, v) for (_, sg), v in zip(keys, vals)]), challenge)
+    jobs = []
+    for j in range(4):
+        r, s = cref.gen_scalars(2, 200 + j, 0)
+        cms = np.stack([pool.commit(p, v) for p, v in zip(peds, vals)])      # synchronous, as inside the solve
+        assert np.array_equal(cms, want_cm)
+        jobs.append((r, s, pool.submit_bsb22(pkh, W, a, b, None if j % 2 else c, r, s, list(zip(peds, vals)), challenge)))
+    for r, s, t in reversed(jobs):
+        proof, _ = pool.wait(t)
+        assert np.array_equal(proof["pok"], want_pok)
+        want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"], want_cm, want_pok)
+        assert len(want) == 164 + 32 * n_commitments
+        assert B.proof_write(proof["raw"], want_cm, proof["pok"]) == want
+    # a commitment with more values than its key has points: the job fails with the key's message, the pool goes on
+    t = pool.submit_bsb22(pkh, W, a, b, c, *cref.gen_scalars(2, 1, 0), [(peds[0], cref.gen_scalars(n_values + 1, 5, 0))], challenge)
+    with pytest.raises(B.MiError):
+        pool.wait(t)
+    r, s = cref.gen_scalars(2, 300, 0)
+    proof, _ = pool.wait(pool.submit_bsb22(pkh, W, a, b, c, r, s, list(zip(peds, vals)), challenge))
+    assert B.proof_write(proof["raw"], want_cm, proof["pok"]) == cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"], want_cm, want_pok)
+    for p in peds:
+        c0.pedersen_pk_free(p)
+    c0.pk_free(pkh)
+    pool.close()
