@@ -4,7 +4,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 rm -rf $O/r3_trace1
-timeout -k 10 300 rocprofv3 --kernel-trace -d $O/r3_trace1 -o t -- python3 bench.py --in-flight 1 --steps 4 --warmup 1 --no-cpu-baseline --no-host-inputs --sharded-msm-log-n 0 --sharded-prove-log-n 0 "$@" > $O/r3_trace1.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace -d $O/r3_trace1 -o t -- python3 bench.py --in-flight 1 --steps 4 --warmup 1 --no-cpu-baseline --sharded-msm-log-n 0 --sharded-prove-log-n 0 "$@" > $O/r3_trace1.log 2>&1
 DB=$(find $O/r3_trace1 -name '*_results.db' | head -1)
 python3 tools/rocpd_summary.py timeline $DB $O/r3_trace1_timeline.txt 400
 python3 tools/rocpd_summary.py stats $DB $O/r3_trace1_stats.csv > /dev/null
