@@ -7,7 +7,7 @@ for r in $(seq 1 ${2:-2}); do
     python - <<PY
 import json
 l = json.loads(open("gpurun_out/abl.log").read().strip().splitlines()[-1])
-print("r$r $v", "proofs/s %.2f" % l["value"], "host inputs %.2f" % l["value_host_inputs"], "ratio %.4f" % (l["value_host_inputs"] / l["value"]), "latency %.2f" % l["single_proof_latency_ms"], "upload", l.get("host_inputs_upload_ms"), flush=True)
+print("r$r $v", "proofs/s %.2f" % l["value"], "HBM-resident %.2f" % l["value_hbm_resident_inputs"], "ratio %.4f" % (l["value"] / l["value_hbm_resident_inputs"]), "latency %.2f" % l["single_proof_latency_ms"], "upload", l.get("host_inputs_upload_ms"), flush=True)
 PY
   done
 done
