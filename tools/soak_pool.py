@@ -1,5 +1,7 @@
-"""Soak: many proofs through the prover pool -- device-resident and HOST inputs mixed (the upload stage) -- every one compared
-with the proof a plain context computed alone.   usage: python tools/soak_pool.py [log_n] [jobs] [in_flight]"""
+"""Soak: many proofs through the prover pool -- device-resident inputs, HOST inputs (the upload stage; with c and with c = NULL) and host
+inputs with a BSB22 commitment (mi_prover_commit + mi_prover_submit_bsb22: the PoK MSM enqueued from a helper thread beside the proof)
+mixed -- every one compared with the proof a plain context computed alone, every commitment and PoK with the first one computed.
+usage: python tools/soak_pool.py [log_n] [jobs] [in_flight]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
@@ -35,21 +37,46 @@ ref = {}
 for w, k in combos:
     ref[(w, k)] = single.prove(pkh, *(x.ptr for x in wit[w]), rs[2 * (k % 4)], rs[2 * (k % 4) + 1], device=True, n_wires=nb_wires, n_constraints=n_constraints)[0]["raw"].copy()
 single.close()
+n_ped = max(1, N >> 5)
+basis = c0.gen_g1(n_ped, 500).download((n_ped, 8)); sigma = c0.gen_g1(n_ped, 501).download((n_ped, 8))
+ped = c0.pedersen_pk_load(basis, sigma)
+vals = [np.ascontiguousarray(hwit[w][0][:n_ped]) for w in range(2)]
+cm_ref = [pool.commit(ped, v) for v in vals]
+pok_ref = [None, None]
 t0 = time.perf_counter(); bad = 0; done = 0
 window = []
+
+
+def check(key, t, kind):
+    global bad, done
+    pr = pool.wait(t)[0]
+    ok = np.array_equal(pr["raw"], ref[key])
+    if kind == "bsb":
+        w = key[0]
+        if pok_ref[w] is None:
+            pok_ref[w] = pr["pok"].copy()
+        ok = ok and np.array_equal(pr["pok"], pok_ref[w])
+    bad += not ok; done += 1
+    if done % 100 == 0:
+        print(f"{done} proofs, {bad} mismatches, {done / (time.perf_counter() - t0):.1f} proofs/s", flush=True)
+
+
 for j in range(jobs):
     w, k = combos[j % len(combos)]
-    if j % 3 == 1:   # every third job hands over host pointers
-        window.append(((w, k), pool.submit(pkh, *hwit[w], rs[2 * k], rs[2 * k + 1])))
+    r, s = rs[2 * k], rs[2 * k + 1]
+    if j % 5 == 1:     # host pointers, c given
+        window.append(((w, k), pool.submit(pkh, *hwit[w], r, s), "host"))
+    elif j % 5 == 2:   # host pointers, c formed on the device
+        window.append(((w, k), pool.submit(pkh, hwit[w][0], hwit[w][1], hwit[w][2], None, r, s), "host"))
+    elif j % 5 == 3:   # the whole caller's step: Commit, then the proof with its PoK
+        bad += not np.array_equal(pool.commit(ped, vals[w]), cm_ref[w])
+        window.append(((w, k), pool.submit_bsb22(pkh, hwit[w][0], hwit[w][1], hwit[w][2], None, r, s, [(ped, vals[w])], rs[0]), "bsb"))
     else:
-        window.append(((w, k), pool.submit(pkh, *(x.ptr for x in wit[w]), rs[2 * k], rs[2 * k + 1], device=True, n_wires=nb_wires, n_constraints=n_constraints)))
+        window.append(((w, k), pool.submit(pkh, *(x.ptr for x in wit[w]), r, s, device=True, n_wires=nb_wires, n_constraints=n_constraints), "dev"))
     if len(window) >= 4 * depth:
-        key, t = window.pop(0)
-        bad += not np.array_equal(pool.wait(t)[0]["raw"], ref[key]); done += 1
-        if done % 100 == 0:
-            print(f"{done} proofs, {bad} mismatches, {done / (time.perf_counter() - t0):.1f} proofs/s", flush=True)
-for key, t in window:
-    bad += not np.array_equal(pool.wait(t)[0]["raw"], ref[key]); done += 1
+        check(*window.pop(0))
+for item in window:
+    check(*item)
 print(f"SOAK log_n={log_n} in_flight={depth}: {done} proofs, {bad} mismatches, {done / (time.perf_counter() - t0):.1f} proofs/s", flush=True)
 pool.close()
 sys.exit(1 if bad else 0)
