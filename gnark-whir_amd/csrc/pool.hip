@@ -82,7 +82,7 @@ static void finish_job(mi_prover *p, Job *j, int32_t rc, const char *err) {
     {
         std::lock_guard<std::mutex> lk(p->m);
         j->rc = rc;
-        if (rc != MI_OK) j->err = err ? err : "";
+        if (rc != MI_OK) { try { j->err = err ? err : ""; } catch (...) { } }
         if (j->set >= 0) { p->sets[j->set].busy = false; j->set = -1; }
         j->done = true;
     }
@@ -103,7 +103,9 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
             p->queue.pop_front();
             p->busy++;
         }
-        int32_t rc, rc_pok = MI_OK;
+        int32_t rc = MI_ENOMEM, rc_pok = MI_OK;
+        std::string prove_err;
+        try {   // (nothing may leave a worker thread: an allocation failure in the bookkeeping below is this job's MI_ENOMEM, not std::terminate)
         // BSB22: ProveKnowledge of every commitment but the last runs before the proof, the last one rides on slot 5 BESIDE the proof's
         // five MSMs and is collected after it (prove.go computes the PoK between the solve and computeH: same values, same points)
         const size_t nb = j->bsb.size();
@@ -140,7 +142,7 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
         } else {
             rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
         }
-        std::string prove_err = rc != MI_OK ? mi_last_error(ctx) : "";
+        prove_err = rc != MI_OK ? mi_last_error(ctx) : "";
         if (f_pok.valid()) { rc_pok = f_pok.get(); pok_pending = rc_pok == MI_OK; if (rc_pok != MI_OK) pok_err = "prover: enqueueing the ProveKnowledge MSM failed"; }
         if (pok_pending) {   // collected whatever the proof did: slot 5 must be idle for the next job
             const int32_t r2 = mi_pedersen_pok_collect(ctx, &poks[nb - 1]);
@@ -149,6 +151,14 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
         if (rc == MI_OK && rc_pok != MI_OK) { rc = rc_pok; prove_err = pok_err; }
         if (rc == MI_OK && nb && j->pok_out) rc = mi_pedersen_fold(poks.data(), nb, &j->challenge, j->pok_out);
         if (rc == MI_OK && j->host && j->stats) j->stats->h2d_ms = j->h2d_ms;
+        } catch (...) {
+            rc = MI_ENOMEM;
+            if (j->gated) {   // the uploader may still be copying this job's vectors: wait for it as the regular path does
+                std::unique_lock<std::mutex> lk(p->m);
+                InputSet &set = p->sets[j->set];
+                p->cv_abc.wait(lk, [&] { return set.abc_state < 0 || set.abc_state >= 3; });
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(p->m);
             p->busy--;
@@ -202,12 +212,11 @@ static void uploader_main(mi_prover *p) {
         }
         if (e != hipSuccess) {
             (void)hipGetLastError();
-            std::string msg = std::string(what) + ": " + hipGetErrorString(e);
             {
                 std::lock_guard<std::mutex> lk(p->m);
                 p->uploading = false;
             }
-            finish_job(p, j, e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, msg.c_str());
+            finish_job(p, j, e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, what);   // (a literal: nothing on this thread may throw)
             p->cv_work.notify_all();
             continue;
         }
