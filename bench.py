@@ -328,6 +328,30 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
     return sharded, sharded_prove
 
 
+def bind_to_gpu_numa_node(torch, local_rank):
+    """One rank per GPU on a multi-socket node: keep this rank's threads -- and, by first touch, the host buffers it is about to allocate,
+    which the uploader reads at ~25 GB/s per rank -- on the NUMA node the GPU hangs off.  Best effort (sysfs may say -1 or be unreadable;
+    the box may confine the process to other cores): returns a short description for the line, or None when nothing was changed."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        pick = cpus & allowed
+        if len(pick) < 8:   # too few of that node's cores are ours: leave the affinity alone
+            return None
+        os.sched_setaffinity(0, pick)
+        return f"GPU {bdf} on NUMA node {node}: {len(pick)} cores"
+    except Exception:
+        return None
+
+
 def self_launch(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N rank processes as CHILDREN of this process -- which has not touched
     the GPU and never will -- with the environment torch.distributed.run would give them, relay rank 0's JSON line, and exit with the
@@ -426,6 +450,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
+    numa = bind_to_gpu_numa_node(torch, local_rank) if world > 1 and not args.rehearse_on_one_gpu else None   # (N = 1 keeps every core: the CPU baseline wants them)
 
     B = _binding()
     # the prover pool: --in-flight contexts on this rank's GPU (own streams, workspaces, host worker thread), one shared key
@@ -737,7 +762,7 @@ def main():
                        "nb_wires": nb_wires, "nb_public": nb_public, "n_constraints": n_constraints, "n_committed": n_committed, "scalar_dist": args.dist,
                        "g1_msm_sizes": [na, nb, nk, N - 1], "g2_msm_size": nb, "pedersen_msm_sizes": [n_committed, n_committed], "proofs_in_flight_per_gpu": in_flight,
                        "caller_threads": callers, "inputs": "host memory (PCIe inside the step)"},
-            "proof_bytes": len(serial_bytes),
+            "proof_bytes": len(serial_bytes), "rank0_numa_binding": numa,
             # the GPU-side rate: the same key and witness with W, a, b, c already in HBM and no commitment (164-byte body) -- what rounds 1-3
             # reported as `value`; no caller of the reference can reach it (gnark's solver is CPU code)
             "value_hbm_resident_inputs": dev_rate, "ms_per_step_hbm_resident_inputs": dev_ms,
