@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(512) k_msm2_count(Msm2Shape s, const Fr *scala
     const u32 cnt = s0 + per <= s.nslices ? per : s.nslices - s0;
     for (u32 k = threadIdx.x; k < per * s.ngroups; k += blockDim.x) lds[k] = 0;
     __syncthreads();
-    for (u32 j = 0; j < cnt; j++) msm2_count_body(s, scalars, montgomery != 0, s0 + j, lds + j * s.ngroups, threadIdx.x, blockDim.x);
+    msm2_count_slices(s, scalars, montgomery != 0, s0, cnt, lds, threadIdx.x, blockDim.x);
     __syncthreads();
     for (u32 k = threadIdx.x; k < per * s.ngroups; k += blockDim.x) {
         u32 g = k / per, j = k % per;
@@ -141,8 +141,9 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
     __syncthreads();
     msm2_stage_copy_body(s, gbase, loff, stage_lo, stage_val, stage_grp, part_lo, part_val, threadIdx.x, blockDim.x);
 }
-__global__ void k_msm2_chunk_count(Msm2Shape s, const u32 *S1, u32 *gstart, u32 *nchunks) {
+__global__ void k_msm2_chunk_count(Msm2Shape s, const u32 *S1, u32 *gstart, u32 *nchunks, u32 *max_word) {
     u32 hi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hi == 0) *max_word = 0;   // k_msm2_colsum's atomicMax target, two launches further down the stream
     if (hi < s.ngroups) msm2_chunk_count_body(s, S1, gstart, nchunks, hi);
 }
 __global__ void __launch_bounds__(1024) k_msm2_hist2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const uint16_t *part_lo, u32 *H2) {
@@ -155,9 +156,12 @@ __global__ void __launch_bounds__(1024) k_msm2_hist2(Msm2Shape s, const u32 *gst
     __syncthreads();
     msm2_hist2_write(s, H2, blockIdx.x, lds_u32, threadIdx.x, blockDim.x);
 }
-__global__ void k_msm2_colsum(Msm2Shape s, const u32 *cstart, u32 *H2, u32 *total) {
+// also leaves the fullest bucket's size in *max_out (zeroed on the stream before the launch): what fetch_max_enqueue's own kernel computes
+__global__ void __launch_bounds__(256) k_msm2_colsum(Msm2Shape s, const u32 *cstart, u32 *H2, u32 *total, u32 *max_out) {
     u32 key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key < s.nkeys) msm2_colsum_body(s, cstart, H2, total, key);
+    u32 m = key < s.nkeys ? msm2_colsum_body(s, cstart, H2, total, key) : 0u;
+    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(max_out, m);
 }
 __global__ void __launch_bounds__(1024) k_msm2_scatter2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const u32 *keystart, const u32 *H2x,
                                                         const uint16_t *part_lo, const u32 *part_val, u32 *sorted) {
@@ -367,15 +371,18 @@ __global__ void __launch_bounds__(256) k_max_u32(const u32 *v, u32 n, u32 *out) 
     for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; }
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
+// totals == nullptr: the word at sl.buf[B_MAX] has been computed already (k_msm2_colsum); only the copy and the event are enqueued
 static int32_t fetch_max_enqueue(mi_ctx *ctx, MsmSlot &sl, const u32 *totals, u32 nkeys) {
     MI_TRY(mi_reserve(ctx, sl.buf[B_MAX], 64));
     u32 *dmax = (u32 *)sl.buf[B_MAX].p;
     hipStream_t st = sl.stream;
-    MI_CHECK_HIP(ctx, hipMemsetAsync(dmax, 0, 4, st));
-    unsigned grid = (nkeys + 255) / 256;
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_max_u32, dim3(grid), dim3(256), 0, st, totals, nkeys, dmax);
-    MI_CHECK_HIP(ctx, hipGetLastError());
+    if (totals) {
+        MI_CHECK_HIP(ctx, hipMemsetAsync(dmax, 0, 4, st));
+        unsigned grid = (nkeys + 255) / 256;
+        if (grid > 1024) grid = 1024;
+        hipLaunchKernelGGL(k_max_u32, dim3(grid), dim3(256), 0, st, totals, nkeys, dmax);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+    }
     MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)sl.host_wsum + 128 * 256 + 32, dmax, 4, hipMemcpyDeviceToHost, st));
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[6], st));
     sl.max_pending = true;
@@ -563,13 +570,14 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     const size_t part_lds = ((size_t)3 * s.ngroups + 1 + 256 + cap) * 4 + (size_t)cap * 2 * 2;   // ... + stage_val | stage_lo, stage_grp (u16)
     if (part_lds > 160 * 1024) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: pass-1 slice does not fit in LDS");
     hipLaunchKernelGGL(k_msm2_partition, dim3(G), dim3(MSM2_PART_THREADS), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val);
-    hipLaunchKernelGGL(k_msm2_chunk_count, dim3((s.ngroups + 63) / 64), dim3(64), 0, st, s, S1, gstart, nchunks);
+    MI_TRY(mi_reserve(ctx, sl.buf[B_MAX], 64));
+    hipLaunchKernelGGL(k_msm2_chunk_count, dim3((s.ngroups + 63) / 64), dim3(64), 0, st, s, S1, gstart, nchunks, (u32 *)sl.buf[B_MAX].p);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, nchunks, s.ngroups, cstart, sl.buf[B_SCAN]));
     hipLaunchKernelGGL(k_msm2_hist2, dim3(chunks_bound), dim3(1024), s.gsize * 4, st, s, gstart, cstart, part_lo, H2);
-    hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, cstart, H2, total);
+    hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, cstart, H2, total, (u32 *)sl.buf[B_MAX].p);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(fetch_max_enqueue(ctx, sl, total, s.nkeys));
+    MI_TRY(fetch_max_enqueue(ctx, sl, nullptr, s.nkeys));
     MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
     hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound + 8), dim3(1024), s.gsize * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
     MI_CHECK_HIP(ctx, hipGetLastError());

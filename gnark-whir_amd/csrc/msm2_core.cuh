@@ -50,10 +50,13 @@ struct Msm2Digits {
     u32 carry;
     u32 w;
     MI_HD void start(const Fr &scalar, bool montgomery) { v = montgomery ? fe_from_mont(scalar) : scalar; carry = 0; w = 0; }
+    // The low c bits, then the whole number moves down by c (c < 32): indexing v.l[] by the window's bit offset instead put v into
+    // scratch memory on the GPU (two scratch loads and a full wait per digit: the counting and partition kernels' waves were parked
+    // three quarters of the time).
     MI_HD int32_t next(const Msm2Shape &s) {
-        u32 bit = w * s.c, limb = bit >> 5, sh = bit & 31;
-        u64 lo = limb < 8 ? v.l[limb] : 0u, hi = limb + 1 < 8 ? v.l[limb + 1] : 0u;
-        u32 raw = (u32)(((hi << 32) | lo) >> sh) & ((1u << s.c) - 1);
+        const u32 raw = v.l[0] & ((1u << s.c) - 1);
+        for (int k = 0; k < 7; k++) v.l[k] = (v.l[k] >> s.c) | (v.l[k + 1] << (32 - s.c));
+        v.l[7] >>= s.c;
         int32_t d = (int32_t)(raw + carry);
         if ((u32)d >= s.half) { d -= (int32_t)(1u << s.c); carry = 1; } else carry = 0;
         w++;
@@ -76,6 +79,34 @@ MI_HD void msm2_count_body(const Msm2Shape &s, const Fr *scalars, bool montgomer
         Msm2Digits dg;
         dg.start(scalars[i], montgomery);
         msm2_count_one(s, dg, lds);
+    }
+}
+// The same for `cnt` consecutive slices g0, g0 + 1, ... (counters of slice j at lds + j * ngroups) with the NEXT scalar's load in flight
+// while the current one is counted: the counting workgroups of msm.hip walk 32 slices each, and one dependent load per slice left
+// their waves parked three quarters of the time.
+MI_HD void msm2_count_slices(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g0, u32 cnt, u32 *lds, u32 tid, u32 nthr) {
+    u32 per = (s.n + s.nslices - 1) / s.nslices;
+    if (per > nthr) {   // (not the shape msm.hip launches: MSM2_SLICE scalars per slice, as many threads)
+        for (u32 j = 0; j < cnt; j++) msm2_count_body(s, scalars, montgomery, g0 + j, lds + j * s.ngroups, tid, nthr);
+        return;
+    }
+    u32 begin, end;
+    msm2_slice_range(s, g0, begin, end);
+    bool have = begin + tid < end;
+    Fr next = have ? scalars[begin + tid] : Fr{};
+    for (u32 j = 0; j < cnt; j++) {
+        const Fr cur = next;
+        const bool have_cur = have;
+        if (j + 1 < cnt) {
+            msm2_slice_range(s, g0 + j + 1, begin, end);
+            have = begin + tid < end;
+            if (have) next = scalars[begin + tid];
+        }
+        if (have_cur) {
+            Msm2Digits dg;
+            dg.start(cur, montgomery);
+            msm2_count_one(s, dg, lds + j * s.ngroups);
+        }
     }
 }
 // ---- pass 1b: partition, staged through LDS so that the global stores are runs, not single entries.
@@ -151,15 +182,25 @@ MI_HD void msm2_hist2_write(const Msm2Shape &s, u32 *H2, u32 chunk_id, const u32
 }
 // ---- column sums: thread = key (hi, lo): H2[chunk][lo] <- exclusive prefix along the chunks of group hi (in place),
 // total[key] <- number of entries of the key
-MI_HD void msm2_colsum_body(const Msm2Shape &s, const u32 *cstart, u32 *H2, u32 *total, u32 key) {
+// Eight chunks per trip: the eight loads go out together (a group that holds the WHIR mix's small scalars has hundreds of chunks, and one
+// dependent load + store per chunk made that group's threads the launch's tail: 0.24 ms for 35 M entries).
+MI_HD u32 msm2_colsum_body(const Msm2Shape &s, const u32 *cstart, u32 *H2, u32 *total, u32 key) {
     u32 hi = key >> s.gbits, lo = key & (s.gsize - 1), run = 0;
-    for (u32 ch = cstart[hi]; ch < cstart[hi + 1]; ch++) {
+    u32 ch = cstart[hi];
+    const u32 end = cstart[hi + 1];
+    for (; ch + 8 <= end; ch += 8) {
+        u32 v[8];
+        for (u32 k = 0; k < 8; k++) v[k] = H2[(size_t)(ch + k) * s.gsize + lo];
+        for (u32 k = 0; k < 8; k++) { H2[(size_t)(ch + k) * s.gsize + lo] = run; run += v[k]; }
+    }
+    for (; ch < end; ch++) {
         size_t i = (size_t)ch * s.gsize + lo;
         u32 v = H2[i];
         H2[i] = run;
         run += v;
     }
     total[key] = run;
+    return run;
 }
 // ---- pass 2b: scatter.  cursor[lo] = keystart[hi*gsize + lo] + H2x[chunk][lo]
 MI_HD void msm2_scatter2_init(const Msm2Shape &s, const u32 *keystart, const u32 *H2x, u32 chunk_id, u32 hi, u32 *lds, u32 tid, u32 nthr) {

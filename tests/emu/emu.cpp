@@ -384,10 +384,12 @@ extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uin
     else for (u32 i = 0; i < n; i++) msm2_precompute_body<F>((const Affine<F> *)pts_v, pre.data(), n, c, s.nwin, i);
     // pass 1
     std::vector<u32> C1((size_t)s.ngroups * G), lds(s.gsize > s.ngroups ? s.gsize : s.ngroups);
-    for (u32 g = 0; g < G; g++) {
-        for (u32 h = 0; h < s.ngroups; h++) lds[h] = 0;
-        for (u32 t = 0; t < nthr; t++) msm2_count_body(s, (const Fr *)sc_v, mont != 0, g, lds.data(), t, nthr);
-        for (u32 h = 0; h < s.ngroups; h++) C1[(size_t)h * G + g] = lds[h];
+    std::vector<u32> two(2 * (size_t)s.ngroups);
+    for (u32 g = 0; g < G; g += 2) {   // two slices per counting workgroup, like k_msm2_count's `per` (the prefetching walk)
+        const u32 cnt = g + 2 <= G ? 2 : 1;
+        for (auto &x : two) x = 0;
+        for (u32 t = 0; t < nthr; t++) msm2_count_slices(s, (const Fr *)sc_v, mont != 0, g, cnt, two.data(), t, nthr);
+        for (u32 j = 0; j < cnt; j++) for (u32 h = 0; h < s.ngroups; h++) C1[(size_t)h * G + g + j] = two[(size_t)j * s.ngroups + h];
     }
     std::vector<u32> S1;
     excl_scan(C1, S1);
