@@ -174,8 +174,15 @@ MI_HD bool msm2_chunk_range(const Msm2Shape &s, const u32 *gstart, const u32 *cs
 MI_HD void msm2_hist2_zero(const Msm2Shape &s, u32 *lds, u32 tid, u32 nthr) {
     for (u32 b = tid; b < s.gsize; b += nthr) lds[b] = 0;
 }
+// (eight entries per trip here and in the scatter: their loads go out together instead of one exposed latency per entry)
 MI_HD void msm2_hist2_count(const uint16_t *part_lo, u32 b, u32 e, u32 *lds, u32 tid, u32 nthr) {
-    for (u32 k = b + tid; k < e; k += nthr) MI_LDS_ATOMIC_ADD(&lds[part_lo[k]], 1u);
+    u32 k = b + tid;
+    for (; k + 7 * nthr < e; k += 8 * nthr) {
+        uint16_t lo[8];
+        for (u32 j = 0; j < 8; j++) lo[j] = part_lo[k + j * nthr];
+        for (u32 j = 0; j < 8; j++) MI_LDS_ATOMIC_ADD(&lds[lo[j]], 1u);
+    }
+    for (; k < e; k += nthr) MI_LDS_ATOMIC_ADD(&lds[part_lo[k]], 1u);
 }
 MI_HD void msm2_hist2_write(const Msm2Shape &s, u32 *H2, u32 chunk_id, const u32 *lds, u32 tid, u32 nthr) {
     for (u32 b = tid; b < s.gsize; b += nthr) H2[(size_t)chunk_id * s.gsize + b] = lds[b];
@@ -207,7 +214,15 @@ MI_HD void msm2_scatter2_init(const Msm2Shape &s, const u32 *keystart, const u32
     for (u32 b = tid; b < s.gsize; b += nthr) lds[b] = keystart[(size_t)hi * s.gsize + b] + H2x[(size_t)chunk_id * s.gsize + b];
 }
 MI_HD void msm2_scatter2_move(const uint16_t *part_lo, const u32 *part_val, u32 b, u32 e, u32 *lds, u32 *sorted, u32 tid, u32 nthr) {
-    for (u32 k = b + tid; k < e; k += nthr) {
+    u32 k = b + tid;
+    for (; k + 7 * nthr < e; k += 8 * nthr) {
+        uint16_t lo[8];
+        u32 val[8], pos[8];
+        for (u32 j = 0; j < 8; j++) { lo[j] = part_lo[k + j * nthr]; val[j] = part_val[k + j * nthr]; }
+        for (u32 j = 0; j < 8; j++) pos[j] = MI_LDS_ATOMIC_ADD(&lds[lo[j]], 1u);
+        for (u32 j = 0; j < 8; j++) sorted[pos[j]] = val[j];
+    }
+    for (; k < e; k += nthr) {
         u32 pos = MI_LDS_ATOMIC_ADD(&lds[part_lo[k]], 1u);
         sorted[pos] = part_val[k];
     }
