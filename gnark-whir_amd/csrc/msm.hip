@@ -117,8 +117,12 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
     for (u32 g = threadIdx.x; g < s.ngroups; g += blockDim.x) hist[g] = 0;
     // a slice has at most MSM2_SLICE = blockDim scalars: one per thread, loaded and made canonical once, kept in registers for
     // both the count and the place phase
+    // XCD-aware slice order (as in k_msm2_scatter2): XCD x walks the contiguous slices [x*Q, (x+1)*Q), so the runs that neighbouring
+    // slices append to a group meet in ONE L2 and leave as whole lines
+    const u32 Q = (s.nslices + 7) / 8, slice = (blockIdx.x & 7) * Q + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= Q || slice >= s.nslices) return;
     u32 begin, end;
-    msm2_slice_range(s, blockIdx.x, begin, end);
+    msm2_slice_range(s, slice, begin, end);
     const u32 i = begin + threadIdx.x;
     const bool have = i < end;
     Msm2Digits dg;
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
         const bool mine = threadIdx.x < 256 && i < s.ngroups;
         u32 v = mine ? hist[i] : 0, total;
         u32 ex = block_exclusive_scan_first256(v, tmp, &total);
-        if (mine) { loff[i] = carry + ex; hist[i] = carry + ex; gbase[i] = S1[(size_t)i * s.nslices + blockIdx.x]; }
+        if (mine) { loff[i] = carry + ex; hist[i] = carry + ex; gbase[i] = S1[(size_t)i * s.nslices + slice]; }
         carry += total;
     }
     if (threadIdx.x == 0) loff[s.ngroups] = carry;
@@ -569,7 +573,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     const u32 cap = ((n + G - 1) / G) * s.nwin;   // entries of one slice at most
     const size_t part_lds = ((size_t)3 * s.ngroups + 1 + 256 + cap) * 4 + (size_t)cap * 2 * 2;   // ... + stage_val | stage_lo, stage_grp (u16)
     if (part_lds > 160 * 1024) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: pass-1 slice does not fit in LDS");
-    hipLaunchKernelGGL(k_msm2_partition, dim3(G), dim3(MSM2_PART_THREADS), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val);
+    hipLaunchKernelGGL(k_msm2_partition, dim3(((G + 7) / 8) * 8), dim3(MSM2_PART_THREADS), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val);
     MI_TRY(mi_reserve(ctx, sl.buf[B_MAX], 64));
     hipLaunchKernelGGL(k_msm2_chunk_count, dim3((s.ngroups + 63) / 64), dim3(64), 0, st, s, S1, gstart, nchunks, (u32 *)sl.buf[B_MAX].p);
     MI_CHECK_HIP(ctx, hipGetLastError());
