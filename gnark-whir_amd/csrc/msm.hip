@@ -78,13 +78,15 @@ __global__ void k_msm_prep_next(u32 nkeys, const u32 *prev_items, const u32 *pre
 static constexpr u32 MSM2_MAX_GROUPS = 4096;   // 2^(c-1-gbits) <= 2^(21-9)
 // workgroup = `per` consecutive slices (per * ngroups <= 8192 counters of LDS): the counters of a group are then written as
 // per * 4-B contiguous segments of C1[group][slice] instead of single words 4 * nslices bytes apart
+// (C: the window width at compile time -- the digits of a scalar then cost a few shifts of registers each, msm2_core.cuh; 0 = any width)
+template <u32 C>
 __global__ void __launch_bounds__(512) k_msm2_count(Msm2Shape s, const Fr *scalars, int montgomery, u32 per, u32 *C1) {
     __shared__ u32 lds[8192];
     const u32 s0 = blockIdx.x * per;
     const u32 cnt = s0 + per <= s.nslices ? per : s.nslices - s0;
     for (u32 k = threadIdx.x; k < per * s.ngroups; k += blockDim.x) lds[k] = 0;
     __syncthreads();
-    msm2_count_slices(s, scalars, montgomery != 0, s0, cnt, lds, threadIdx.x, blockDim.x);
+    msm2_count_slices<C>(s, scalars, montgomery != 0, s0, cnt, lds, threadIdx.x, blockDim.x);
     __syncthreads();
     for (u32 k = threadIdx.x; k < per * s.ngroups; k += blockDim.x) {
         u32 g = k / per, j = k % per;
@@ -109,6 +111,7 @@ __device__ u32 block_exclusive_scan_first256(u32 v, u32 *lds, u32 *total) {
     return incl - v;
 }
 static constexpr u32 MSM2_PART_THREADS = MSM2_SLICE;   // one scalar per thread: 8 waves per workgroup hide the LDS-atomic latency of place/copy
+template <u32 C>
 __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape s, const Fr *scalars, int montgomery, const u32 *S1, u32 cap,
                                                                       uint16_t *part_lo, u32 *part_val) {
     extern __shared__ u32 lds_u32[];
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
     Msm2Digits dg;
     if (have) dg.start(scalars[i], montgomery != 0);
     __syncthreads();
-    if (have) msm2_count_one(s, dg, hist);
+    if (have) msm2_count_one<C>(s, dg, hist);
     __syncthreads();
     u32 carry = 0;
     for (u32 base = 0; base < s.ngroups; base += 256) {   // loff = exclusive scan of hist; hist becomes the cursor
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
     }
     if (threadIdx.x == 0) loff[s.ngroups] = carry;
     __syncthreads();
-    if (have) msm2_place_one(s, dg, i, hist, stage_lo, stage_val, stage_grp);
+    if (have) msm2_place_one<C>(s, dg, i, hist, stage_lo, stage_val, stage_grp);
     __syncthreads();
     msm2_stage_copy_body(s, gbase, loff, stage_lo, stage_val, stage_grp, part_lo, part_val, threadIdx.x, blockDim.x);
 }
@@ -317,7 +320,9 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     (void)hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_msm2_hist2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_msm2_partition, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define MI_PART_LDS(C) (void)hipFuncSetAttribute((const void *)k_msm2_partition<C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    for (u32 c = 15; c <= 22; c++) { MSM2_FOR_C(c, MI_PART_LDS) }   // (15: the run-time-width instance)
+#undef MI_PART_LDS
     (void)hipFuncSetAttribute((const void *)k_msm2_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // Stream priorities (3 levels on this device).  prove.hip runs A, B1, B2, K on slots 0..3 and Z on slot 4; computeH runs on
     // the context's own stream (high, api.hip).  With equal priorities the hardware shares the CUs evenly, all five MSMs crawl
@@ -545,7 +550,9 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     static const u32 per_knob = getenv("MI_MSM2_COUNT_PER") ? (u32)atoi(getenv("MI_MSM2_COUNT_PER")) : 32u;
     u32 per = per_knob >= 1 && per_knob <= 64 ? per_knob : 32u;
     while (per > 1 && per * s.ngroups > 8192) per >>= 1;
-    hipLaunchKernelGGL(k_msm2_count, dim3((G + per - 1) / per), dim3(512), 0, st, s, scalars, mont, per, C1);
+#define MI_LAUNCH_COUNT(C) hipLaunchKernelGGL(k_msm2_count<C>, dim3((G + per - 1) / per), dim3(512), 0, st, s, scalars, mont, per, C1)
+    MSM2_FOR_C(s.c, MI_LAUNCH_COUNT)
+#undef MI_LAUNCH_COUNT
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, C1, (size_t)s.ngroups * G, S1, sl.buf[B_SCAN]));
     // Entry-indexed workspaces (two partition arrays, chunk histograms, sorted entries; later the per-item partial sums) take
@@ -573,7 +580,9 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     const u32 cap = ((n + G - 1) / G) * s.nwin;   // entries of one slice at most
     const size_t part_lds = ((size_t)3 * s.ngroups + 1 + 256 + cap) * 4 + (size_t)cap * 2 * 2;   // ... + stage_val | stage_lo, stage_grp (u16)
     if (part_lds > 160 * 1024) MI_FAIL(ctx, MI_EINVAL, "fixed-base msm: pass-1 slice does not fit in LDS");
-    hipLaunchKernelGGL(k_msm2_partition, dim3(((G + 7) / 8) * 8), dim3(MSM2_PART_THREADS), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val);
+#define MI_LAUNCH_PART(C) hipLaunchKernelGGL(k_msm2_partition<C>, dim3(((G + 7) / 8) * 8), dim3(MSM2_PART_THREADS), part_lds, st, s, scalars, mont, S1, cap, part_lo, part_val)
+    MSM2_FOR_C(s.c, MI_LAUNCH_PART)
+#undef MI_LAUNCH_PART
     MI_TRY(mi_reserve(ctx, sl.buf[B_MAX], 64));
     hipLaunchKernelGGL(k_msm2_chunk_count, dim3((s.ngroups + 63) / 64), dim3(64), 0, st, s, S1, gstart, nchunks, (u32 *)sl.buf[B_MAX].p);
     MI_CHECK_HIP(ctx, hipGetLastError());

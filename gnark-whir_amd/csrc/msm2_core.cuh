@@ -62,13 +62,36 @@ struct Msm2Digits {
         w++;
         return d;
     }
+    // Window width known at compile time (C = 16..22; C = 0: the run-time walk above).  Called from a fully unrolled loop over w: the
+    // limb index is then a constant too, a digit is two shifts, an or and a mask of registers, and nothing moves.
+    template <u32 C> MI_HD int32_t at(u32 win, const Msm2Shape &s) {
+        if (C == 0) return next(s);
+        const u32 bit = win * C, limb = bit >> 5, sh = bit & 31;
+        u32 raw = limb < 8 ? v.l[limb < 8 ? limb : 0] >> sh : 0u;
+        if (sh + C > 32 && limb + 1 < 8) raw |= v.l[limb + 1 < 8 ? limb + 1 : 0] << ((32 - sh) & 31);
+        raw &= (1u << (C ? C : 1)) - 1;
+        int32_t d = (int32_t)(raw + carry);
+        if ((u32)d >= s.half) { d -= (int32_t)(1u << (C ? C : 1)); carry = 1; } else carry = 0;
+        return d;
+    }
 };
+// windows of a width known at compile time (C = 0: s.nwin)
+template <u32 C> MI_HD u32 msm2_nwin_c(const Msm2Shape &s) { return C ? (256 + (C ? C : 1) - 1) / (C ? C : 1) : s.nwin; }
+// CALL(C) with the compile-time width that equals c, or CALL(0) (run-time width) for any other
+#define MSM2_FOR_C(c, CALL) \
+    switch (c) { case 16: CALL(16); break; case 17: CALL(17); break; case 18: CALL(18); break; case 19: CALL(19); break; \
+                 case 20: CALL(20); break; case 21: CALL(21); break; case 22: CALL(22); break; default: CALL(0); break; }
 
 // ---- pass 1a: workgroup = slice g; LDS hist[ngroups]; C1[hi][g]
 // one scalar (already canonical in dg, restarted by the caller): its non-zero digits counted by group
+template <u32 C = 0>
 MI_HD void msm2_count_one(const Msm2Shape &s, Msm2Digits dg, u32 *lds) {
-    for (u32 w = 0; w < s.nwin; w++) {
-        int32_t d = dg.next(s);
+    const u32 nw = msm2_nwin_c<C>(s);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (u32 w = 0; w < nw; w++) {
+        int32_t d = dg.template at<C>(w, s);
         if (d) MI_LDS_ATOMIC_ADD(&lds[(((u32)(d < 0 ? -d : d) - 1) + (s.wkeys ? w * s.half : 0u)) >> s.gbits], 1u);
     }
 }
@@ -84,6 +107,7 @@ MI_HD void msm2_count_body(const Msm2Shape &s, const Fr *scalars, bool montgomer
 // The same for `cnt` consecutive slices g0, g0 + 1, ... (counters of slice j at lds + j * ngroups) with the NEXT scalar's load in flight
 // while the current one is counted: the counting workgroups of msm.hip walk 32 slices each, and one dependent load per slice left
 // their waves parked three quarters of the time.
+template <u32 C = 0>
 MI_HD void msm2_count_slices(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g0, u32 cnt, u32 *lds, u32 tid, u32 nthr) {
     u32 per = (s.n + s.nslices - 1) / s.nslices;
     if (per > nthr) {   // (not the shape msm.hip launches: MSM2_SLICE scalars per slice, as many threads)
@@ -105,7 +129,7 @@ MI_HD void msm2_count_slices(const Msm2Shape &s, const Fr *scalars, bool montgom
         if (have_cur) {
             Msm2Digits dg;
             dg.start(cur, montgomery);
-            msm2_count_one(s, dg, lds + j * s.ngroups);
+            msm2_count_one<C>(s, dg, lds + j * s.ngroups);
         }
     }
 }
@@ -116,9 +140,14 @@ MI_HD void msm2_count_slices(const Msm2Shape &s, const Fr *scalars, bool montgom
 // gbase[hi] + (e - loff[hi]), gbase[hi] = S1[hi * G + g]: consecutive e of a group are consecutive in part_lo / part_val.
 // one scalar i (canonical in dg): its entries go to their groups' runs of the staging area.  stage_grp keeps every entry's group
 // next to it: the copy phase then needs two LDS reads per entry instead of a binary search over loff (8 dependent reads).
+template <u32 C = 0>
 MI_HD void msm2_place_one(const Msm2Shape &s, Msm2Digits dg, u32 i, u32 *cursor, uint16_t *stage_lo, u32 *stage_val, uint16_t *stage_grp) {
-    for (u32 w = 0; w < s.nwin; w++) {
-        int32_t d = dg.next(s);
+    const u32 nw = msm2_nwin_c<C>(s);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (u32 w = 0; w < nw; w++) {
+        int32_t d = dg.template at<C>(w, s);
         if (!d) continue;
         u32 key = (u32)(d < 0 ? -d : d) - 1 + (s.wkeys ? w * s.half : 0u);
         u32 pos = MI_LDS_ATOMIC_ADD(&cursor[key >> s.gbits], 1u);
@@ -127,6 +156,7 @@ MI_HD void msm2_place_one(const Msm2Shape &s, Msm2Digits dg, u32 i, u32 *cursor,
         stage_val[pos] = (s.wkeys ? i : w * s.n + i) | (d < 0 ? 0x80000000u : 0u);
     }
 }
+template <u32 C = 0>
 MI_HD void msm2_stage_place_body(const Msm2Shape &s, const Fr *scalars, bool montgomery, u32 g, u32 *cursor, uint16_t *stage_lo, u32 *stage_val,
                                  uint16_t *stage_grp, u32 tid, u32 nthr) {
     u32 begin, end;
@@ -134,7 +164,7 @@ MI_HD void msm2_stage_place_body(const Msm2Shape &s, const Fr *scalars, bool mon
     for (u32 i = begin + tid; i < end; i += nthr) {
         Msm2Digits dg;
         dg.start(scalars[i], montgomery);
-        msm2_place_one(s, dg, i, cursor, stage_lo, stage_val, stage_grp);
+        msm2_place_one<C>(s, dg, i, cursor, stage_lo, stage_val, stage_grp);
     }
 }
 // gbase[hi] = S1[hi * G + g] (the slice's run of group hi in the partitioned arrays), loaded once per workgroup

@@ -388,7 +388,9 @@ extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uin
     for (u32 g = 0; g < G; g += 2) {   // two slices per counting workgroup, like k_msm2_count's `per` (the prefetching walk)
         const u32 cnt = g + 2 <= G ? 2 : 1;
         for (auto &x : two) x = 0;
-        for (u32 t = 0; t < nthr; t++) msm2_count_slices(s, (const Fr *)sc_v, mont != 0, g, cnt, two.data(), t, nthr);
+#define EMU_COUNT(C) msm2_count_slices<C>(s, (const Fr *)sc_v, mont != 0, g, cnt, two.data(), t, nthr)
+        for (u32 t = 0; t < nthr; t++) { MSM2_FOR_C(s.c, EMU_COUNT) }   // the compile-time-width digits where the kernels use them
+#undef EMU_COUNT
         for (u32 j = 0; j < cnt; j++) for (u32 h = 0; h < s.ngroups; h++) C1[(size_t)h * G + g + j] = two[(size_t)j * s.ngroups + h];
     }
     std::vector<u32> S1;
@@ -405,7 +407,9 @@ extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uin
         excl_scan(hist, loff);
         if (loff[s.ngroups] > cap) return -1;
         for (u32 h = 0; h < s.ngroups; h++) hist[h] = loff[h];
-        for (u32 t = 0; t < nthr; t++) msm2_stage_place_body(s, (const Fr *)sc_v, mont != 0, g, hist.data(), stage_lo.data(), stage_val.data(), stage_grp.data(), t, nthr);
+#define EMU_PLACE(C) msm2_stage_place_body<C>(s, (const Fr *)sc_v, mont != 0, g, hist.data(), stage_lo.data(), stage_val.data(), stage_grp.data(), t, nthr)
+        for (u32 t = 0; t < nthr; t++) { MSM2_FOR_C(s.c, EMU_PLACE) }
+#undef EMU_PLACE
         std::vector<u32> gbase(s.ngroups);
         for (u32 h = 0; h < s.ngroups; h++) gbase[h] = S1[(size_t)h * G + g];
         for (u32 t = 0; t < nthr; t++) msm2_stage_copy_body(s, gbase.data(), loff.data(), stage_lo.data(), stage_val.data(), stage_grp.data(), part_lo.data(), part_val.data(), t, nthr);
