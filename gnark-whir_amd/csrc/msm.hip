@@ -187,6 +187,42 @@ __global__ void __launch_bounds__(1024) k_msm2_scatter2(Msm2Shape s, const u32 *
     msm2_scatter2_move(part_lo, part_val, b, e, lds_u32, sorted, threadIdx.x, blockDim.x);
 }
 
+// The staged scatter (msm2_core.cuh): LDS = cursor[gsize] | cnt -> loc [gsize] | wave sums [16] | stage values [chunk] | stage buckets [chunk] (u16).
+// Needs chunk <= 8 * 1024 entries; the launcher falls back to k_msm2_scatter2 otherwise.
+__global__ void __launch_bounds__(1024) k_msm2_scatter2_staged(Msm2Shape s, const u32 *gstart, const u32 *cstart, const u32 *keystart, const u32 *H2x,
+                                                               const uint16_t *part_lo, const u32 *part_val, u32 *sorted) {
+    extern __shared__ u32 lds_u32[];
+    u32 *cursor = lds_u32, *loc = cursor + s.gsize, *wsum = loc + s.gsize, *st_val = wsum + 16;
+    uint16_t *st_lo = (uint16_t *)(st_val + s.chunk);
+    const u32 total = cstart[s.ngroups], Q = (total + 7) / 8;
+    const u32 chunk_id = (blockIdx.x & 7) * Q + (blockIdx.x >> 3);   // XCD-aware chunk order, as in k_msm2_scatter2
+    if ((blockIdx.x >> 3) >= Q) return;
+    u32 hi, b, e;
+    if (!msm2_chunk_range(s, gstart, cstart, chunk_id, hi, b, e)) return;
+    msm2_scatter2_init(s, keystart, H2x, chunk_id, hi, cursor, threadIdx.x, blockDim.x);
+    for (u32 k = threadIdx.x; k < s.gsize; k += blockDim.x) loc[k] = 0;
+    __syncthreads();
+    uint16_t lo[MSM2_STAGE_PER];
+    u32 val[MSM2_STAGE_PER], rank[MSM2_STAGE_PER];
+    const u32 m = msm2_stage2_rank(part_lo, part_val, b, e, loc, threadIdx.x, blockDim.x, lo, val, rank);
+    __syncthreads();
+    // exclusive scan of loc[0 .. gsize) in place: `per` consecutive counters per thread, wave scan of the thread sums, scan of the 16 wave sums
+    const u32 per = (s.gsize + blockDim.x - 1) / blockDim.x, k0 = threadIdx.x * per;
+    u32 mine = 0;
+    for (u32 k = 0; k < per; k++) if (k0 + k < s.gsize) mine += loc[k0 + k];
+    u32 incl = mine;
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)incl, off); if ((int)(threadIdx.x & 63) >= off) incl += o; }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u32 before = incl - mine;
+    for (u32 w = 0; w < (threadIdx.x >> 6); w++) before += wsum[w];
+    for (u32 k = 0; k < per; k++) if (k0 + k < s.gsize) { const u32 c = loc[k0 + k]; loc[k0 + k] = before; before += c; }
+    __syncthreads();
+    msm2_stage2_place(loc, lo, val, rank, m, st_lo, st_val);
+    __syncthreads();
+    msm2_stage2_copy(cursor, loc, st_lo, st_val, e - b, sorted, threadIdx.x, blockDim.x);
+}
+
 // ---------------------------------------------------------------- exclusive scan of u32 (out has m+1 entries, out[m] = total)
 static constexpr u32 SCAN_PER_THREAD = 16, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_PER_THREAD * SCAN_THREADS;
 __device__ u32 block_exclusive_scan_256(u32 v, u32 *lds, u32 *total) {
@@ -324,6 +360,7 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     for (u32 c = 15; c <= 22; c++) { MSM2_FOR_C(c, MI_PART_LDS) }   // (15: the run-time-width instance)
 #undef MI_PART_LDS
     (void)hipFuncSetAttribute((const void *)k_msm2_scatter2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_msm2_scatter2_staged, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     // Stream priorities (3 levels on this device).  prove.hip runs A, B1, B2, K on slots 0..3 and Z on slot 4; computeH runs on
     // the context's own stream (high, api.hip).  With equal priorities the hardware shares the CUs evenly, all five MSMs crawl
     // along together and their latency-bound tails pile up at the end of the proof.  Z's stream at LOW priority lets the four
@@ -592,7 +629,13 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(fetch_max_enqueue(ctx, sl, nullptr, s.nkeys));
     MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
-    hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound + 8), dim3(1024), s.gsize * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
+    // staged (destination-order) scatter where a chunk fits eight entries per thread and two workgroups still share a CU's LDS
+    static const bool plain_scatter = getenv("MI_MSM2_PLAIN_SCATTER") != nullptr;   // A/B switch
+    const size_t staged_lds = ((size_t)2 * s.gsize + 16 + chunk) * 4 + (size_t)chunk * 2;
+    if (!plain_scatter && chunk <= MSM2_STAGE_PER * 1024 && staged_lds <= 80 * 1024)
+        hipLaunchKernelGGL(k_msm2_scatter2_staged, dim3(chunks_bound + 8), dim3(1024), staged_lds, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
+    else
+        hipLaunchKernelGGL(k_msm2_scatter2, dim3(chunks_bound + 8), dim3(1024), s.gsize * 4, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[0], st));
     return MI_OK;

@@ -258,6 +258,39 @@ MI_HD void msm2_scatter2_move(const uint16_t *part_lo, const u32 *part_val, u32 
     }
 }
 
+// ---- pass 2b, staged: the chunk is counting-sorted INSIDE the workgroup first, then leaves in destination order.  A wave's 64 stores of
+// the plain scatter above go to 64 different lines (the entries of a chunk arrive in scalar order); in destination order consecutive
+// lanes write the consecutive words of a bucket's run (about four at 2^23 uniform pairs, hundreds for the WHIR mix's small scalars), so a
+// store instruction touches a quarter of the lines or fewer -- the address path of those stores, not LDS, was what the scatter waited on
+// (SQ_WAIT_INST_ANY 0.67, SQ_WAIT_INST_LDS 0.00).
+//   rank:  thread t holds entries b + t + j * nthr (j < MSM2_STAGE_PER); rank[j] = its place among the chunk's entries of the same bucket
+//   scan:  loc = exclusive scan of the per-bucket counts (the caller's block scan)
+//   place: entry -> stage[loc[bucket] + rank]
+//   copy:  stage slot p of bucket q goes to sorted[cursor[q] + p - loc[q]]   (cursor as in msm2_scatter2_init)
+static constexpr u32 MSM2_STAGE_PER = 8;
+MI_HD u32 msm2_stage2_rank(const uint16_t *part_lo, const u32 *part_val, u32 b, u32 e, u32 *cnt, u32 tid, u32 nthr, uint16_t *lo, u32 *val, u32 *rank) {
+    u32 m = 0;
+    for (u32 j = 0; j < MSM2_STAGE_PER; j++) {
+        const u32 k = b + tid + j * nthr;
+        if (k < e) { lo[j] = part_lo[k]; val[j] = part_val[k]; m = j + 1; }
+    }
+    for (u32 j = 0; j < MSM2_STAGE_PER; j++) if (j < m) rank[j] = MI_LDS_ATOMIC_ADD(&cnt[lo[j]], 1u);
+    return m;
+}
+MI_HD void msm2_stage2_place(const u32 *loc, const uint16_t *lo, const u32 *val, const u32 *rank, u32 m, uint16_t *st_lo, u32 *st_val) {
+    for (u32 j = 0; j < MSM2_STAGE_PER; j++) if (j < m) {
+        const u32 p = loc[lo[j]] + rank[j];
+        st_lo[p] = lo[j];
+        st_val[p] = val[j];
+    }
+}
+MI_HD void msm2_stage2_copy(const u32 *cursor, const u32 *loc, const uint16_t *st_lo, const u32 *st_val, u32 n, u32 *sorted, u32 tid, u32 nthr) {
+    for (u32 p = tid; p < n; p += nthr) {
+        const u32 q = st_lo[p];
+        sorted[cursor[q] + (p - loc[q])] = st_val[p];
+    }
+}
+
 // ---- pk_load: the window copies pre[w][i] = 2^(c*w) * P_i, affine.  Thread i walks the windows.
 template <class F>
 MI_HD void msm2_precompute_body(const Affine<F> *base, Affine<F> *pre, u32 n, u32 c, u32 nwin, u32 i) {

@@ -434,7 +434,18 @@ extern "C" int emu_msm2_g1(void *out_v, const void *pts_v, const void *sc_v, uin
         u32 hi, b, e;
         msm2_chunk_range(s, gstart.data(), cstart.data(), ch, hi, b, e);
         for (u32 t = 0; t < nthr; t++) msm2_scatter2_init(s, keystart.data(), H2.data(), ch, hi, lds.data(), t, nthr);
-        for (u32 t = 0; t < nthr; t++) msm2_scatter2_move(part_lo.data(), part_val.data(), b, e, lds.data(), sorted.data(), t, nthr);
+        if (e - b <= MSM2_STAGE_PER * nthr && (ch & 1)) {   // every other chunk through the staged scatter (k_msm2_scatter2_staged's phases)
+            std::vector<u32> loc(s.gsize, 0), cursor(lds.begin(), lds.begin() + s.gsize), st_val(e - b), rk((size_t)nthr * MSM2_STAGE_PER), vv((size_t)nthr * MSM2_STAGE_PER), mm(nthr);
+            std::vector<uint16_t> st_lo(e - b), ll((size_t)nthr * MSM2_STAGE_PER);
+            for (u32 t = 0; t < nthr; t++)
+                mm[t] = msm2_stage2_rank(part_lo.data(), part_val.data(), b, e, loc.data(), t, nthr, &ll[(size_t)t * MSM2_STAGE_PER], &vv[(size_t)t * MSM2_STAGE_PER], &rk[(size_t)t * MSM2_STAGE_PER]);
+            u32 run = 0;
+            for (u32 q = 0; q < s.gsize; q++) { u32 c = loc[q]; loc[q] = run; run += c; }
+            for (u32 t = 0; t < nthr; t++)
+                msm2_stage2_place(loc.data(), &ll[(size_t)t * MSM2_STAGE_PER], &vv[(size_t)t * MSM2_STAGE_PER], &rk[(size_t)t * MSM2_STAGE_PER], mm[t], st_lo.data(), st_val.data());
+            for (u32 t = 0; t < nthr; t++) msm2_stage2_copy(cursor.data(), loc.data(), st_lo.data(), st_val.data(), e - b, sorted.data(), t, nthr);
+        } else
+            for (u32 t = 0; t < nthr; t++) msm2_scatter2_move(part_lo.data(), part_val.data(), b, e, lds.data(), sorted.data(), t, nthr);
     }
     // items / levels over nkeys keys (one window), then bucket reduce with nwin = 1
     MsmShape ks;
