@@ -388,6 +388,21 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
         // null (msm_accum_enqueue).  The caller (mi_init_prio) unwinds through mi_shutdown, which frees what was created.
         MI_CHECK_HIP(ctx, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, idx == 4 ? pz : pw));
     }
+    // K (slot 3) runs on B1's stream (slot 1).  With a stream of its own it landed on the hardware queue of B2's stream, behind the whole
+    // G2 chain, and a single proof ended with K's accumulation alone on the GPU: rocprofv3 timeline, K's level 1 starting at 27 of 31 ms.
+    // Behind B1 -- the shortest of the five MSMs -- one proof is 1.0 ms shorter (30.8 against 31.9 ms) and the job unchanged; behind A
+    // (whose sort K shares) 0.8 ms.  MI_MSM_ALIAS=<slot><slot> picks another pair, MI_MSM_ALIAS=none gives every slot its own stream.
+    {
+        int a = 3, b = 1;
+        if (const char *e = getenv("MI_MSM_ALIAS")) {
+            a = e[0] - '0'; b = e[1] ? e[1] - '0' : -1;
+            if (a < 0 || a >= MI_MSM_SLOTS || b < 0 || b >= MI_MSM_SLOTS || a == b) a = b = -1;
+        }
+        if (a >= 0) {
+            (void)hipStreamDestroy(ctx->msm[a].stream);
+            ctx->msm[a].stream = ctx->msm[b].stream;
+        }
+    }
     for (auto &sl : ctx->msm) {
         for (auto &e : sl.ev) MI_CHECK_HIP(ctx, hipEventCreate(&e));
         MI_CHECK_HIP(ctx, hipHostMalloc(&sl.host_wsum, 128 * 256 + 64));
@@ -395,6 +410,7 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     return MI_OK;
 }
 void mi_msm_state_free(mi_ctx *ctx) {
+    for (int i = 0; i < MI_MSM_SLOTS; i++) for (int j = i + 1; j < MI_MSM_SLOTS; j++) if (ctx->msm[j].stream == ctx->msm[i].stream) ctx->msm[j].stream = nullptr;   // aliases
     for (auto &sl : ctx->msm) {
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
         for (auto &e : sl.ev) if (e) (void)hipEventDestroy(e);
