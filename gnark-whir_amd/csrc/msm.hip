@@ -224,64 +224,66 @@ __global__ void __launch_bounds__(1024) k_msm2_scatter2_staged(Msm2Shape s, cons
 }
 
 // ---------------------------------------------------------------- exclusive scan of u32 (out has m+1 entries, out[m] = total)
-static constexpr u32 SCAN_PER_THREAD = 16, SCAN_THREADS = 256, SCAN_BLOCK = SCAN_PER_THREAD * SCAN_THREADS;
-__device__ u32 block_exclusive_scan_256(u32 v, u32 *lds, u32 *total) {
-    // Hillis-Steele over 256 thread sums
-    u32 tid = threadIdx.x;
-    lds[tid] = v;
-    __syncthreads();
-    for (u32 off = 1; off < 256; off <<= 1) {
-        u32 a = tid >= off ? lds[tid - off] : 0;
-        __syncthreads();
-        lds[tid] += a;
-        __syncthreads();
-    }
-    u32 incl = lds[tid];
-    *total = lds[255];
-    __syncthreads();
+// Every kernel of this family is a grid of SINGLE-WAVE workgroups (64 threads, scans by wave shuffles, no LDS, no barrier).  These launches
+// sit between the heavy kernels of an MSM's chain, and beside them run the level-1 accumulations of the other MSMs, whose one-wave
+// workgroups keep every SIMD's register file full: a four-wave workgroup needs a free slot on all four SIMDs of one CU at the same
+// moment (rocprofv3: k_scan_block_sums 3.7 ms inside a proof, 12 us alone), one wave takes any slot.  Measured on the job and on the
+// single proof: no difference either way (the freed slots go to the accumulations' next workgroups first); kept for the simpler kernels.
+static constexpr u32 SCAN_PER_THREAD = 16, SCAN_THREADS = 64, SCAN_BLOCK = SCAN_PER_THREAD * SCAN_THREADS;
+static constexpr u32 SCAN_MAX_INLINE_BLOCKS = 8 * SCAN_THREADS;   // mode 2 of k_scan_final: every workgroup scans the block sums itself, eight per lane
+__device__ __forceinline__ u32 wave_inclusive_scan(u32 v) {
+    for (int off = 1; off < 64; off <<= 1) { const u32 o = (u32)__shfl_up((int)v, off); if ((int)(threadIdx.x & 63) >= off) v += o; }
+    return v;
+}
+__device__ __forceinline__ u32 wave_exclusive_scan(u32 v, u32 *total) {
+    const u32 incl = wave_inclusive_scan(v);
+    *total = (u32)__shfl((int)incl, 63);
     return incl - v;
 }
-__global__ void __launch_bounds__(256) k_scan_block_sums(const u32 *in, size_t m, u32 *block_sums) {
-    __shared__ u32 lds[256];
+__global__ void __launch_bounds__(64) k_scan_block_sums(const u32 *in, size_t m, u32 *block_sums) {
     size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     u32 s = 0;
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) if (base + k < m) s += in[base + k];
     u32 total;
-    block_exclusive_scan_256(s, lds, &total);
+    wave_exclusive_scan(s, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
-__global__ void __launch_bounds__(256) k_scan_of_sums(u32 *block_sums, u32 nblocks) {  // single workgroup, in place
-    __shared__ u32 lds[256];
+__global__ void __launch_bounds__(64) k_scan_of_sums(u32 *block_sums, u32 nblocks) {  // single workgroup, in place; eight sums per lane per trip
     u32 carry = 0;
-    for (u32 base = 0; base < nblocks; base += 256) {
-        u32 i = base + threadIdx.x;
-        u32 v = i < nblocks ? block_sums[i] : 0, total;
-        u32 ex = block_exclusive_scan_256(v, lds, &total);
-        if (i < nblocks) block_sums[i] = carry + ex;
+    for (u32 base = 0; base < nblocks; base += 8 * 64) {
+        const u32 i0 = base + threadIdx.x * 8;
+        u32 v[8], mine = 0;
+        for (u32 k = 0; k < 8; k++) { v[k] = i0 + k < nblocks ? block_sums[i0 + k] : 0; mine += v[k]; }
+        u32 total;
+        u32 ex = carry + wave_exclusive_scan(mine, &total);
+        for (u32 k = 0; k < 8; k++) { if (i0 + k < nblocks) block_sums[i0 + k] = ex; ex += v[k]; }
         carry += total;
     }
     if (threadIdx.x == 0) block_sums[nblocks] = carry;
 }
 // mode 0: block_sums holds the exclusive scan of the block sums (+ the total at [gridDim.x]) -- after k_scan_of_sums
 // mode 1: a single block: no block sums at all
-// mode 2: block_sums holds the raw sums of <= 256 blocks: every workgroup scans them itself (saves the k_scan_of_sums launch)
-__global__ void __launch_bounds__(256) k_scan_final(const u32 *in, size_t m, const u32 *block_sums, u32 *out, int mode) {
-    __shared__ u32 lds[256];
-    __shared__ u32 my_off;
+// mode 2: block_sums holds the raw sums of <= SCAN_MAX_INLINE_BLOCKS blocks: every workgroup scans them itself (saves the k_scan_of_sums launch)
+__global__ void __launch_bounds__(64) k_scan_final(const u32 *in, size_t m, const u32 *block_sums, u32 *out, int mode) {
     u32 offset = 0, grand = 0;
     if (mode == 0) { offset = block_sums[blockIdx.x]; grand = block_sums[gridDim.x]; }
-    if (mode == 2) {
-        u32 v = threadIdx.x < gridDim.x ? block_sums[threadIdx.x] : 0;
-        u32 ex = block_exclusive_scan_256(v, lds, &grand);
-        if (threadIdx.x == blockIdx.x) my_off = ex;
-        __syncthreads();
-        offset = my_off;
+    if (mode == 2) {   // lane t holds the sums of blocks 8 t .. 8 t + 7; this block's offset = sums of the blocks before it
+        const u32 i0 = threadIdx.x * 8;
+        u32 mine = 0, before_in_lane = 0;
+        for (u32 k = 0; k < 8; k++) {
+            const u32 v = i0 + k < gridDim.x ? block_sums[i0 + k] : 0;
+            if (i0 + k < blockIdx.x) before_in_lane += v;
+            mine += v;
+        }
+        const u32 ex = wave_exclusive_scan(mine, &grand);
+        const u32 owner = blockIdx.x >> 3;   // the lane that holds this block's sum
+        offset = (u32)__shfl((int)(ex + before_in_lane), (int)owner);
     }
     size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     u32 v[SCAN_PER_THREAD], s = 0;
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) { v[k] = base + k < m ? in[base + k] : 0; s += v[k]; }
     u32 total;
-    u32 ex = block_exclusive_scan_256(s, lds, &total) + offset;
+    u32 ex = wave_exclusive_scan(s, &total) + offset;
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
         if (base + k < m) out[base + k] = ex;
         ex += v[k];
@@ -290,9 +292,8 @@ __global__ void __launch_bounds__(256) k_scan_final(const u32 *in, size_t m, con
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = grand;
 }
 // prep of the next level fused with the first half of its scan: thread = SCAN_PER_THREAD consecutive keys, as in k_scan_block_sums
-__global__ void __launch_bounds__(256) k_msm_prep_next_sums(u32 nkeys, const u32 *prev_items, const u32 *prev_item_start, u32 L, u32 *start, u32 *cnt,
-                                                            u32 *items, u32 *block_sums) {
-    __shared__ u32 lds[256];
+__global__ void __launch_bounds__(64) k_msm_prep_next_sums(u32 nkeys, const u32 *prev_items, const u32 *prev_item_start, u32 L, u32 *start, u32 *cnt,
+                                                           u32 *items, u32 *block_sums) {
     size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
     u32 s = 0;
     for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
@@ -303,7 +304,7 @@ __global__ void __launch_bounds__(256) k_msm_prep_next_sums(u32 nkeys, const u32
         }
     }
     u32 total;
-    block_exclusive_scan_256(s, lds, &total);
+    wave_exclusive_scan(s, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
 static int32_t exclusive_scan(mi_ctx *ctx, hipStream_t st, const u32 *in, size_t m, u32 *out, DevBuf &tmp) {
@@ -312,14 +313,14 @@ static int32_t exclusive_scan(mi_ctx *ctx, hipStream_t st, const u32 *in, size_t
     MI_TRY(mi_reserve(ctx, tmp, (size_t)(nblocks + 1) * 4));
     u32 *bs = (u32 *)tmp.p;
     if (nblocks == 1) {
-        hipLaunchKernelGGL(k_scan_final, dim3(1), dim3(256), 0, st, in, m, bs, out, 1);
-    } else if (nblocks <= 256) {
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(256), 0, st, in, m, bs);
-        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(256), 0, st, in, m, bs, out, 2);
+        hipLaunchKernelGGL(k_scan_final, dim3(1), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 1);
+    } else if (nblocks <= SCAN_MAX_INLINE_BLOCKS) {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs);
+        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 2);
     } else {
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(256), 0, st, in, m, bs);
-        hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(256), 0, st, bs, nblocks);
-        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(256), 0, st, in, m, bs, out, 0);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs);
+        hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(SCAN_THREADS), 0, st, bs, nblocks);
+        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 0);
     }
     MI_CHECK_HIP(ctx, hipGetLastError());
     return MI_OK;
@@ -518,15 +519,15 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         u64 m_next = (m + L - 1) / L;  // entries of the largest key at the next level
         if (m_next <= 1) break;
         // next level: (start, cnt, items) of the keys that go on, and the exclusive scan of their items
-        if (scan_blocks <= 256) {   // prep fused with the block sums, the scan of the sums fused with the final pass: two launches
+        if (scan_blocks <= SCAN_MAX_INLINE_BLOCKS) {   // prep fused with the block sums, the scan of the sums fused with the final pass: two launches
             MI_TRY(mi_reserve(ctx, sl.buf[B_SCAN], (size_t)(scan_blocks + 1) * 4));
             u32 *bs = (u32 *)sl.buf[B_SCAN].p;
-            hipLaunchKernelGGL(k_msm_prep_next_sums, dim3(scan_blocks), dim3(256), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt,
+            hipLaunchKernelGGL(k_msm_prep_next_sums, dim3(scan_blocks), dim3(SCAN_THREADS), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt,
                                nxt.items, bs);
-            hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, nxt.items, (size_t)nkeys, bs, nxt.item_start, 2);
+            hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_THREADS), 0, st, nxt.items, (size_t)nkeys, bs, nxt.item_start, 2);
             MI_CHECK_HIP(ctx, hipGetLastError());
         } else {
-            hipLaunchKernelGGL(k_msm_prep_next, dim3((nkeys + 255) / 256), dim3(256), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt, nxt.items);
+            hipLaunchKernelGGL(k_msm_prep_next, dim3((nkeys + 63) / 64), dim3(64), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt, nxt.items);
             MI_CHECK_HIP(ctx, hipGetLastError());
             MI_TRY(exclusive_scan(ctx, st, nxt.items, nkeys, nxt.item_start, sl.buf[B_SCAN]));
         }
@@ -641,7 +642,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(exclusive_scan(ctx, st, nchunks, s.ngroups, cstart, sl.buf[B_SCAN]));
     hipLaunchKernelGGL(k_msm2_hist2, dim3(chunks_bound), dim3(1024), s.gsize * 4, st, s, gstart, cstart, part_lo, H2);
-    hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, cstart, H2, total, (u32 *)sl.buf[B_MAX].p);
+    hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 63) / 64), dim3(64), 0, st, s, cstart, H2, total, (u32 *)sl.buf[B_MAX].p);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_TRY(fetch_max_enqueue(ctx, sl, nullptr, s.nkeys));
     MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
@@ -677,7 +678,8 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     LevelArrays A{la, la + stride, la + 2 * stride, la + 3 * stride}, B{la + 4 * stride, la + 5 * stride, la + 6 * stride, la + 7 * stride};
     void *bucket = acc.buf[B_BUCKET].p;
     MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * ops.xyzz_bytes, st));
-    hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, S, L1, A.start, A.cnt, A.items);
+    hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 63) / 64), dim3(64), 0, st,   // single-wave workgroups, like the scans
+                       s, S, L1, A.start, A.cnt, A.items);
     MI_CHECK_HIP(ctx, hipGetLastError());
     if (acc.accum_gate) {   // the caller's condition for the heavy part (prove.hip: computeH first)
         const hipEvent_t g = (*acc.accum_gate)();

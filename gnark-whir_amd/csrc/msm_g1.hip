@@ -72,7 +72,7 @@ static void launch_accum_xyzz29(hipStream_t st, unsigned grid, const void *pin, 
 }
 static void launch_accum_affine29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
                                   const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab, u32 rp_partials, hipEvent_t ev_before) {
-    hipLaunchKernelGGL(k_msm_item_table<Fp>, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
+    hipLaunchKernelGGL(k_msm_item_table<Fp>, dim3(grid < 32768 ? grid : 32768), dim3(64), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
     if (ev_before) (void)hipEventRecord(ev_before, st);
     // rp_partials: bit 0 = partial sums stay in the R' form, bit 1 = the two-waves-per-SIMD build
     if (rp_partials & 2) hipLaunchKernelGGL(k_msm_accum_affine29_w2, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,

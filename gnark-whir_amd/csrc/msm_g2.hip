@@ -159,7 +159,7 @@ static void launch_accum_xyzz_g2_29(hipStream_t st, unsigned grid, const void *p
 static void launch_accum_affine_g2_29(hipStream_t st, unsigned grid, const void *pts, const u32 *sorted, const u32 *start, const u32 *cnt, const u32 *items,
                                       const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab, u32 rp_partials,
                                       hipEvent_t ev_before) {
-    hipLaunchKernelGGL(k_msm_item_table<Fp2>, dim3(grid < 8192 ? grid : 8192), dim3(256), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
+    hipLaunchKernelGGL(k_msm_item_table<Fp2>, dim3(grid < 32768 ? grid : 32768), dim3(64), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
     if (ev_before) (void)hipEventRecord(ev_before, st);
     hipLaunchKernelGGL(k_msm_accum_affine_g2_29, dim3(grid), dim3(64), 0, st, (const G2Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
                        (G2X *)bucket, (G2X *)pout, rp_partials & 1u);
