@@ -50,7 +50,9 @@ if os.path.isdir(G + "r4_pmc_fetch") and os.path.isdir(G + "r4_pmc_write"):
                     "--sharded-msm-log-n 0 --sharded-prove-log-n 0 --n-committed 0` (no commitment: the per-launch averages are those of the proof's own MSMs), N=2^23, final round-4 code (_sources: sha256[:16] of the kernel sources the passes ran on; bench.py withholds "
                     "`traffic` when they differ); KB as rocprofv3 reports them, summed over the counter's dimensions; FETCH_SIZE raw (64-B gathers need no correction; 16-B-per-lane streams need x2)")
     json.dump(out, open("profiles/r04_pmc_bench_traffic.json", "w"), indent=1)
-    for k in ("k_msm_accum_affine29", "k_ntt_pass_wave", "k_msm2_scatter2"):
+    for k in ("k_msm_accum_affine29", "k_ntt_pass_wave", "k_msm2_scatter2_staged"):
+        if k not in out["FETCH_SIZE"]:
+            continue
         print(k, "fetch MB/launch", round(out["FETCH_SIZE"][k]["kb_per_launch"] / 1e3, 1), "write", round(out["WRITE_SIZE"].get(k, {"kb_per_launch": 0})["kb_per_launch"] / 1e3, 1))
 if os.path.isdir(G + "r4_pmc_valu"):
     subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "pmc", db("r4_pmc_valu"), "profiles/r04_pmc_valu_proofs.csv"], stdout=subprocess.DEVNULL)
