@@ -53,6 +53,7 @@ def cpu_baseline(pk_host, W, a, b, c, r, s, ped, log_n, gpu_proof_bytes):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cref
     cref.WAIT_POLICY = None   # keep libgomp's default (spinning) waits for the timed sample: the CPU side at its best
+    cref.NATIVE = True        # ... compiled for THIS machine (-march=native, on the spot); the portable library serves if that fails
     runs = []
     cpu_bytes = None
     for _ in range(2):   # the first call also spins up the OpenMP team; a second one only if the first was short
@@ -70,7 +71,9 @@ def cpu_baseline(pk_host, W, a, b, c, r, s, ped, log_n, gpu_proof_bytes):
     if cpu_bytes != gpu_proof_bytes:
         raise SystemExit("bench.py: GPU proof bytes differ from the oracle's proof bytes on the same inputs")
     dt = min(runs)
-    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": cref.num_threads(), "kind": "port",
+    return {"value": 1.0 / dt, "unit": "proofs/s", "cores": cref.num_threads(),
+            "kind": f"port (the oracle's portable C restatement, 4 x 64-bit CIOS with unsigned __int128, no assembly, no ADX/BMI2 intrinsics; gcc {cref.BUILD_FLAGS}; OpenMP): "
+                    "a stated baseline, slower than gnark-crypto's assembly field arithmetic -- never gnark",
             "sample": f"N=2^{log_n}, measured: the whole benchmarked step itself (Commit + ProveKnowledge + fold over {n_vals} committed values, prove; same pk, W, a, b, c, r, s; "
                       f"best of {len(runs)}: {dt:.2f} s on {cref.num_threads()} threads); proof bytes equal the GPU proof's ({len(cpu_bytes)} B compared)",
             "proof_bytes_match": True, "proof_bytes_compared": len(cpu_bytes)}
@@ -387,7 +390,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)   # ~1 s of proofs: one rare runtime hiccup then moves the result by < 2 %
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=23, help="FFT domain (2^23 = BASELINE configs[1])")
-    ap.add_argument("--dist", choices=["whir", "uniform"], default="whir")
+    ap.add_argument("--dist", choices=["whir", "half", "uniform"], default="whir",
+                    help="witness (W, a) distribution: the WHIR mix of SURVEY 8d (a documented guess), uniform Fr, or half of each (row by row)")
+    ap.add_argument("--no-sensitivity", action="store_true", help="skip the `sensitivity` legs (the same key proved with a half-uniform and a uniform witness)")
+    ap.add_argument("--knobs", default="", help="tuning: name=value,... for mi_debug_set_knob on every context of the pool (include/mi355x_groth16.h lists the names)")
     ap.add_argument("--n-committed", type=int, default=-1,
                     help="private wires under the proof's ONE BSB22 commitment (lookup operands; default 2^18 = N / 32, a documented estimate like the infinity ratios; 0 = a circuit without lookups: 164-byte proofs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -463,6 +469,9 @@ def main():
         assert pool.lib.mi_debug_set_msm_chunk(pool.ctx(i).h, args.msm_chunk) == 0
         assert pool.lib.mi_debug_set_msm_bound_levels(pool.ctx(i).h, 1 if args.bound_levels else 0) == 0
         assert pool.lib.mi_debug_set_prove_schedule(pool.ctx(i).h, 1 if args.hold_accum else 0) == 0
+    for part in [x for x in args.knobs.split(",") if x]:
+        k_, _, v_ = part.partition("=")
+        pool.set_knob(k_.strip(), int(v_))
     if args.ntt_plan:
         np_ = [int(x) for x in args.ntt_plan.split(",")]
         for i in range(pool.in_flight):
@@ -493,7 +502,7 @@ def main():
         committed_wires = np.concatenate([committed_private, np.array([nb_wires - 1], dtype=np.uint32)])   # the last wire plays CommitmentIndex
     na, nb = int((inf_a == 0).sum()), int((inf_b == 0).sum())
     nk = nb_wires - nb_public - (n_committed + 1 if n_committed else 0)
-    dist_id = 1 if args.dist == "whir" else 0
+    dist_id = 0 if args.dist == "uniform" else 1
     g1a, g1b, g1k, g1z = ctx.gen_g1(na, seed + 1), ctx.gen_g1(nb, seed + 2), ctx.gen_g1(nk, seed + 3), ctx.gen_g1(N, seed + 4)
     g2b = ctx.gen_g2(nb, seed + 5)
     small = ctx.gen_g1(3, seed + 6).download((3, 8)); small2 = ctx.gen_g2(2, seed + 7).download((2, 16))
@@ -517,10 +526,22 @@ def main():
             if want_cpu:
                 key_host[name] = d.download((cnt, k))
             d.free()
-    W = ctx.gen_scalars(nb_wires, seed + 8, dist_id)
-    a = ctx.gen_scalars(n_constraints, seed + 9, dist_id); b = ctx.gen_scalars(n_constraints, seed + 10, 0)
-    c = ctx.alloc(32 * n_constraints)
-    ctx.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)   # c = a*b so that (a, b, c) is a satisfied R1CS row set
+    def gen_witness(dist):
+        """W, a (the distribution under test), b (uniform), c = a o b on the device; 'half': every other row of W and a by a seeded coin uniform"""
+        did = 0 if dist == "uniform" else 1
+        W_ = ctx.gen_scalars(nb_wires, seed + 8, did); a_ = ctx.gen_scalars(n_constraints, seed + 9, did)
+        if dist == "half":
+            for arr, cnt, sd in ((W_, nb_wires, 8), (a_, n_constraints, 9)):
+                u = ctx.gen_scalars(cnt, seed + sd, 0)
+                hm, hu = arr.download((cnt, 4)), u.download((cnt, 4)); u.free()
+                coin = np.random.default_rng(seed + 100 + sd).integers(0, 2, cnt).astype(bool)
+                hm[coin] = hu[coin]
+                arr.upload(hm)
+        b_ = ctx.gen_scalars(n_constraints, seed + 10, 0)
+        c_ = ctx.alloc(32 * n_constraints)
+        ctx.field_op_dev(0, 2, c_.ptr, a_.ptr, b_.ptr, n_constraints)   # c = a*b so that (a, b, c) is a satisfied R1CS row set
+        return W_, a_, b_, c_
+    W, a, b, c = gen_witness(args.dist)
     rs = ctx.gen_scalars(3, seed + 11, 0).download((3, 4))       # r, s and the PoK fold challenge (gnark: fr.Hash of the commitment wire values, "G16-BSB22" -- Go's part)
     ctx.sync()
     # what the caller holds: host memory (the solver's output)
@@ -634,6 +655,58 @@ def main():
             if B.proof_write(raw) != body_bytes:
                 raise SystemExit("bench.py: a device-input proof differs from the reference proof of the same inputs")
         dev_rate, dev_ms = args.steps * world / dtd, dtd / args.steps * 1e3
+
+    # `sensitivity`: the headline rests on ONE guessed input, the witness distribution ("a documented guess").  The same key, the
+    # same step, proved with half of the rows of W and a uniform and with all of them uniform (the floor: ~14 non-zero digits per wire
+    # scalar instead of ~4): proofs/s on the caller's path, with the inputs in HBM, one proof alone, G1 level-1 additions per proof.
+    # Rank 0 of a one-GPU run only; every proof of a leg is compared with that leg's own untimed reference proof.
+    def sensitivity_leg(dist):
+        W2, a2, b2, c2 = gen_witness(dist)
+        ctx.sync()
+        W2h, a2h, b2h = W2.download((nb_wires, 4)), a2.download((n_constraints, 4)), b2.download((n_constraints, 4))
+        vals2 = np.ascontiguousarray(W2h[committed_private]) if n_committed else None
+        lat = None
+        for _ in range(2):
+            t1 = time.perf_counter()
+            pr, st1 = ctx.prove(pkh, W2.ptr, a2.ptr, b2.ptr, c2.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
+            lat = (time.perf_counter() - t1) * 1e3
+        body2 = B.proof_write(pr["raw"])
+        ref2 = body2
+        if n_committed:
+            cm0 = ctx.pedersen_commit(ped, vals2)
+            pok0 = B.pedersen_fold(ctx.pedersen_commit(ped, vals2, knowledge=True).reshape(1, 8), rs[2])
+            ref2 = B.proof_write(pr["raw"], cm0.reshape(1, 8), pok0)
+
+        def step2():
+            if not n_committed:
+                proof, st = pool.wait(pool.submit(pkh, W2h, a2h, b2h, None, rs[0], rs[1]))
+                return B.proof_write(proof["raw"]), st
+            cm = pool.commit(ped, vals2)
+            proof, st = pool.wait(pool.submit_bsb22(pkh, W2h, a2h, b2h, None, rs[0], rs[1], [(ped, vals2)], rs[2]))
+            return B.proof_write(proof["raw"], cm.reshape(1, 8), proof["pok"]), st
+        list(ex.map(lambda _: step2(), range(max(args.warmup, callers))))
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        got = list(ex.map(lambda _: step2(), range(args.steps)))
+        torch.cuda.synchronize(); rate = args.steps / (time.perf_counter() - t1)
+        if any(bts != ref2 for bts, _ in got):
+            raise SystemExit(f"bench.py: a proof of the `{dist}` sensitivity leg differs from its reference proof")
+        sub2 = lambda: pool.submit(pkh, W2.ptr, a2.ptr, b2.ptr, c2.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
+        for t in [sub2() for _ in range(args.warmup)]:
+            pool.wait(t)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        raws = [pool.wait(t)[0]["raw"] for t in [sub2() for _ in range(args.steps)]]
+        torch.cuda.synchronize(); rate_dev = args.steps / (time.perf_counter() - t1)
+        if any(B.proof_write(raw) != body2 for raw in raws):
+            raise SystemExit(f"bench.py: an HBM-resident proof of the `{dist}` sensitivity leg differs from its reference proof")
+        for d in (W2, a2, b2, c2):
+            d.free()
+        return {"value": rate, "value_hbm_resident_inputs": rate_dev, "single_proof_latency_ms": lat, "g1_level1_additions_per_proof": int(st1["g1_accum_entries"]),
+                "proofs_validated": 2 * args.steps}
+    sensitivity = None
+    if rank == 0 and world == 1 and not args.no_sensitivity and args.dist == "whir":
+        sensitivity = {"what": "the same key and step with other witness distributions (rows of W and a): `whir` = the headline's 45 % {0,1} / 25 % bytes / 5 % 64-bit / 25 % "
+                               "uniform mix, `half_uniform` = every row uniform with probability 1/2, `uniform` = every row uniform (the floor)",
+                       "half_uniform": sensitivity_leg("half"), "uniform": sensitivity_leg("uniform")}
     ex.shutdown()
 
     # HBM ledger of the PROVE path, taken right after the timed regions: key + tables, every context's workspaces, the pool's input sets,
@@ -660,6 +733,34 @@ def main():
         solo = {"pairs": n_constraints, "scalars": "uniform", "msm_total_ms": st["total_ms"], "accum_launch_ms": st["g1_accum_kernel_ms"],
                 "accum_GBps_algorithmic": 96.0 * n_constraints / (st["g1_accum_kernel_ms"] * 1e-3) / 1e9,
                 "mixed_adds_per_s": st["g1_accum_entries"] / (st["g1_accum_kernel_ms"] * 1e-3), "msm_pts_per_s": n_constraints / (st["total_ms"] * 1e-3)}
+    # ... and the launch the roofline line is quoted on: the proof's LARGEST level-1 launch -- the Z MSM's (N - 1 uniform scalars against the
+    # key's fixed-base window tables, here rebuilt through the public entry points with the key's own window width) -- ALONE on the GPU.
+    # A solo launch is a basis a better schedule cannot lower: inside the job the same launch shares the CUs with whatever runs beside it,
+    # and the more evenly it shares the longer it takes (rounds 1-4 quoted that in-job duration; it stays in the line as `in_job`).
+    zsolo = None
+    if rank == 0:
+        try:
+            cz = ctx.pk_table_plan(pkh)[2]
+            n_z = N - 1
+            nwin_z = (256 + cz - 1) // cz if cz else 0
+            free_b = torch.cuda.mem_get_info()[0]
+            if cz and free_b > 1.3 * nwin_z * n_z * 64:
+                tab = ctx.msm_precompute(g1z.ptr, n_z, cz)
+                ctx.msm_table_to_rprime(tab.ptr, nwin_z * n_z)
+                hsc = ctx.gen_scalars(n_z, seed + 21, 0)
+                ctx.msm_fixed_dev(tab.ptr, hsc.ptr, n_z, cz, flags=2)   # sizes the workspaces
+                best = None
+                for _ in range(3):
+                    ctx.msm_fixed_dev(tab.ptr, hsc.ptr, n_z, cz, flags=2)
+                    st = ctx.stats()
+                    if best is None or st["g1_accum_kernel_ms"] < best["g1_accum_kernel_ms"]:
+                        best = st
+                tab.free(); hsc.free()
+                zsolo = {"pairs": n_z, "scalars": "uniform", "window_bits": cz, "windows": nwin_z, "msm_total_ms": best["total_ms"], "accum_launch_ms": best["g1_accum_kernel_ms"],
+                         "accum_GBps_algorithmic": 96.0 * n_z / (best["g1_accum_kernel_ms"] * 1e-3) / 1e9, "mixed_adds": int(best["g1_accum_entries"]),
+                         "mixed_adds_per_s": best["g1_accum_entries"] / (best["g1_accum_kernel_ms"] * 1e-3), "msm_pts_per_s": n_z / (best["total_ms"] * 1e-3)}
+        except B.MiError as e:
+            zsolo = {"error": str(e)}
     # computeH alone on the GPU (6 transforms of size N, the pointwise steps fused into the last one's edges): the NTT's own roofline line
     ntt_solo = None
     if rank == 0:
@@ -712,8 +813,8 @@ def main():
         # plans) AND those sources are unchanged: a file older than the kernels reads as traffic: null, never as stale bytes.  The
         # accumulate kernel gathers 64-B points, so its FETCH_SIZE is taken raw; the NTT passes stream 16 B per lane, so theirs gets
         # the guide's x2 correction.
-        traffic = traffic_ntt = None
-        pmc_file = os.path.join("profiles", "r04_pmc_bench_traffic.json")
+        traffic = traffic_ntt = traffic_solo = None
+        pmc_file = os.path.join("profiles", "r05_pmc_bench_traffic.json")
         pmc_src = f"{pmc_file} (committed PMC passes of this workload, not this run; file sha256 {_sha16(os.path.join(ROOT, pmc_file))})"
         csrc = os.path.join(ROOT, "gnark-whir_amd", "csrc")
         if log_n == 23 and args.dist == "whir" and not (args.msm_plan or args.fixed_base or args.ntt_plan or args.msm_group_bits or args.msm_chunk):
@@ -725,6 +826,8 @@ def main():
                 kname = "k_msm_accum_affine29"
                 if fresh_msm:
                     traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
+                    if "solo_z" in pmc:   # the same two counters over the solo Z-shaped launch (tools/solo_z_msm.py under --pmc)
+                        traffic_solo = (pmc["solo_z"]["FETCH_SIZE_kb"] + pmc["solo_z"]["WRITE_SIZE_kb"]) * 1024.0
                 else:
                     pmc_src += "; STALE for the MSM kernels (their sources changed since the passes): traffic withheld"
                 if fresh_ntt:
@@ -750,6 +853,21 @@ def main():
             census_src = f"profiles/r04_isa_census_accum_affine29.json: {cen['valu_per_addition']} vector instructions per mixed addition ({cen['mad_u64_u32_per_addition']} v_mad_u64_u32) = {cen['cycles_per_addition']:.0f} cycles per wave-addition"
         except Exception:
             pass
+        # roofline of the dominant kernel: achieved = the algorithmic 96 B per pair of ONE launch / that launch's duration.
+        # Basis: the Z-shaped launch alone on the GPU (zsolo above) when it ran; the job's average in-job launch otherwise (and always as `in_job`).
+        in_job = {"launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes, "achieved": achieved, "frac": achieved / 8000.0,
+                  "note": "average over the proofs' four G1 level-1 launches while three proofs share the GPU (HIP events on the launch's stream): what rounds 1-4 reported as "
+                          "`achieved`; it falls when the launch shares the CUs more evenly with the other streams, i.e. when the job gets FASTER"}
+        if zsolo and "accum_launch_ms" in zsolo:
+            roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm",
+                        "basis": f"solo launch: the proof's largest level-1 launch (Z MSM: {zsolo['pairs']} uniform scalars, {zsolo['windows']} windows of {zsolo['window_bits']} bits, fixed-base tables) alone on the GPU",
+                        "achieved": zsolo["accum_GBps_algorithmic"], "peak": 8000.0, "unit": "GB/s", "frac": zsolo["accum_GBps_algorithmic"] / 8000.0,
+                        "traffic": traffic_solo, "traffic_source": pmc_src, "launch_ms": zsolo["accum_launch_ms"], "algorithmic_bytes_per_launch": 96.0 * zsolo["pairs"],
+                        "in_job": dict(in_job, traffic=traffic)}
+        else:
+            roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm", "basis": "in-job average launch (the solo Z-shaped launch did not run)",
+                        "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": pmc_src,
+                        "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes, "in_job": in_job}
         line = {
             "metric": "Groth16 proofs/sec for WHIR-verifier circuit (2^20 poly); G1 MSM pts/sec",
             "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -786,10 +904,7 @@ def main():
             # inside a proof the five MSMs overlap on five streams, so per-MSM spans there are not rates
             "g1_msm_pts_per_s": solo["msm_pts_per_s"], "g1_pairs_per_proof": g1_pairs_per_proof,
             "phase_ms": {k: last[k] for k in ("compute_h_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "msm_k_ms", "msm_z_ms", "assemble_ms", "total_ms")},
-            "roofline": {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "traffic_source": pmc_src,
-                         "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes},
+            "roofline": roofline,
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
             # time = computeH alone on the GPU / its 6 transforms (gnark's 7th, the coset FFT of c, is never needed: DESIGN.md 4)
             "roofline_ntt": {"kernel": "k_ntt_pass_wave + k_ntt_contig_pair + k_ntt_strided_triple + k_ntt_contig_last_sub (all passes of one size-N transform)", "bound": "hbm",
@@ -799,7 +914,9 @@ def main():
                              "compute_h_solo_ms": ntt_solo["compute_h_ms"], "pass_launches_per_compute_h": ntt_solo["pass_launches"],
                              "algorithmic_bytes_per_transform": 64.0 * N},
             # why the HBM fraction is small: the kernel is bound by 256-bit modular products on the VALU (no MFMA form exists)
-            "g1_msm_solo": solo,
+            "g1_msm_solo": solo, "g1_msm_z_shaped_solo": zsolo,
+            # the headline's sensitivity to the witness distribution, and the floor next to the headline
+            "sensitivity": sensitivity, "value_uniform_witness": None if not sensitivity else sensitivity["uniform"]["value"],
             # the level-1 accumulate gathers one 64-B point per mixed addition from tables of 7..16 GB: measured ceiling of the memory
             # system for that access pattern, the kernel's own gather rate alone on the GPU, and the job's aggregate rate
             "random_gather": {"ceiling_gathers_per_s": 256 * 4 * 64 * 4 * 128 / (gather_ms * 1e-3), "ceiling_GBps_useful": 256 * 4 * 64 * 4 * 128 * 64 / (gather_ms * 1e-3) / 1e9,

@@ -21,11 +21,11 @@ EXPORTS = [
     "mi_g2_compress", "mi_proof_write", "mi_g1_sum", "mi_g2_sum", "mi_gen_scalars_dev", "mi_gen_g1_dev",
     "mi_gen_g2_dev", "mi_field_op_dev", "mi_g1_add_dev", "mi_g2_add_dev", "mi_bench_modmul_dev", "mi_bench_valu_dev", "mi_bench_gather_dev",
     "mi_dev_alloc", "mi_dev_free", "mi_dev_upload", "mi_dev_download", "mi_dev_sync",
-    "mi_msm_precompute_g1_dev", "mi_msm_precompute_g2_dev", "mi_msm_g1_fixed_dev", "mi_msm_g2_fixed_dev",
+    "mi_msm_precompute_g1_dev", "mi_msm_precompute_g2_dev", "mi_msm_g1_fixed_dev", "mi_msm_g2_fixed_dev", "mi_msm_table_to_rprime_g1_dev", "mi_msm_table_to_rprime_g2_dev", "mi_pk_table_plan",
     "mi_batch_scalar_mul_g1", "mi_batch_scalar_mul_g1_dev", "mi_batch_scalar_mul_g2", "mi_batch_scalar_mul_g2_dev",
     "mi_pedersen_pk_load", "mi_pedersen_pk_free", "mi_pedersen_commit", "mi_pedersen_prove_knowledge", "mi_pedersen_fold",
     "mi_debug_set_prove_fixed_base", "mi_debug_set_prove_schedule", "mi_debug_set_msm_batch_affine", "mi_debug_set_msm_group_bits", "mi_debug_inject_hip_failure", "mi_debug_set_ntt_plan", "mi_debug_set_ntt_threads", "mi_debug_set_ntt_wave_stages",
-    "mi_debug_set_msm_plan", "mi_debug_set_msm_chunk", "mi_debug_set_msm_one_pass_sort", "mi_debug_set_msm_bound_levels", "mi_debug_set_msm_limb29", "mi_debug_set_msm_l1_waves", "mi_debug_set_msm_precompute_batched", "mi_debug_set_ntt_fuse_pair",
+    "mi_debug_set_msm_plan", "mi_debug_set_msm_chunk", "mi_debug_set_msm_one_pass_sort", "mi_debug_set_msm_bound_levels", "mi_debug_set_msm_limb29", "mi_debug_set_msm_l1_waves", "mi_debug_set_msm_precompute_batched", "mi_debug_set_ntt_fuse_pair", "mi_debug_set_knob",
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
     "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22", "mi_prover_trim", "mi_ctx_trim",
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_create_rank_ex", "mi_group_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
@@ -172,6 +172,10 @@ class Context:
     def sync(self):
         self._ck(self.lib.mi_dev_sync(self.h))
 
+    def set_knob(self, name, value):
+        """mi_debug_set_knob: a named measurement / test knob of this context (the header lists them)"""
+        self._ck(self.lib.mi_debug_set_knob(self.h, C.c_char_p(name.encode()), C.c_int64(int(value))))
+
     def alloc(self, nbytes):
         return DevArray(self, nbytes)
 
@@ -265,6 +269,15 @@ class Context:
         f = self.lib.mi_msm_precompute_g2_dev if g2 else self.lib.mi_msm_precompute_g1_dev
         self._ck(f(self.h, _p(base_ptr), C.c_size_t(n), C.c_uint32(c), _p(pre.ptr)))
         return pre
+
+    def msm_table_to_rprime(self, pre_ptr, n_points, g2=False):
+        f = self.lib.mi_msm_table_to_rprime_g2_dev if g2 else self.lib.mi_msm_table_to_rprime_g1_dev
+        self._ck(f(self.h, _p(pre_ptr), C.c_size_t(n_points)))
+
+    def pk_table_plan(self, pkh):
+        c = (C.c_uint32 * 3)()
+        self._ck(self.lib.mi_pk_table_plan(pkh, c))
+        return tuple(int(x) for x in c)
 
     def msm_fixed_dev(self, pre_ptr, sc_ptr, n, c, flags=0, g2=False):
         out = np.zeros(24 if g2 else 12, np.uint64)
@@ -382,6 +395,11 @@ class Prover:
         if not p:
             raise MiError("mi_prover_ctx: index out of range")
         return Context(_borrowed=p)
+
+    def set_knob(self, name, value):
+        """the knob on every proving context of the pool (call while the pool is idle)"""
+        for i in range(self.in_flight):
+            self.ctx(i).set_knob(name, value)
 
     def submit(self, pkh, W, a, b, c, r, s, device=False, n_wires=None, n_constraints=None) -> int:
         out = np.zeros(32, np.uint64); st = Stats(); t = C.c_uint64()

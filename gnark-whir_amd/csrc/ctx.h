@@ -16,6 +16,8 @@ struct DevBuf {             // growable device scratch owned by the ctx (no hipM
 #define MI_MSM_SLOTS 6
 struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, workspaces, pinned result
     hipStream_t stream = nullptr;
+    hipStream_t l1_stream = nullptr;   // knob "l1_stream": the level-1 accumulate launch alone runs here (lowest priority), between two events
+    hipEvent_t ev_l1[2]{};
     hipEvent_t ev[7]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job, 5: bucket sums ready (deferred reduce),
                             // 6: the largest bucket's size has landed in host memory (exact level count, msm.hip)
     bool max_pending = false;       // this slot's sort has a "largest bucket" word on its way to the host (ev[6])
@@ -49,7 +51,7 @@ struct mi_ctx {
     hipEvent_t ev[24]{};
     // scratch
     alignas(16) unsigned char ntt_state[384];  // NttState (ntt.hip): root tables + plan knobs
-    alignas(16) unsigned char msm_knobs[64];   // MsmKnobs (msm.hip)
+    alignas(16) unsigned char msm_knobs[128];   // MsmKnobs (msm.hip)
     DevBuf ws[24];
     MsmSlot msm[MI_MSM_SLOTS];          // MSM / prove workspaces, see msm.hip / prove.hip
     int cu_count = 256;
@@ -121,6 +123,7 @@ int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *sr
 void mi_ntt_state_init(mi_ctx *ctx);
 size_t mi_ntt_table_bytes(mi_ctx *ctx);
 void mi_ntt_state_free(mi_ctx *ctx);
+bool mi_ntt_set_knob(mi_ctx *ctx, const char *name, int64_t value);   // the NTT's share of mi_debug_set_knob: true = name known and value accepted
 void mi_ntt_state_trim(mi_ctx *ctx);   // frees every table and marks them unbuilt (mi_ctx_trim)
 int32_t mi_msm_state_init(mi_ctx *ctx);   // MI_OK or the first failing HIP call; partial state is freed by mi_msm_state_free
 // Stream priority schemes (3 hardware levels; comment in msm.hip).  A context on its own ranks computeH high, the wire MSMs

@@ -32,7 +32,19 @@ struct MsmKnobs {
     u32 gbits = 0;                              // fixed-base sort: log2 buckets per pass-1 group (0 = automatic)
     u32 bound_levels = 0;                       // 1: as many item levels as the worst case needs (windows * n entries in one bucket) instead of
                                                 // as many as the fullest bucket of THIS sort needs (tests compare both)
+    // named knobs of mi_debug_set_knob (the header lists them): measurement switches that used to be environment variables
+    u32 l1_wg = 1;                              // G1 level-1 29-bit kernel: waves per workgroup, 1 / 2 / 4
+    u32 g2_wg = 1;                              // G2 level-1 29-bit kernel: waves per workgroup, 1 / 2 / 4
+    u32 z_waves = 0;                            // 2: the Z MSM's level-1 launch alone on the two-waves-per-SIMD build
+    u32 g1_grid_per_cu = 0, g2_grid_per_cu = 0; // resident-grid cap per CU of the level-1 launches (0 = 128)
+    u32 count_per = 0;                          // fixed-base sort: slices per counting workgroup (0 = 32)
+    u32 plain_scatter = 0;                      // fixed-base sort: 1 = pass 2 by the plain scatter instead of the staged one
+    u32 finisher = 1;                           // 1: item levels whose fullest key holds <= finisher_max partial sums end in ONE launch (k_msm_finish_keys)
+    u32 finisher_max = 0;                       // 0 = automatic
+    u32 l1_stream = 0;                          // 1: the level-1 accumulate launches run on streams of their own at the lowest priority
+    u32 finisher_min_level = 2;                 // the finisher may follow accumulate pass number finisher_min_level + 1 at the earliest
 };
+static_assert(sizeof(MsmKnobs) <= sizeof(mi_ctx::msm_knobs), "mi_ctx::msm_knobs is too small");
 static MsmKnobs *knobs_of(mi_ctx *ctx) { return reinterpret_cast<MsmKnobs *>(ctx->msm_knobs); }
 __global__ void k_msm_hist(MsmShape s, const int16_t *digits, u32 *H);
 __global__ void k_msm_scatter(MsmShape s, const int16_t *digits, const u32 *keystart, const u32 *Hx, u32 *sorted);
@@ -307,6 +319,23 @@ __global__ void __launch_bounds__(64) k_msm_prep_next_sums(u32 nkeys, const u32 
     wave_exclusive_scan(s, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
+// The finisher's two lists (msm_curve_kernels.cuh k_msm_finish_keys): keys that still hold 2 .. small_max partial sums / more than
+// small_max.  One atomic per wave and list; the order inside a list is whatever the atomics give (the sums do not depend on it).
+// counters[0..1] are zeroed with the bucket array at the start of the accumulate stage.
+__global__ void __launch_bounds__(64) k_msm_finish_list(u32 nkeys, const u32 *items, u32 small_max, u32 *list_small, u32 *list_big, u32 *counters) {
+    const u32 key = blockIdx.x * 64 + threadIdx.x, lane = threadIdx.x;
+    const u32 c = key < nkeys ? items[key] : 0;
+    const bool small = c > 1 && c <= small_max, big = c > small_max;
+    const unsigned long long ms = __ballot(small), mb = __ballot(big), below = (1ull << lane) - 1;
+    u32 base_s = 0, base_b = 0;
+    if (lane == 0) {
+        if (ms) base_s = atomicAdd(&counters[0], (u32)__popcll(ms));
+        if (mb) base_b = atomicAdd(&counters[1], (u32)__popcll(mb));
+    }
+    base_s = (u32)__shfl((int)base_s, 0); base_b = (u32)__shfl((int)base_b, 0);
+    if (small) list_small[base_s + (u32)__popcll(ms & below)] = key;
+    if (big) list_big[base_b + (u32)__popcll(mb & below)] = key;
+}
 static int32_t exclusive_scan(mi_ctx *ctx, hipStream_t st, const u32 *in, size_t m, u32 *out, DevBuf &tmp) {
     u32 nblocks = (u32)((m + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (nblocks == 0) nblocks = 1;
@@ -352,7 +381,6 @@ static MsmShape key_shape(const MsmSlot &sl) {
 
 int32_t mi_msm_state_init(mi_ctx *ctx) {
     new (ctx->msm_knobs) MsmKnobs();
-    if (const char *e = getenv("MI_MSM_BA_ROUNDS")) { const int r = atoi(e); if (r >= 0 && r <= 4) knobs_of(ctx)->ba_rounds = (u32)r; }   // A/B switch
     // the c = 16 histogram / cursor image is 128 KiB of LDS (gfx950 allows 160 KiB per workgroup)
     (void)hipFuncSetAttribute((const void *)k_msm_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_msm_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -372,15 +400,9 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     // The runtime maps streams onto a few hardware queues in creation order, and two streams on one queue run one after the other: the
     // order in which the slots' streams are created decides WHICH two MSMs of a proof share a queue (rocprofv3: with the natural order
-    // K (slot 3) queued behind B2's whole G2 chain (slot 2) and ended a single proof).  MI_MSM_STREAM_ORDER overrides it (experiments).
-    int order[MI_MSM_SLOTS] = {0, 1, 2, 3, 4, 5};
-    if (const char *e = getenv("MI_MSM_STREAM_ORDER")) {
-        int got[MI_MSM_SLOTS], n = 0; bool seen[MI_MSM_SLOTS] = {};
-        for (const char *q = e; *q && n < MI_MSM_SLOTS; q++) if (*q >= '0' && *q < '0' + MI_MSM_SLOTS && !seen[*q - '0']) { seen[*q - '0'] = true; got[n++] = *q - '0'; }
-        if (n == MI_MSM_SLOTS) for (int i = 0; i < n; i++) order[i] = got[i];
-    }
-    for (int k = 0; k < MI_MSM_SLOTS; k++) {
-        const int idx = order[k];
+    // K (slot 3) queued behind B2's whole G2 chain (slot 2) and ended a single proof; every other order measured within 0.3 ms of
+    // this one or worse).
+    for (int idx = 0; idx < MI_MSM_SLOTS; idx++) {
         MsmSlot &sl = ctx->msm[idx];
         int pw = 0, pz = prio_lo;   // wires, Z: MI_PRIO_SOLO, MI_PRIO_POOL_SECOND
         if (ctx->prio_scheme == MI_PRIO_POOL_FIRST) { pw = prio_hi; pz = 0; }
@@ -392,19 +414,14 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     // K (slot 3) runs on B1's stream (slot 1).  With a stream of its own it landed on the hardware queue of B2's stream, behind the whole
     // G2 chain, and a single proof ended with K's accumulation alone on the GPU: rocprofv3 timeline, K's level 1 starting at 27 of 31 ms.
     // Behind B1 -- the shortest of the five MSMs -- one proof is 1.0 ms shorter (30.8 against 31.9 ms) and the job unchanged; behind A
-    // (whose sort K shares) 0.8 ms.  MI_MSM_ALIAS=<slot><slot> picks another pair, MI_MSM_ALIAS=none gives every slot its own stream.
-    {
-        int a = 3, b = 1;
-        if (const char *e = getenv("MI_MSM_ALIAS")) {
-            a = e[0] - '0'; b = e[1] ? e[1] - '0' : -1;
-            if (a < 0 || a >= MI_MSM_SLOTS || b < 0 || b >= MI_MSM_SLOTS || a == b) a = b = -1;
-        }
-        if (a >= 0) {
-            (void)hipStreamDestroy(ctx->msm[a].stream);
-            ctx->msm[a].stream = ctx->msm[b].stream;
-        }
-    }
+    // (whose sort K shares) 0.8 ms.  The two chains are enqueued from two host threads (mi_prove_enqueue_b_msms / _ak_msms) and so
+    // interleave on the one stream: their buffers are disjoint, every wait one of them inserts also holds the other, and the event
+    // pair around K's level-1 launch may bracket a kernel of B1's chain (the stats of slot 3 are then an upper bound).
+    (void)hipStreamDestroy(ctx->msm[3].stream);
+    ctx->msm[3].stream = ctx->msm[1].stream;
     for (auto &sl : ctx->msm) {
+        MI_CHECK_HIP(ctx, hipStreamCreateWithPriority(&sl.l1_stream, hipStreamNonBlocking, prio_lo));
+        for (auto &e : sl.ev_l1) MI_CHECK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : sl.ev) MI_CHECK_HIP(ctx, hipEventCreate(&e));
         MI_CHECK_HIP(ctx, hipHostMalloc(&sl.host_wsum, 128 * 256 + 64));
     }
@@ -414,6 +431,8 @@ void mi_msm_state_free(mi_ctx *ctx) {
     for (int i = 0; i < MI_MSM_SLOTS; i++) for (int j = i + 1; j < MI_MSM_SLOTS; j++) if (ctx->msm[j].stream == ctx->msm[i].stream) ctx->msm[j].stream = nullptr;   // aliases
     for (auto &sl : ctx->msm) {
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
+        if (sl.l1_stream) { (void)hipStreamSynchronize(sl.l1_stream); (void)hipStreamDestroy(sl.l1_stream); }
+        for (auto &e : sl.ev_l1) if (e) (void)hipEventDestroy(e);
         for (auto &e : sl.ev) if (e) (void)hipEventDestroy(e);
         if (sl.host_wsum) (void)hipHostFree(sl.host_wsum);
         for (auto &b : sl.buf) if (b.p) (void)hipFree(b.p);
@@ -477,17 +496,16 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         // Levels that turn out to be (nearly) empty -- the bound is a worst case -- still cost microseconds, not a full dispatch.
         u32 grid = (u32)((items_bound + 63) / 64);
         u32 grid_cap = (u32)ctx->cu_count * 128;
-        {   // experiment switches: resident-grid caps per CU for the level-1 kernels (MI_G1_GRID_PER_CU / MI_G2_GRID_PER_CU)
-            static const int g1cap = getenv("MI_G1_GRID_PER_CU") ? atoi(getenv("MI_G1_GRID_PER_CU")) : 0;
-            static const int g2cap = getenv("MI_G2_GRID_PER_CU") ? atoi(getenv("MI_G2_GRID_PER_CU")) : 0;
-            const int capx = ops.xyzz_bytes == 256 ? g2cap : g1cap;
-            if (level == 0 && capx > 0) grid_cap = (u32)ctx->cu_count * (u32)capx;
+        {   // knobs g1_grid_per_cu / g2_grid_per_cu: resident-grid caps per CU for the level-1 kernels
+            const u32 capx = ops.xyzz_bytes == 256 ? knobs_of(ctx)->g2_grid_per_cu : knobs_of(ctx)->g1_grid_per_cu;
+            if (level == 0 && capx > 0) grid_cap = (u32)ctx->cu_count * capx;
         }
         if (grid > grid_cap) grid = grid_cap;
         if (grid == 0) grid = 1;
         // the timed span (mi_stats.g1_accum_kernel_ms) brackets the accumulate kernel alone: on the 29-bit path the launcher records the
         // opening event AFTER its item-table kernel (0.1 ms alone, up to 0.5 ms waiting for CUs with three proofs in flight)
         const bool rp_path = level == 0 && pts && rprime && ops.accum_affine_rp;
+        hipStream_t lst = st;   // the stream of this level's accumulate launch
         if (time_first && level == 0 && !rp_path) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
         const u32 ba_rounds = knobs_of(ctx)->ba_rounds;
         // batch-affine rounds (msm_ba_g1.cuh) where the buckets hold a few items each (>= 32 entries on average) and the scratch fits
@@ -497,8 +515,6 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
                             mi_try_reserve(sl.buf[B_BA_NODES], (items_bound + 1) * 512) && mi_try_reserve(sl.buf[B_BA_PREFIX], (items_bound + 1) * 256) &&
                             mi_try_reserve(sl.buf[B_BA_TOT], 2 * ba_tot);
         if (use_ba) {
-            static const bool ba_trace = getenv("MI_MSM_BA_TRACE") != nullptr;
-            if (ba_trace) fprintf(stderr, "msm: batch-affine level 1, %u rounds, nkeys %u, items <= %llu\n", ba_rounds, nkeys, (unsigned long long)items_bound);
             MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
             ops.accum_affine_ba(st, (u32)ctx->cu_count * 64, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, final_out, pout, sl.buf[B_ITEMTAB].p,
                                 rp_partials ? 1u : 0u, ba_rounds, items_bound + 1, ba_waves, sl.buf[B_BA_NODES].p, sl.buf[B_BA_PREFIX].p, sl.buf[B_BA_TOT].p,
@@ -507,17 +523,48 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
             MI_TRY(mi_reserve(ctx, sl.buf[B_ITEMTAB], (items_bound + 1) * 16));
             // which build of the G1 level-1 kernel: three waves per SIMD (168 VGPRs: a SIMD's register file is full, and a freed wave slot
             // is too small for any 256-VGPR G2 workgroup, which then waits for the END of this launch) or two (196: one freed slot admits one)
-            static const int z_waves = getenv("MI_G1_Z_WAVES") ? atoi(getenv("MI_G1_Z_WAVES")) : 0;   // experiment: the Z MSM's launch alone
-            const bool two = knobs_of(ctx)->l1_waves == 2 || (z_waves == 2 && &sl == &ctx->msm[4]);
-            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p,
-                                (rp_partials ? 1u : 0u) | (two ? 2u : 0u), time_first ? sl.ev[1] : nullptr);
+            const MsmKnobs *kn = knobs_of(ctx);
+            const bool g2 = ops.xyzz_bytes == 256;
+            const bool two = !g2 && (kn->l1_waves == 2 || (kn->z_waves == 2 && &sl == &ctx->msm[4]));
+            const u32 wg = g2 ? kn->g2_wg : kn->l1_wg, wg_log = wg == 4 ? 2u : wg == 2 ? 1u : 0u;   // waves per workgroup
+            // knob "l1_stream": this one launch on the slot's lowest-priority stream -- the accumulation is what fills the GPU; everything
+            // else (sorts, NTT passes, upper levels, reduces) is dispatched ahead of it whenever a workgroup of it retires
+            if (kn->l1_stream) {
+                MI_CHECK_HIP(ctx, hipEventRecord(sl.ev_l1[0], st));
+                MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.l1_stream, sl.ev_l1[0], 0));
+                lst = sl.l1_stream;
+            }
+            ops.accum_affine_rp(lst, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p,
+                                (rp_partials ? 1u : 0u) | (two ? 2u : 0u) | (wg_log << 2), time_first ? sl.ev[1] : nullptr);
         } else if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else if (rp_partials) ops.accum_xyzz_rp(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         MI_CHECK_HIP(ctx, hipGetLastError());
-        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], st));
+        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], lst));
+        if (lst != st) {
+            MI_CHECK_HIP(ctx, hipEventRecord(sl.ev_l1[1], lst));
+            MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, sl.ev_l1[1], 0));
+        }
         u64 m_next = (m + L - 1) / L;  // entries of the largest key at the next level
         if (m_next <= 1) break;
+        // the finisher: no key holds more than finish_max partial sums -> one list launch + one launch end the machinery (the lists live in
+        // the next level's start / cnt arrays, free from here on; the counters behind the bucket array, zeroed with it)
+        {
+            const MsmKnobs *kn = knobs_of(ctx);
+            const u64 fin_max = kn->finisher_max ? kn->finisher_max : ops.finish_max;
+            if (kn->finisher && ops.finish_keys && m_next <= fin_max && level >= kn->finisher_min_level) {
+                u32 *counters = (u32 *)((char *)final_out + (size_t)nkeys * ops.xyzz_bytes);
+                hipLaunchKernelGGL(k_msm_finish_list, dim3((nkeys + 63) / 64), dim3(64), 0, st, nkeys, cur.items, MSM_FIN_SMALL, nxt.start, nxt.cnt, counters);
+                const u32 T = ops.finish_T;
+                u32 nb_small = (nkeys + T - 1) / T, nb_big = nkeys;
+                const u32 cap_small = (u32)ctx->cu_count * 8, cap_big = (u32)ctx->cu_count * 4;
+                if (nb_small > cap_small) nb_small = cap_small;
+                if (nb_big > cap_big) nb_big = cap_big;
+                ops.finish_keys(st, nb_small, nb_big, pout, nxt.start, nxt.cnt, counters, cur.item_start, cur.items, final_out, rp_partials ? 1u : 0u);
+                MI_CHECK_HIP(ctx, hipGetLastError());
+                break;
+            }
+        }
         // next level: (start, cnt, items) of the keys that go on, and the exclusive scan of their items
         if (scan_blocks <= SCAN_MAX_INLINE_BLOCKS) {   // prep fused with the block sums, the scan of the sums fused with the final pass: two launches
             MI_TRY(mi_reserve(ctx, sl.buf[B_SCAN], (size_t)(scan_blocks + 1) * 4));
@@ -601,8 +648,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     hipStream_t st = sl.stream;
     // slices per counting workgroup: a group's counters leave as ONE segment of per x 4 B (per = 8: 32-B segments, 255 MB written for a
     // 16 MB matrix at N = 2^23 by the PMC counters; 32: whole 128-B lines)
-    static const u32 per_knob = getenv("MI_MSM2_COUNT_PER") ? (u32)atoi(getenv("MI_MSM2_COUNT_PER")) : 32u;
-    u32 per = per_knob >= 1 && per_knob <= 64 ? per_knob : 32u;
+    u32 per = kn->count_per >= 1 && kn->count_per <= 64 ? kn->count_per : 32u;
     while (per > 1 && per * s.ngroups > 8192) per >>= 1;
 #define MI_LAUNCH_COUNT(C) hipLaunchKernelGGL(k_msm2_count<C>, dim3((G + per - 1) / per), dim3(512), 0, st, s, scalars, mont, per, C1)
     MSM2_FOR_C(s.c, MI_LAUNCH_COUNT)
@@ -647,7 +693,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     MI_TRY(fetch_max_enqueue(ctx, sl, nullptr, s.nkeys));
     MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
     // staged (destination-order) scatter where a chunk fits eight entries per thread and two workgroups still share a CU's LDS
-    static const bool plain_scatter = getenv("MI_MSM2_PLAIN_SCATTER") != nullptr;   // A/B switch
+    const bool plain_scatter = kn->plain_scatter != 0;   // (tests and A/Bs: mi_debug_set_knob "plain_scatter")
     const size_t staged_lds = ((size_t)2 * s.gsize + 16 + chunk) * 4 + (size_t)chunk * 2;
     if (!plain_scatter && chunk <= MSM2_STAGE_PER * 1024 && staged_lds <= 80 * 1024)
         hipLaunchKernelGGL(k_msm2_scatter2_staged, dim3(chunks_bound + 8), dim3(1024), staged_lds, st, s, gstart, cstart, keystart, H2, part_lo, part_val, sorted);
@@ -671,13 +717,13 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     hipStream_t st = acc.stream;
     if (&srt != &acc) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, srt.ev[0], 0));
     MI_TRY(mi_reserve(ctx, acc.buf[B_LEVELS], ((size_t)s.nkeys + 1) * 4 * 8));
-    MI_TRY(mi_reserve(ctx, acc.buf[B_BUCKET], (size_t)s.nkeys * ops.xyzz_bytes));
+    MI_TRY(mi_reserve(ctx, acc.buf[B_BUCKET], (size_t)s.nkeys * ops.xyzz_bytes + 64));   // + the finisher's two list counters
     const u32 *S = (const u32 *)srt.buf[B_S].p, *sorted = (const u32 *)srt.buf[B_SORTED].p;
     u32 *la = (u32 *)acc.buf[B_LEVELS].p;
     const size_t stride = (size_t)s.nkeys + 1;
     LevelArrays A{la, la + stride, la + 2 * stride, la + 3 * stride}, B{la + 4 * stride, la + 5 * stride, la + 6 * stride, la + 7 * stride};
     void *bucket = acc.buf[B_BUCKET].p;
-    MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * ops.xyzz_bytes, st));
+    MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * ops.xyzz_bytes + 64, st));
     hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 63) / 64), dim3(64), 0, st,   // single-wave workgroups, like the scans
                        s, S, L1, A.start, A.cnt, A.items);
     MI_CHECK_HIP(ctx, hipGetLastError());
@@ -869,13 +915,23 @@ static int32_t msm_host_entry(mi_ctx *ctx, int curve, const AffT *pts, const mi_
 template <class F, class JacT>
 static int32_t msm_fixed_dev_entry(mi_ctx *ctx, int curve, const void *pre_dev, const void *scalars_dev, size_t n, uint32_t c, uint32_t flags, JacT *out) {
     std::memset(&ctx->stats, 0, sizeof(ctx->stats));
+    const uint32_t rp = (flags & MI_MSM_TABLE_RPRIME) ? MI_MSM_PTS_RPRIME : 0;   // the table was converted by mi_msm_table_to_rprime_*: level 1 in 29-bit limbs
+    flags &= ~MI_MSM_TABLE_RPRIME;
     MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
-    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pre_dev, scalars_dev, n, flags | MI_MSM_EXACT_SIZE, ctx->ev[0], curve == 1, c));
+    MI_TRY(mi_msm_enqueue(ctx, 0, -1, curve, pre_dev, scalars_dev, n, flags | MI_MSM_EXACT_SIZE | rp, ctx->ev[0], curve == 1, c));
     if (n) MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->msm[0].stream));
     XYZZ<F> r;
     MI_TRY(mi_msm_finish(ctx, 0, curve, &r));
     if (n) MI_CHECK_HIP(ctx, hipEventElapsedTime(&ctx->stats.total_ms, ctx->ev[0], ctx->ev[1]));
     xyzz_to_jac_out<F>(r, out);
+    return MI_OK;
+}
+static int32_t table_to_rprime(mi_ctx *ctx, int curve, void *pre_dev, size_t n_points) {
+    if (!ctx || (!pre_dev && n_points)) return MI_EINVAL;
+    if (knobs_of(ctx)->no_rprime) MI_FAIL(ctx, MI_EINVAL, "msm: the 29-bit level-1 kernels are switched off on this context (mi_debug_set_msm_limb29)");
+    mi_msm_ops(curve).to_rprime(ctx->stream, pre_dev, pre_dev, n_points);
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MI_OK;
 }
 
@@ -890,12 +946,14 @@ int32_t mi_msm_precompute_g2_dev(mi_ctx *ctx, const mi_g2_affine *base_dev, size
     MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return MI_OK;
 }
+int32_t mi_msm_table_to_rprime_g1_dev(mi_ctx *ctx, mi_g1_affine *pre_dev, size_t n_points) { return table_to_rprime(ctx, 1, pre_dev, n_points); }
+int32_t mi_msm_table_to_rprime_g2_dev(mi_ctx *ctx, mi_g2_affine *pre_dev, size_t n_points) { return table_to_rprime(ctx, 2, pre_dev, n_points); }
 int32_t mi_msm_g1_fixed_dev(mi_ctx *ctx, const mi_g1_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c, uint32_t flags, mi_g1_jac *out) {
-    if (!ctx || !out || ((!pre_dev || !scalars_dev) && n) || (flags & ~1u)) return MI_EINVAL;
+    if (!ctx || !out || ((!pre_dev || !scalars_dev) && n) || (flags & ~3u)) return MI_EINVAL;
     return msm_fixed_dev_entry<Fp>(ctx, 1, pre_dev, scalars_dev, n, c, flags, out);
 }
 int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c, uint32_t flags, mi_g2_jac *out) {
-    if (!ctx || !out || ((!pre_dev || !scalars_dev) && n) || (flags & ~1u)) return MI_EINVAL;
+    if (!ctx || !out || ((!pre_dev || !scalars_dev) && n) || (flags & ~3u)) return MI_EINVAL;
     return msm_fixed_dev_entry<Fp2>(ctx, 2, pre_dev, scalars_dev, n, c, flags, out);
 }
 int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on) {
@@ -917,6 +975,27 @@ int32_t mi_debug_set_msm_batch_affine(mi_ctx *ctx, uint32_t rounds) {
 int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves) {
     if (!ctx || (waves != 2 && waves != 3)) return MI_EINVAL;
     knobs_of(ctx)->l1_waves = waves;
+    return MI_OK;
+}
+int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return MI_EINVAL;
+    MsmKnobs *k = knobs_of(ctx);
+    const auto is = [name](const char *n) { return std::strcmp(name, n) == 0; };
+    const bool wg_ok = value == 1 || value == 2 || value == 4;
+    if (is("l1_wg") && wg_ok) k->l1_wg = (u32)value;
+    else if (is("g2_wg") && wg_ok) k->g2_wg = (u32)value;
+    else if (is("l1_waves") && (value == 2 || value == 3)) k->l1_waves = (u32)value;
+    else if (is("z_waves") && (value == 0 || value == 2)) k->z_waves = (u32)value;
+    else if (is("g1_grid_per_cu") && value >= 0 && value <= 65536) k->g1_grid_per_cu = (u32)value;
+    else if (is("g2_grid_per_cu") && value >= 0 && value <= 65536) k->g2_grid_per_cu = (u32)value;
+    else if (is("count_per") && value >= 0 && value <= 64) k->count_per = (u32)value;
+    else if (is("plain_scatter") && (value == 0 || value == 1)) k->plain_scatter = (u32)value;
+    else if (is("finisher") && (value == 0 || value == 1)) k->finisher = (u32)value;
+    else if (is("finisher_max") && value >= 0 && value <= (1 << 20)) k->finisher_max = (u32)value;
+    else if (is("l1_stream") && (value == 0 || value == 1)) k->l1_stream = (u32)value;
+    else if (is("finisher_min_level") && value >= 0 && value <= 16) k->finisher_min_level = (u32)value;
+    else if (mi_ntt_set_knob(ctx, name, value)) return MI_OK;
+    else MI_FAIL(ctx, MI_EINVAL, std::string("mi_debug_set_knob: unknown knob or value out of range: ") + name);
     return MI_OK;
 }
 int32_t mi_debug_set_msm_bound_levels(mi_ctx *ctx, uint32_t on) {

@@ -88,6 +88,64 @@ __global__ void __launch_bounds__(256) k_msm_item_table(const u32 *start, const 
         tab[item] = make_uint4(key, b, e, items[key] == 1 ? 1u : 0u);
     }
 }
+// ---- the finisher: ONE launch that ends the item machinery.  When the fullest key is down to <= a few thousand partial sums, every key
+// that still holds more than one is on one of two device-side lists (k_msm_finish_list, msm.hip): keys with <= MSM_FIN_SMALL partial
+// sums are summed by one thread each (the first nb_small workgroups, grid-stride over the small list); the others by one workgroup
+// each: thread t adds the partial sums t, t + T, ... in place, then a tree over the first min(T, count) slots -- through the partial-sum
+// array itself (global memory, workgroup barriers), so the same load / add / store forms serve every representation.  Replaces
+// log_L2(count) more levels of three launches each on the tail of every MSM (the WHIR witness: one bucket of ~2 M entries, 255 of ~8 K).
+// Form: per-thread running sum with load(p) / add(p) / store(p) over the partial-sum representation and to_bucket(b) (standard XYZZ).
+template <class F> struct FinStd {
+    typedef XYZZ<F> Partial;
+    static constexpr int LDS_WORDS_PER_WAVE = 0;
+    XYZZ<F> acc;
+    MI_D explicit FinStd(u32 *) {}
+    MI_D void load(const Partial *p) { acc = *p; }
+    MI_D void add(const Partial *p) { xyzz_add(acc, *p); }
+    MI_D void store(Partial *p) const { *p = acc; }
+    MI_D void to_bucket(XYZZ<F> *b) const { *b = acc; }
+};
+template <class Form, class BucketT, int T, int WPS>
+__global__ void __launch_bounds__(T, WPS) k_msm_finish_keys(typename Form::Partial *partials, const u32 *list_small, const u32 *list_big, const u32 *counters,
+                                                           const u32 *item_start, const u32 *items, u32 nb_small, BucketT *bucket) {
+    __shared__ u32 lds[Form::LDS_WORDS_PER_WAVE ? Form::LDS_WORDS_PER_WAVE * (T / 64) : 1];
+    Form f(&lds[Form::LDS_WORDS_PER_WAVE ? (threadIdx.x >> 6) * Form::LDS_WORDS_PER_WAVE + (threadIdx.x & 63) : 0]);
+    const u32 n_small = counters[0], n_big = counters[1], tid = threadIdx.x;
+    if (blockIdx.x < nb_small) {
+        for (u32 i = blockIdx.x * T + tid; i < n_small; i += nb_small * T) {
+            const u32 key = list_small[i], base = item_start[key], cnt = items[key];
+            f.load(partials + base);
+            for (u32 k = 1; k < cnt; k++) f.add(partials + base + k);
+            f.to_bucket(bucket + key);
+        }
+        return;
+    }
+    for (u32 i = blockIdx.x - nb_small; i < n_big; i += gridDim.x - nb_small) {   // (key, count) are the workgroup's: every barrier below is reached by all
+        const u32 key = list_big[i], base = item_start[key], cnt = items[key];
+        typename Form::Partial *slot = partials + base;
+        u32 w = cnt < (u32)T ? cnt : (u32)T;   // live slots
+        if (tid < w) {
+            f.load(slot + tid);
+            for (u32 k = tid + T; k < cnt; k += T) f.add(slot + k);
+            f.store(slot + tid);
+        }
+        __syncthreads();
+        u32 h = 1;
+        while (h < w) h <<= 1;
+        for (h >>= 1; h > 0; h >>= 1) {
+            if (tid < h && tid + h < w) { f.add(slot + tid + h); f.store(slot + tid); }
+            __syncthreads();
+            w = w < h ? w : h;
+        }
+        if (tid == 0) f.to_bucket(bucket + key);
+    }
+}
+template <class Form, class BucketT, int T, int WPS>
+static void launch_finish_form(hipStream_t st, unsigned nb_small, unsigned nb_big, void *partials, const u32 *list_small, const u32 *list_big, const u32 *counters,
+                               const u32 *item_start, const u32 *items, void *bucket) {
+    hipLaunchKernelGGL((k_msm_finish_keys<Form, BucketT, T, WPS>), dim3(nb_small + nb_big), dim3(T), 0, st, (typename Form::Partial *)partials, list_small, list_big,
+                       counters, item_start, items, nb_small, (BucketT *)bucket);
+}
 // Point-sharded MSM, SURVEY 8e option ii: own[i] += sum_p recv[p * own_len + i] -- the bucket sums the other devices hold for
 // the keys this device owns, added to its own before the bucket reduce.
 template <class F>

@@ -6,6 +6,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+static constexpr uint32_t MSM_FIN_SMALL = 16;   // the finisher: keys with <= this many partial sums are summed by one thread each
 struct MsmCurveOps {
     size_t xyzz_bytes;   // sizeof(XYZZ<F>): 128 (G1) / 256 (G2)
     void (*accum_affine)(hipStream_t st, unsigned grid, const void *pts, const uint32_t *sorted, const uint32_t *start, const uint32_t *cnt,
@@ -42,6 +43,12 @@ struct MsmCurveOps {
                             const uint32_t *items, const uint32_t *item_start, uint32_t nkeys, void *bucket, void *partial_out, void *item_table,
                             uint32_t rp_partials, uint32_t rounds, uint64_t items_bound, uint32_t target_waves, void *nodes, void *prefix, void *totals,
                             void *invs, hipEvent_t ev_before);
+    // The finisher (msm_curve_kernels.cuh k_msm_finish_keys): every key on the two lists (k_msm_finish_list) has its partial sums
+    // partials[item_start[key] .. + items[key]) -- standard XYZZ, or the packed R' form when rp -- summed into bucket[key] (standard).
+    // Workgroups of finish_T threads; a key on the big list may hold at most finish_max partial sums (the chain of its one workgroup).
+    void (*finish_keys)(hipStream_t st, unsigned nb_small, unsigned nb_big, void *partials, const uint32_t *list_small, const uint32_t *list_big,
+                        const uint32_t *counters, const uint32_t *item_start, const uint32_t *items, void *bucket, uint32_t rp);
+    uint32_t finish_T, finish_max;
     // dst[i] = src[i] with both coordinates multiplied by 2^5 mod p: standard Montgomery form -> the R' packed form (dst may be src)
     void (*to_rprime)(hipStream_t st, void *dst, const void *src, size_t n);
 };

@@ -43,12 +43,12 @@ static __device__ __forceinline__ void msm_accum_affine29_body(const G1Aff *pts,
         else partial_out[item] = g1x29_to_std(acc);
     }
 }
-__global__ void __launch_bounds__(64, 3) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
-                                                           G1X *bucket, G1X *partial_out, u32 rp_partials) {
-    msm_accum_affine29_body(pts, sorted, tab, item_start, nkeys, bucket, partial_out, rp_partials);
-}
-__global__ void __launch_bounds__(64, 2) k_msm_accum_affine29_w2(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
-                                                              G1X *bucket, G1X *partial_out, u32 rp_partials) {
+// WG = waves per workgroup (1, 2, 4), WPS = waves per SIMD the registers are budgeted for (3: 168 VGPRs, 2: 196).  A workgroup of four
+// waves takes one slot on each SIMD of a CU and gives all four back together: the multi-wave workgroups of the other streams (sorts,
+// NTT passes, sum trees) then find a CU with room on every SIMD at once instead of waiting for the end of the launch.
+template <int WG, int WPS>
+__global__ void __launch_bounds__(64 * WG, WPS) k_msm_accum_affine29(const G1Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+                                                                    G1X *bucket, G1X *partial_out, u32 rp_partials) {
     msm_accum_affine29_body(pts, sorted, tab, item_start, nkeys, bucket, partial_out, rp_partials);
 }
 // Levels >= 2 of the item machinery over partial sums in the packed R' form: k_msm_accum_xyzz's decomposition, the additions in
@@ -74,11 +74,14 @@ static void launch_accum_affine29(hipStream_t st, unsigned grid, const void *pts
                                   const u32 *item_start, u32 nkeys, u32 L, void *bucket, void *pout, void *item_tab, u32 rp_partials, hipEvent_t ev_before) {
     hipLaunchKernelGGL(k_msm_item_table<Fp>, dim3(grid < 32768 ? grid : 32768), dim3(64), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
     if (ev_before) (void)hipEventRecord(ev_before, st);
-    // rp_partials: bit 0 = partial sums stay in the R' form, bit 1 = the two-waves-per-SIMD build
-    if (rp_partials & 2) hipLaunchKernelGGL(k_msm_accum_affine29_w2, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
-                                            (G1X *)bucket, (G1X *)pout, rp_partials & 1u);
-    else hipLaunchKernelGGL(k_msm_accum_affine29, dim3(grid), dim3(64), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
-                            (G1X *)bucket, (G1X *)pout, rp_partials & 1u);
+    // rp_partials: bit 0 = partial sums stay in the R' form, bit 1 = the two-waves-per-SIMD build, bits 2..3 = log2 of the waves per workgroup
+    const u32 wg_log = (rp_partials >> 2) & 3u, wg = 1u << wg_log;
+    const unsigned g = (grid + wg - 1) / wg;   // `grid` counts waves
+#define MI_L1(WG, WPS) hipLaunchKernelGGL((k_msm_accum_affine29<WG, WPS>), dim3(g), dim3(64 * WG), 0, st, (const G1Aff *)pts, sorted, (const uint4 *)item_tab, \
+                                          item_start, nkeys, (G1X *)bucket, (G1X *)pout, rp_partials & 1u)
+    if (rp_partials & 2) { if (wg == 4) MI_L1(4, 2); else if (wg == 2) MI_L1(2, 2); else MI_L1(1, 2); }
+    else { if (wg == 4) MI_L1(4, 3); else if (wg == 2) MI_L1(2, 3); else MI_L1(1, 3); }
+#undef MI_L1
 }
 // one batch-affine round (msm_ba_g1.cuh)
 template <int R>
@@ -117,6 +120,22 @@ static void launch_accum_affine_ba(hipStream_t st, unsigned grid_cap, const void
     default: hipLaunchKernelGGL(k_ba_finish<4>, dim3(fgrid), dim3(64), 0, st, pts, sorted, tab, item_start, nkeys, (const uint4 *)nodes, bk, po, rpp); break;
     }
 }
+// the finisher over partial sums in the packed R' form (k_msm_accum_xyzz29's additions)
+struct FinG1rp {
+    typedef G1X Partial;
+    static constexpr int LDS_WORDS_PER_WAVE = 0;
+    G1X29 acc;
+    MI_D explicit FinG1rp(u32 *) {}
+    MI_D void load(const Partial *p) { acc = g1x29_load_rp(reinterpret_cast<const u32 *>(p)); }
+    MI_D void add(const Partial *p) { g1x29_add(acc, g1x29_load_rp(reinterpret_cast<const u32 *>(p))); }
+    MI_D void store(Partial *p) const { g1x29_store_rp(acc, reinterpret_cast<u32 *>(p)); }
+    MI_D void to_bucket(G1X *b) const { *b = g1x29_to_std(acc); }
+};
+static void launch_finish_g1(hipStream_t st, unsigned nb_small, unsigned nb_big, void *partials, const u32 *list_small, const u32 *list_big, const u32 *counters,
+                             const u32 *item_start, const u32 *items, void *bucket, u32 rp) {
+    if (rp) launch_finish_form<FinG1rp, G1X, 256, 1>(st, nb_small, nb_big, partials, list_small, list_big, counters, item_start, items, bucket);
+    else launch_finish_form<FinStd<Fp>, G1X, 256, 1>(st, nb_small, nb_big, partials, list_small, list_big, counters, item_start, items, bucket);
+}
 __global__ void k_g1_to_rprime(G1Aff *dst, const G1Aff *src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -128,6 +147,6 @@ static void launch_to_rprime(hipStream_t st, void *dst, const void *src, size_t 
 }
 
 const MsmCurveOps &msm_g1_ops() {
-    static const MsmCurveOps ops = {sizeof(G1X), launch_accum_affine<Fp>, launch_accum_xyzz<Fp>, launch_bucket_reduce<Fp>, SumT<Fp>::value, launch_sum_tree<Fp>, launch_precompute<Fp>, launch_precompute_batched<Fp>, sizeof(Fp), host_combine_windows<Fp>, launch_sum_slices<Fp>, launch_accum_affine29, launch_accum_xyzz29, launch_accum_affine_ba, launch_to_rprime};
+    static const MsmCurveOps ops = {sizeof(G1X), launch_accum_affine<Fp>, launch_accum_xyzz<Fp>, launch_bucket_reduce<Fp>, SumT<Fp>::value, launch_sum_tree<Fp>, launch_precompute<Fp>, launch_precompute_batched<Fp>, sizeof(Fp), host_combine_windows<Fp>, launch_sum_slices<Fp>, launch_accum_affine29, launch_accum_xyzz29, launch_accum_affine_ba, launch_finish_g1, 256, 4096, launch_to_rprime};
     return ops;
 }

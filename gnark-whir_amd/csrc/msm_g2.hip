@@ -101,10 +101,12 @@ static __device__ __forceinline__ void g2x29_store_rp(const LdsAccG2_29 &A, bool
         for (int q = 0; q < 4; q++) d4[4 * comp + q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
     }
 }
-__global__ void __launch_bounds__(64, 2) k_msm_accum_affine_g2_29(const G2Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
-                                                                  G2X *bucket, G2X *partial_out, u32 rp_partials) {
-    __shared__ u32 lds[72 * 64];
-    const LdsAccG2_29 A{&lds[threadIdx.x]};
+// WG = waves per workgroup (each wave has its own 18 KiB accumulator image)
+template <int WG>
+__global__ void __launch_bounds__(64 * WG, 2) k_msm_accum_affine_g2_29(const G2Aff *pts, const u32 *sorted, const uint4 *tab, const u32 *item_start, u32 nkeys,
+                                                                       G2X *bucket, G2X *partial_out, u32 rp_partials) {
+    __shared__ u32 lds[72 * 64 * WG];
+    const LdsAccG2_29 A{&lds[(threadIdx.x >> 6) * (72 * 64) + (threadIdx.x & 63)]};
     const u32 total = item_start[nkeys], stride = gridDim.x * blockDim.x;
     for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride) {
         const uint4 rec = tab[item];
@@ -161,8 +163,40 @@ static void launch_accum_affine_g2_29(hipStream_t st, unsigned grid, const void 
                                       hipEvent_t ev_before) {
     hipLaunchKernelGGL(k_msm_item_table<Fp2>, dim3(grid < 32768 ? grid : 32768), dim3(64), 0, st, start, cnt, items, item_start, nkeys, (uint4 *)item_tab);
     if (ev_before) (void)hipEventRecord(ev_before, st);
-    hipLaunchKernelGGL(k_msm_accum_affine_g2_29, dim3(grid), dim3(64), 0, st, (const G2Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys,
-                       (G2X *)bucket, (G2X *)pout, rp_partials & 1u);
+    // rp_partials: bit 0 = partial sums stay in the R' form, bits 2..3 = log2 of the waves per workgroup (`grid` counts waves)
+    const u32 wg = 1u << ((rp_partials >> 2) & 3u);
+    const unsigned g = (grid + wg - 1) / wg;
+#define MI_L1G2(WG) hipLaunchKernelGGL(k_msm_accum_affine_g2_29<WG>, dim3(g), dim3(64 * WG), 0, st, (const G2Aff *)pts, sorted, (const uint4 *)item_tab, item_start, nkeys, \
+                                       (G2X *)bucket, (G2X *)pout, rp_partials & 1u)
+    if (wg == 4) MI_L1G2(4); else if (wg == 2) MI_L1G2(2); else MI_L1G2(1);
+#undef MI_L1G2
+}
+// the finisher over partial sums in the packed R' form: the running sum in the LDS image of the level kernels (k_msm_accum_xyzz_g2_29)
+struct FinG2rp {
+    typedef G2X Partial;
+    static constexpr int LDS_WORDS_PER_WAVE = 72 * 64;
+    LdsAccG2_29 A;
+    bool inf = true;
+    MI_D explicit FinG2rp(u32 *lane_base) : A{lane_base} {}
+    MI_D void add(const Partial *p) {
+        const u32 *bw = reinterpret_cast<const u32 *>(p);
+        u32 any = 0;
+#pragma unroll
+        for (int i = 32; i < 48; i++) any |= bw[i];   // ZZ = 0 exactly: only the stored infinity
+        g2x29_add(A, inf, [bw](int comp) { return f2_29_unpack(bw + 16 * comp); }, any == 0);
+    }
+    MI_D void load(const Partial *p) { inf = true; add(p); }   // (infinity + b = b: four component copies into the image)
+    MI_D void store(Partial *p) const { g2x29_store_rp(A, inf, p); }
+    MI_D void to_bucket(G2X *b) const {
+        G2X out = G2X::inf();
+        if (!inf) out = G2X{f2_29_to_std(A.ld(0)), f2_29_to_std(A.ld(1)), f2_29_to_std(A.ld(2)), f2_29_to_std(A.ld(3))};
+        *b = out;
+    }
+};
+static void launch_finish_g2(hipStream_t st, unsigned nb_small, unsigned nb_big, void *partials, const u32 *list_small, const u32 *list_big, const u32 *counters,
+                             const u32 *item_start, const u32 *items, void *bucket, u32 rp) {
+    if (rp) launch_finish_form<FinG2rp, G2X, 64, 2>(st, nb_small, nb_big, partials, list_small, list_big, counters, item_start, items, bucket);
+    else launch_finish_form<FinStd<Fp2>, G2X, 64, 2>(st, nb_small, nb_big, partials, list_small, list_big, counters, item_start, items, bucket);
 }
 __global__ void k_g2_to_rprime(G2Aff *dst, const G2Aff *src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,6 +209,6 @@ static void launch_g2_to_rprime(hipStream_t st, void *dst, const void *src, size
 }
 
 const MsmCurveOps &msm_g2_ops() {
-    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, launch_precompute_batched<Fp2>, sizeof(Fp2), host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, launch_accum_xyzz_g2_29, nullptr, launch_g2_to_rprime};
+    static const MsmCurveOps ops = {sizeof(G2X), launch_accum_affine_g2, launch_accum_xyzz<Fp2>, launch_bucket_reduce<Fp2>, SumT<Fp2>::value, launch_sum_tree<Fp2>, launch_precompute<Fp2>, launch_precompute_batched<Fp2>, sizeof(Fp2), host_combine_windows<Fp2>, launch_sum_slices<Fp2>, launch_accum_affine_g2_29, launch_accum_xyzz_g2_29, nullptr, launch_finish_g2, 64, 1024, launch_g2_to_rprime};
     return ops;
 }

@@ -59,13 +59,16 @@ __global__ void k_ntt_contig_last_sub(Fr *A, const Fr *Cin, NttPass pa, NttTable
 void mi_ntt_state_init(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= sizeof(ctx->ntt_state), "NttState lives in ctx->ntt_state");
     new (ctx->ntt_state) NttState();
-    if (const char *e = getenv("MI_NTT_LDS_FLOOR_KB")) state_of(ctx)->lds_floor = (u32)atoi(e) * 1024u;
     (void)hipFuncSetAttribute((const void *)k_ntt_pass, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_pass_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_contig_pair, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+bool mi_ntt_set_knob(mi_ctx *ctx, const char *name, int64_t value) {
+    if (!std::strcmp(name, "ntt_lds_floor_kb") && value >= 0 && value <= 160) { state_of(ctx)->lds_floor = (u32)value * 1024u; return true; }
+    return false;
 }
 void mi_ntt_state_free(mi_ctx *ctx) {
     NttState *st = state_of(ctx);
@@ -535,7 +538,7 @@ static int32_t ntt_run(mi_ctx *ctx, Fr *dst, const Fr *src, u32 n_valid, u32 log
         if (skip & 4) continue;
         u32 tiles = 1u << (log_n - p.log_r - p.log_c);
         size_t lds_bytes = (size_t)32 * ntt_plane_slots(p);
-        if (st->lds_floor > lds_bytes) lds_bytes = st->lds_floor;   // occupancy cap of the pass kernels (experiments: MI_NTT_LDS_FLOOR_KB)
+        if (st->lds_floor > lds_bytes) lds_bytes = st->lds_floor;   // occupancy cap of the pass kernels (mi_debug_set_knob "ntt_lds_floor_kb")
         u32 E = 1u << (p.log_r + p.log_c);
         // one butterfly per thread per stage when the tile allows: 64 KiB of LDS admits two workgroups per CU,
         // so 1024-thread workgroups are what fills the SIMDs (8 waves each) and hides the mad->addc chains

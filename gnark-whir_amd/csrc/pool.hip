@@ -74,7 +74,7 @@ struct mi_prover {
     mi_ctx *commit_ctx = nullptr; // mi_prover_commit: the mid-solve Pedersen commitments of all callers, one at a time
     std::mutex commit_m;
     uint32_t busy = 0;            // workers inside a prove
-    bool early_handover = true;   // a host job goes to a worker once W has arrived (MI_POOL_EARLY_HANDOVER=0: only when W, a, b, c all have)
+    bool early_handover = true;   // a host job goes to a worker once W has arrived (false: only when W, a, b, c all have; measured equal on the job, 2 ms worse on one proof)
     std::string err;
 };
 
@@ -311,7 +311,6 @@ int32_t mi_prover_create(int device_id, uint32_t in_flight, mi_prover **out) {
         return MI_EHIP;
     }
     p->sets.resize(in_flight + 1);
-    if (const char *e = getenv("MI_POOL_EARLY_HANDOVER")) p->early_handover = atoi(e) != 0;
     for (mi_ctx *c : p->ctx) p->workers.emplace_back(worker_main, p, c);
     p->uploader = std::thread(uploader_main, p);
     *out = p;

@@ -208,8 +208,7 @@ struct mi_pedersen_pk {
 static constexpr u32 PEDERSEN_TABLE_C = 17;
 // best effort: without room (or below 2^15 points) the key stays on the generic path
 static void pedersen_build_tables(mi_ctx *ctx, mi_pedersen_pk *pk) {
-    static const bool off = getenv("MI_PEDERSEN_TABLES") && atoi(getenv("MI_PEDERSEN_TABLES")) == 0;   // A/B switch
-    if (off || pk->n < ((size_t)1 << 15) || !mi_msm_limb29_enabled(ctx)) return;
+    if (pk->n < ((size_t)1 << 15) || !mi_msm_limb29_enabled(ctx)) return;
     const u32 c = PEDERSEN_TABLE_C;
     const size_t nwin = (256 + c - 1) / c, bytes = nwin * pk->n * sizeof(G1Aff);
     size_t free_b = 0, total_b = 0;
@@ -331,6 +330,11 @@ int32_t mi_get_mem_ledger(mi_ctx *ctx, const mi_pk *pk, mi_mem_ledger *out) {
         if (i == 0 || i == 1 || i == 14) out->ctx_ntt_vectors += cap; else out->ctx_other += cap;
     }
     for (const auto &sl : ctx->msm) for (const auto &b : sl.buf) out->ctx_msm += b.cap;
+    return MI_OK;
+}
+int32_t mi_pk_table_plan(const mi_pk *pk, uint32_t c_out[3]) {
+    if (!pk || !c_out) return MI_EINVAL;
+    c_out[0] = pk->c_ak; c_out[1] = pk->c_b; c_out[2] = pk->c_z;
     return MI_OK;
 }
 int32_t mi_pk_load(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out) {
@@ -518,15 +522,9 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     // bus: there the accumulations are what fills the GPU meanwhile.
     const bool hold = ctx->hold_accum && !host && (!gate || gate->abc_arrived);
     std::future<int32_t> f_b, f_ak;
-    static const bool helper_threads = !(getenv("MI_PROVE_HELPER_THREADS") && atoi(getenv("MI_PROVE_HELPER_THREADS")) == 0);   // A/B switch
     int32_t rc_inline = MI_OK;
     auto start_wires = [&](hipEvent_t ev_w) {   // ev_w: "W is resident" on some stream, or null when the host already knows it is
         const std::function<hipEvent_t()> *g = hold ? &h_gate : nullptr;
-        if (!helper_threads) {   // the round-2 form: both groups enqueued by this thread, one after the other (no hold: it would wait for itself)
-            rc_inline = mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, false, nullptr);
-            if (rc_inline == MI_OK) rc_inline = mi_prove_enqueue_ak_msms(ctx, pk, W, ev_w, false, nullptr);
-            return;
-        }
         try {
             f_b = std::async(std::launch::async, [=]() -> int32_t { try { return mi_prove_enqueue_b_msms(ctx, pk, W, ev_w, false, g); } catch (...) { return MI_ENOMEM; } });
         } catch (...) {   // no thread to be had: this thread does it (without the hold: it would wait for itself); no exception crosses the C-ABI
@@ -562,12 +560,6 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         if (!host) {
             // inputs already in HBM
             MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
-            static const bool old_order = getenv("MI_PROVE_OLD_ORDER") && atoi(getenv("MI_PROVE_OLD_ORDER")) != 0;   // A/B switch: round 2's flow
-            if (old_order) {
-                MI_TRY(enqueue_h_and_z());
-                MI_TRY(mi_prove_enqueue_b_msms(ctx, pk, W, ev[2], false, nullptr));
-                return mi_prove_enqueue_ak_msms(ctx, pk, W, ev[2], false, nullptr);
-            }
             start_wires(ev[2]);
             return enqueue_h_and_z();
         }

@@ -179,6 +179,12 @@ int32_t mi_msm_g2_dev(mi_ctx *ctx, const mi_g2_affine *pts_dev, const mi_fr *sca
  * result as mi_msm_g1/g2.  mi_pk_load builds such tables for the prove path's large MSMs when they fit. ---- */
 int32_t mi_msm_precompute_g1_dev(mi_ctx *ctx, const mi_g1_affine *base_dev, size_t n, uint32_t c, mi_g1_affine *pre_dev);
 int32_t mi_msm_precompute_g2_dev(mi_ctx *ctx, const mi_g2_affine *base_dev, size_t n, uint32_t c, mi_g2_affine *pre_dev);
+/* In place: the table's coordinates times 2^5 mod p -- the packed R' = 2^261 form the 9 x 29-bit level-1 kernels gather from (what
+ * mi_pk_load keeps its own tables in).  A converted table is passed to mi_msm_g*_fixed_dev with MI_MSM_TABLE_RPRIME; it is no longer a
+ * table of standard Montgomery points.  n_points = ceil(256/c) * n. */
+int32_t mi_msm_table_to_rprime_g1_dev(mi_ctx *ctx, mi_g1_affine *pre_dev, size_t n_points);
+int32_t mi_msm_table_to_rprime_g2_dev(mi_ctx *ctx, mi_g2_affine *pre_dev, size_t n_points);
+#define MI_MSM_TABLE_RPRIME 2u /* flags of mi_msm_g*_fixed_dev: pre_dev went through mi_msm_table_to_rprime_* */
 int32_t mi_msm_g1_fixed_dev(mi_ctx *ctx, const mi_g1_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c,
                             uint32_t flags, mi_g1_jac *out);
 int32_t mi_msm_g2_fixed_dev(mi_ctx *ctx, const mi_g2_affine *pre_dev, const mi_fr *scalars_dev, size_t n, uint32_t c,
@@ -214,6 +220,8 @@ typedef struct mi_mem_ledger {
     uint64_t ctx_other;        /* staging areas for host inputs and the rest */
 } mi_mem_ledger;
 int32_t mi_get_mem_ledger(mi_ctx *ctx, const mi_pk *pk, mi_mem_ledger *out);
+/* window bits of the fixed-base tables the key was loaded with, for the MSM groups A+K, B1+B2, Z (0 = that group runs the generic plan) */
+int32_t mi_pk_table_plan(const mi_pk *pk, uint32_t c_out[3]);
 /* Workspaces only ever grow (no hipMalloc in steady state).  mi_ctx_trim gives them back: every scratch buffer, MSM slot array and NTT
  * table of an IDLE context is freed (streams, events and keys stay); the next call grows what it needs again.  For a service that has
  * proved an N = 2^26 circuit and goes back to 2^23, or before loading a second large key.  mi_prover_trim does the same for every
@@ -502,6 +510,22 @@ int32_t mi_debug_set_msm_batch_affine(mi_ctx *ctx, uint32_t rounds);
 /* on = 1 (default): the fixed-base window tables of mi_pk_load / mi_msm_precompute_* convert to affine with one inversion per 16 points
  * (needs n XYZZ + n coordinates of scratch while building; falls back by itself without room); 0: one inversion per point.  Same tables. */
 int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
+/* Named measurement / test knobs of one context (the switches that are not worth an entry point each; none changes a result).
+ * MI_EINVAL for an unknown name or a value out of range.  The library reads NO environment variable for any of this: the only
+ * variables it looks at are MI_GROUP_TIMEOUT_MS and MI_GROUP_SHM_CHUNK_KB of the device groups (documented at mi_group_create_rank_ex).
+ *   "l1_wg" 1 | 2 | 4        waves per workgroup of the G1 level-1 bucket-accumulate kernel (a workgroup takes one slot on each SIMD of
+ *                            a CU and returns them together, so the other streams' multi-wave workgroups find room)
+ *   "g2_wg" 1 | 2 | 4        the same for the G2 level-1 kernel (each wave has its own 18 KiB LDS accumulator image)
+ *   "l1_waves" 2 | 3         = mi_debug_set_msm_l1_waves
+ *   "z_waves" 0 | 2          2: the Z MSM's level-1 launch alone on the two-waves-per-SIMD build
+ *   "g1_grid_per_cu", "g2_grid_per_cu"   resident-grid cap per CU of the level-1 launches, in waves (0 = 128)
+ *   "count_per" 0..64        fixed-base sort: slices per counting workgroup (0 = 32)
+ *   "plain_scatter" 0 | 1    fixed-base sort: pass 2 by the plain scatter instead of the LDS-staged one
+ *   "finisher" 0 | 1         1 (default): once no bucket holds more than "finisher_max" partial sums the item levels end in ONE launch
+ *                            (k_msm_finish_keys) instead of log_8 more levels of three launches each
+ *   "finisher_max" 0..2^20   0 = automatic (G1 4096, G2 1024)
+ *   "ntt_lds_floor_kb" 0..160   LDS every NTT pass workgroup requests at least (caps the workgroups per CU) */
+int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value);
 /* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
  * running; 0 disarms.  Used to prove that init / load / prove unwind without leaks or crashes. */
 int32_t mi_debug_inject_hip_failure(int32_t nth);

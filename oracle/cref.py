@@ -30,11 +30,32 @@ class PkDesc(C.Structure):
     ]
 
 
+NATIVE = False        # bench.py's cpu_baseline leg sets this before the first call: build and load the -march=native library ON THIS MACHINE
+BUILD_FLAGS = None    # compiler flags of the library that got loaded (reported in bench.py's cpu_baseline.kind)
+PORTABLE_FLAGS = "-O3 -march=x86-64-v2 -fopenmp"   # = oracle/Makefile CFLAGS: the library built in the build container travels to another CPU
+NATIVE_FLAGS = "-O3 -march=native -fopenmp"
+
+
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libgroth16_ref.so")
     if force or not os.path.exists(so):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
+
+
+def build_native():
+    """the same source with -march=native, compiled on the machine that will time it (oracle/Makefile `native`); None when no compiler
+    or no writable place is to be had -- the portable library then serves"""
+    import tempfile
+    for d in (_HERE, tempfile.gettempdir()):
+        so = os.path.join(d, "libgroth16_ref_native.so")
+        try:
+            subprocess.check_call(["gcc"] + NATIVE_FLAGS.split() + ["-fPIC", "-Wno-unused-function", "-shared", "-o", so, os.path.join(_HERE, "groth16_ref.c")],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            return so
+        except Exception:
+            continue
+    return None
 
 
 def lib():
@@ -45,7 +66,10 @@ def lib():
         # bench.py's cpu_baseline leg sets WAIT_POLICY = None: the timed CPU sample keeps libgomp's default (spinning) waits.
         if WAIT_POLICY:
             os.environ.setdefault("OMP_WAIT_POLICY", WAIT_POLICY)
-        _LIB = C.CDLL(build())
+        global BUILD_FLAGS
+        so = build_native() if NATIVE else None
+        BUILD_FLAGS = NATIVE_FLAGS if so else PORTABLE_FLAGS
+        _LIB = C.CDLL(so or build())
         _LIB.ref_proof_write.restype = C.c_size_t
     return _LIB
 

@@ -1,0 +1,131 @@
+"""GPU parity for the round-5 code paths behind mi_debug_set_knob: the level-1 kernels as 1 / 2 / 4-wave workgroups (G1 both builds, G2),
+and the finisher (one launch that ends the item levels) on / off and with small thresholds, in every partial-sum representation --
+all against the oracle, with the inputs that make the levels interesting (a giant bucket, repeated and opposite points, infinities)."""
+import numpy as np
+import pytest
+import pyref as P
+import cref
+from helpers import *
+from gpu_common import load_binding
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    B = load_binding()
+    c = B.Context(0)
+    yield c
+    c.close()
+
+
+def _reset(ctx):
+    for k, v in (("l1_wg", 1), ("g2_wg", 1), ("l1_waves", 3), ("z_waves", 0), ("finisher", 1), ("finisher_max", 0), ("plain_scatter", 0), ("count_per", 0),
+                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0)):
+        ctx.set_knob(k, v)
+    assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
+
+
+def _skewed(n, seed, g2=False):
+    """WHIR-mix scalars with a giant bucket (a third equal 1), repeated points, an opposite pair, infinities"""
+    pts = (cref.gen_g2 if g2 else cref.gen_g1)(n, seed); sc = cref.gen_scalars(n, seed + 1, 1)
+    sc[::3] = fr_arr([1])[0]
+    pts[3] = 0; pts[6] = pts[5]; sc[6] = sc[5]
+    neg = g2_arr([P.g2_neg(g2_pts(pts[7:8])[0])])[0] if g2 else g1_arr([P.g1_neg(g1_pts(pts[7:8])[0])])[0]
+    pts[8] = neg; sc[8] = sc[7]
+    pts[100:200] = pts[99]
+    return pts, sc
+
+
+def test_unknown_knob_is_rejected(ctx):
+    B = load_binding()
+    with pytest.raises(B.MiError):
+        ctx.set_knob("no_such_knob", 1)
+    with pytest.raises(B.MiError):
+        ctx.set_knob("l1_wg", 3)
+
+
+@pytest.mark.parametrize("wg", [1, 2, 4])
+def test_level1_workgroup_sizes_agree_with_oracle(ctx, wg):
+    n = (1 << 17) + 77
+    pts, sc = _skewed(n, 9100)
+    n2 = (1 << 15) + 13
+    p2, s2 = _skewed(n2, 9200, g2=True)
+    want1, want2 = cref.msm_g1(pts, sc), cref.msm_g2(p2, s2)
+    try:
+        for waves in (3, 2):
+            ctx.set_knob("l1_wg", wg); ctx.set_knob("g2_wg", wg); ctx.set_knob("l1_waves", waves)
+            for cap in (0, 3):   # a tiny resident grid: every wave strides over many items
+                ctx.set_knob("g1_grid_per_cu", cap); ctx.set_knob("g2_grid_per_cu", cap)
+                assert np.array_equal(ctx.msm_g1(pts, sc), want1), (wg, waves, cap)
+                assert np.array_equal(ctx.msm_g2(p2, s2), want2), (wg, waves, cap)
+    finally:
+        _reset(ctx)
+
+
+@pytest.mark.parametrize("limb29", [1, 2, 0])
+def test_finisher_on_off_and_thresholds_agree_with_oracle(ctx, limb29):
+    """finisher off = the item levels to the end (round 4's flow); on with the automatic threshold; on with thresholds that put it after
+    level 1, 2, 3 (small item sizes make many levels); partial sums in the R' form (1), the standard form after a 29-bit level 1 (2),
+    and 8 x 32-bit kernels throughout (0); G1 and G2"""
+    n = (1 << 17) + 5
+    pts, sc = _skewed(n, 9300)
+    n2 = (1 << 15) + 7
+    p2, s2 = _skewed(n2, 9400, g2=True)
+    want1, want2 = cref.msm_g1(pts, sc), cref.msm_g2(p2, s2)
+    try:
+        assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, limb29) == 0
+        for plan in ((0, 0, 0, 0, 0), (11, 4, 2, 0, 0), (9, 16, 8, 0, 0)):
+            assert ctx.lib.mi_debug_set_msm_plan(ctx.h, *plan) == 0
+            for fin, fmax in ((0, 0), (1, 0), (1, 17), (1, 300), (1, 1 << 20)):
+                ctx.set_knob("finisher", fin); ctx.set_knob("finisher_max", fmax)
+                assert np.array_equal(ctx.msm_g1(pts, sc), want1), (limb29, plan, fin, fmax)
+                assert np.array_equal(ctx.msm_g2(p2, s2), want2), (limb29, plan, fin, fmax)
+    finally:
+        _reset(ctx)
+
+
+def test_finisher_all_pairs_one_point(ctx):
+    """every pair the same point and scalar: every addition in every level and in the finisher's tree is a doubling (the special case
+    of the R'-form and standard additions), G1 and G2"""
+    n = 1 << 16
+    same = cref.gen_g1(n, 9500); same[:] = same[0]
+    ssc = cref.gen_scalars(n, 9501, 0); ssc[:] = ssc[0]
+    n2 = 1 << 14
+    same2 = cref.gen_g2(n2, 9502); same2[:] = same2[0]
+    want1, want2 = cref.msm_g1(same, ssc), cref.msm_g2(same2, ssc[:n2])
+    try:
+        for plan in ((0, 0, 0, 0, 0), (5, 0, 0, 0, 0)):
+            assert ctx.lib.mi_debug_set_msm_plan(ctx.h, *plan) == 0
+            for fmax in (0, 40, 1 << 20):
+                ctx.set_knob("finisher_max", fmax)
+                assert np.array_equal(ctx.msm_g1(same, ssc), want1), (plan, fmax)
+                assert np.array_equal(ctx.msm_g2(same2, ssc[:n2]), want2), (plan, fmax)
+    finally:
+        _reset(ctx)
+
+
+def test_prove_with_round5_knobs_gives_the_oracle_bytes(ctx):
+    """a whole proof (fixed-base tables and generic plans) under the combinations the benchmark may run with"""
+    B = load_binding()
+    log_n = 15
+    N = 1 << log_n
+    pk = synthetic_pk(log_n, N - 50, 300, 6161, n_committed=9)
+    W = cref.gen_scalars(N - 50, 1, 1); a = cref.gen_scalars(N - 10, 2, 1); b = cref.gen_scalars(N - 10, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    try:
+        for knob in ((0, 0, 0), (17, 18, 17)):
+            assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0
+            pkh = ctx.pk_load(pk)
+            for cfg in ({}, {"l1_wg": 4}, {"l1_wg": 4, "l1_waves": 2, "g2_wg": 2}, {"finisher": 0}, {"finisher_max": 20, "l1_wg": 2, "z_waves": 2},
+                        {"plain_scatter": 1, "count_per": 8}):
+                _reset(ctx)
+                for k, v in cfg.items():
+                    ctx.set_knob(k, v)
+                got, _ = ctx.prove(pkh, W, a, b, c, r, s)
+                assert B.proof_write(got["raw"]) == want, (knob, cfg)
+            ctx.pk_free(pkh)
+    finally:
+        _reset(ctx)
+        assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
