@@ -4,6 +4,7 @@
 #include "curve.cuh"
 #include <cstring>
 
+thread_local std::string *mi_err_sink = nullptr;
 std::atomic<int> mi_fault_countdown{0};
 
 extern "C" {

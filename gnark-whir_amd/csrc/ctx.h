@@ -88,7 +88,12 @@ static inline void mi_set_err(struct mi_ctx *ctx, const std::string &msg);
         if (rc__ != MI_OK) return rc__;                                                               \
     } while (0)
 
+// A helper thread that works on a context beside the thread that owns the call (the prover pool's ProveKnowledge enqueue, pool.hip)
+// records its failures in a string of its own: set for the duration of its work, it replaces ctx->err for THIS thread, so the two
+// threads never write one std::string and each failure reaches the job with the message of the thread that met it.
+extern thread_local std::string *mi_err_sink;
 static inline void mi_set_err(struct mi_ctx *ctx, const std::string &msg) {
+    if (mi_err_sink) { *mi_err_sink = msg; return; }
     std::lock_guard<std::mutex> lk(ctx->err_m);
     ctx->err = msg;
 }

@@ -80,6 +80,8 @@ struct mi_group {
     std::vector<hipEvent_t> ev_x, ev_in, ev_done, ev_h;
     std::vector<DevBuf> recv;      // per local rank: bucket slices received from the other ranks
     std::vector<DevBuf> stage;     // per local rank: small staging area for the all-gathers (transport 1)
+    int timeout_ms = 60000;        // how long a rank waits for its peers without anything completing (MI_GROUP_TIMEOUT_MS; both transports)
+    bool nonblocking = false;      // transport 1, one rank per process: the communicator is non-blocking and every wait on it is a deadline poll
     std::string err;
     bool broken = false;           // a transport call failed half-way: rings / communicator are in an unknown state, every later call is refused
     std::atomic<bool> busy{false};   // calls on one group must not overlap: an entry point that finds it set returns MI_EINVAL (GroupCall)
@@ -96,8 +98,6 @@ struct mi_pk_sharded {
 #define G_FAIL(g, code, msg) do { (g)->err = (msg); return (code); } while (0)
 #define G_HIP(g, call) do { hipError_t e__ = mi_fault_hit() ? hipErrorUnknown : (call); if (e__ != hipSuccess) { (g)->err = std::string(#call) + ": " + hipGetErrorString(e__); \
                             return e__ == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP; } } while (0)
-#define G_NCCL(g, call) do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) { (g)->err = std::string(#call) + ": " + ncclGetErrorString(r__); \
-                             return MI_EHIP; } } while (0)
 #define G_CTX(g, i, expr) do { int32_t rc__ = (expr); if (rc__ != MI_OK) { (g)->err = mi_last_error((g)->ctx[i]); return rc__; } } while (0)
 
 // Entry-point guard: the group's exchange streams, receive buffers and per-rank contexts serve ONE call at a time.  A second call that
@@ -133,7 +133,7 @@ static void shm_pause(unsigned &spins) {
 // unlinks the name, so that nothing outlives the processes whatever way they end.
 static int32_t shm_attach(mi_group *g, const uint8_t id[128]) {
     ShmLink &L = g->shm;
-    if (const char *e = getenv("MI_GROUP_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) L.timeout_ms = v; }
+    L.timeout_ms = g->timeout_ms;
     uint64_t chunk = (uint64_t)1 << 20;
     uint32_t nslot = 4;
     if (const char *e = getenv("MI_GROUP_SHM_CHUNK_KB")) { const long v = atol(e); if (v >= 4 && v <= (1 << 16)) chunk = (uint64_t)v << 10; }
@@ -225,6 +225,51 @@ static int32_t shm_allgather(mi_group *g, const void *local, size_t bytes, void 
     return MI_OK;
 }
 
+// ---------------------------------------------------------------- transport 1 with one rank per process: deadlines
+// The communicator of a per-rank group is NON-BLOCKING (ncclCommInitRankConfig, blocking = 0): no RCCL call may hold this thread for
+// longer than it takes to queue work, and every wait -- for the communicator to come up, for a group of sends / receives to be
+// issued, for the exchange stream to drain -- is a poll of ncclCommGetAsyncError / hipStreamQuery against MI_GROUP_TIMEOUT_MS.  When
+// the deadline passes (a peer's process ended, a link went down) or RCCL reports an asynchronous error, the communicator is ABORTED
+// (ncclCommAbort: its kernels leave the stream), the group is marked broken and the call returns an error: a timeout, not a hang.
+// Single-process groups (ncclCommInitAll) keep blocking communicators: all their ranks live and die with this process.
+static inline bool nccl_ok(ncclResult_t r) { return r == ncclSuccess || r == ncclInProgress; }
+static int32_t nccl_abort_all(mi_group *g, const std::string &msg) {
+    for (auto &c : g->comm) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+    g->broken = true;
+    G_FAIL(g, MI_EHIP, msg);
+}
+// waits until communicator i has left the "in progress" state (the last non-blocking call on it has been carried out)
+static int32_t nccl_settle(mi_group *g, int i, const char *what) {
+    if (!g->nonblocking) return MI_OK;
+    const Deadline dl(g->timeout_ms);
+    unsigned spins = 0;
+    for (;;) {
+        ncclResult_t st = ncclSuccess;
+        const ncclResult_t r = ncclCommGetAsyncError(g->comm[i], &st);
+        if (r != ncclSuccess) return nccl_abort_all(g, std::string("group: ncclCommGetAsyncError failed ") + what + ": " + ncclGetErrorString(r));
+        if (st == ncclSuccess) return MI_OK;
+        if (st != ncclInProgress) return nccl_abort_all(g, std::string("group: RCCL reported an asynchronous error ") + what + ": " + ncclGetErrorString(st));
+        if (dl.passed()) return nccl_abort_all(g, std::string("group: RCCL did not finish ") + what + " (timeout; did a peer's process end?)");
+        shm_pause(spins);
+    }
+}
+// waits for stream s of local rank i to drain, watching the communicator meanwhile
+static int32_t nccl_wait_stream(mi_group *g, int i, hipStream_t s, const char *what) {
+    if (!g->nonblocking) { G_HIP(g, hipStreamSynchronize(s)); return MI_OK; }
+    const Deadline dl(g->timeout_ms);
+    unsigned spins = 0;
+    for (;;) {
+        const hipError_t q = mi_fault_hit() ? hipErrorUnknown : hipStreamQuery(s);
+        if (q == hipSuccess) return MI_OK;
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); return nccl_abort_all(g, std::string("group: the exchange stream failed ") + what + ": " + hipGetErrorString(q)); }
+        ncclResult_t st = ncclSuccess;
+        if (ncclCommGetAsyncError(g->comm[i], &st) != ncclSuccess || (st != ncclSuccess && st != ncclInProgress))
+            return nccl_abort_all(g, std::string("group: RCCL reported an asynchronous error ") + what + ": " + ncclGetErrorString(st));
+        if (dl.passed()) return nccl_abort_all(g, std::string("group: the exchange did not complete ") + what + " (timeout; did a peer's process end?)");
+        shm_pause(spins);
+    }
+}
+
 // ---------------------------------------------------------------- point-to-point batches
 struct Xfer { int src, dst; const void *sp; void *dp; size_t bytes; };   // global ranks; a pointer is meaningful in its owner's process only
 // transport 3: every transfer this process takes part in advances chunk by chunk through ring[src][dst] -- the source copies a chunk
@@ -295,13 +340,38 @@ static int32_t run_xfers_shm(mi_group *g, const std::vector<Xfer> &list, const s
 static int32_t run_xfers_impl(mi_group *g, const std::vector<Xfer> &xs_list, const std::vector<hipStream_t> &xs) {
     if (g->transport == 3) return run_xfers_shm(g, xs_list, xs);
     if (g->transport == 1) {
-        G_NCCL(g, ncclGroupStart());
+        // every ncclGroupStart is closed by its ncclGroupEnd whatever happens in between (an open group would swallow this thread's next
+        // RCCL calls); the first failure is reported after the group has been closed
+        ncclResult_t bad = ncclSuccess;
+        const char *where = "";
+        ncclResult_t r = ncclGroupStart();
+        if (!nccl_ok(r)) { g->err = std::string("ncclGroupStart: ") + ncclGetErrorString(r); return MI_EHIP; }
         for (const Xfer &x : xs_list) {
-            if (!x.bytes) continue;
-            if (g->local(x.src)) { (void)hipSetDevice(g->dev[x.src - g->rank0]); G_NCCL(g, ncclSend(x.sp, x.bytes, ncclUint8, x.dst, g->comm[x.src - g->rank0], xs[x.src - g->rank0])); }
-            if (g->local(x.dst)) { (void)hipSetDevice(g->dev[x.dst - g->rank0]); G_NCCL(g, ncclRecv(x.dp, x.bytes, ncclUint8, x.src, g->comm[x.dst - g->rank0], xs[x.dst - g->rank0])); }
+            if (!x.bytes || bad != ncclSuccess) continue;
+            if (g->local(x.src)) {
+                (void)hipSetDevice(g->dev[x.src - g->rank0]);
+                r = mi_fault_hit() ? ncclInternalError : ncclSend(x.sp, x.bytes, ncclUint8, x.dst, g->comm[x.src - g->rank0], xs[x.src - g->rank0]);
+                if (!nccl_ok(r)) { bad = r; where = "ncclSend"; continue; }
+            }
+            if (g->local(x.dst)) {
+                (void)hipSetDevice(g->dev[x.dst - g->rank0]);
+                r = ncclRecv(x.dp, x.bytes, ncclUint8, x.src, g->comm[x.dst - g->rank0], xs[x.dst - g->rank0]);
+                if (!nccl_ok(r)) { bad = r; where = "ncclRecv"; }
+            }
         }
-        G_NCCL(g, ncclGroupEnd());
+        r = ncclGroupEnd();
+        if (bad == ncclSuccess && !nccl_ok(r)) { bad = r; where = "ncclGroupEnd"; }
+        if (bad != ncclSuccess) {
+            const std::string msg = std::string("group: ") + where + ": " + ncclGetErrorString(bad);
+            if (g->nonblocking) return nccl_abort_all(g, msg);   // part of the batch may be queued: the communicator cannot be used again
+            G_FAIL(g, MI_EHIP, msg);
+        }
+        if (g->nonblocking) {
+            // one rank per process: the batch is issued AND complete (or the group is broken) before anything else is built on it -- a peer
+            // that ended mid-exchange surfaces here, within the deadline, not in some later synchronisation without one
+            MI_TRY(nccl_settle(g, 0, "while issuing an exchange"));
+            MI_TRY(nccl_wait_stream(g, 0, xs[0], "in an exchange"));
+        }
         return MI_OK;
     }
     // same process, no communicator (a device named twice): peer copies on the source's stream, then every stream waits for all.
@@ -340,7 +410,8 @@ static int32_t run_xfers(mi_group *g, const std::vector<Xfer> &xs_list, const st
 // local: n_local x bytes (this process's ranks, in order); all: world x bytes in rank order.  Single process: a copy.  One rank
 // per process: ncclAllGather(ncclUint8) through a staging area (transport 1) or the shared segment (transport 3).
 static int32_t group_allgather(mi_group *g, const void *local, size_t bytes, void *all) {
-    if (g->n_local() == g->world) { std::memcpy(all, local, bytes * (size_t)g->world); return MI_OK; }
+    // (a per-rank RCCL group of ONE rank goes through its communicator all the same: that is how a 1-GPU box runs the polled path)
+    if (g->n_local() == g->world && !g->nonblocking) { std::memcpy(all, local, bytes * (size_t)g->world); return MI_OK; }
     if (g->n_local() != 1) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
     int32_t rc;
     if (g->transport == 3) rc = shm_allgather(g, local, bytes, all);
@@ -351,9 +422,15 @@ static int32_t group_allgather(mi_group *g, const void *local, size_t bytes, voi
         char *st = (char *)g->stage[0].p;
         hipStream_t s = g->xs[0];
         G_HIP(g, hipMemcpyAsync(st, local, bytes, hipMemcpyHostToDevice, s));
-        G_NCCL(g, ncclAllGather(st, st + bytes, bytes, ncclUint8, g->comm[0], s));
+        const ncclResult_t r = mi_fault_hit() ? ncclInternalError : ncclAllGather(st, st + bytes, bytes, ncclUint8, g->comm[0], s);
+        if (!nccl_ok(r)) {
+            const std::string msg = std::string("group: ncclAllGather: ") + ncclGetErrorString(r);
+            if (g->nonblocking) return nccl_abort_all(g, msg);
+            G_FAIL(g, MI_EHIP, msg);
+        }
+        MI_TRY(nccl_settle(g, 0, "while issuing an all-gather"));
         G_HIP(g, hipMemcpyAsync(all, st + bytes, bytes * (size_t)g->world, hipMemcpyDeviceToHost, s));
-        G_HIP(g, hipStreamSynchronize(s));
+        MI_TRY(nccl_wait_stream(g, 0, s, "in an all-gather"));
         return MI_OK;
     }();
     if (rc != MI_OK) g->broken = true;   // some ranks may have got through, others not: nothing collective can follow
@@ -416,7 +493,9 @@ int32_t mi_group_destroy(mi_group *g) {
         (void)hipSetDevice(g->dev[i]);
         if (g->ctx[i]) (void)hipStreamSynchronize(g->ctx[i]->stream);
         if (i < (int)g->xs.size() && g->xs[i]) { (void)hipStreamSynchronize(g->xs[i]); (void)hipStreamDestroy(g->xs[i]); }
-        if (i < (int)g->comm.size() && g->comm[i]) (void)ncclCommDestroy(g->comm[i]);
+        // (a broken group's communicator was aborted where it broke; one that is merely unused is destroyed -- on a non-blocking
+        //  communicator neither call holds this thread)
+        if (i < (int)g->comm.size() && g->comm[i]) (void)(g->broken ? ncclCommAbort(g->comm[i]) : ncclCommDestroy(g->comm[i]));
         for (auto *v : {&g->ev_x, &g->ev_in, &g->ev_done, &g->ev_h}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
         if (i < (int)g->recv.size() && g->recv[i].p) (void)hipFree(g->recv[i].p);
         if (i < (int)g->stage.size() && g->stage[i].p) (void)hipFree(g->stage[i].p);
@@ -475,6 +554,7 @@ int32_t mi_group_create_rank_ex(int device_id, int rank, int world, const uint8_
     mi_group *g = new (std::nothrow) mi_group();
     if (!g) return MI_ENOMEM;
     g->world = world; g->rank0 = rank; g->transport = transport;
+    if (const char *e = getenv("MI_GROUP_TIMEOUT_MS")) { const int v = atoi(e); if (v > 0) g->timeout_ms = v; }
     mi_ctx *c = nullptr;
     int32_t rc = mi_init(device_id, &c);
     if (rc != MI_OK) { delete g; return rc; }
@@ -485,7 +565,12 @@ int32_t mi_group_create_rank_ex(int device_id, int rank, int world, const uint8_
         std::memcpy(&u, id, 128);
         (void)hipSetDevice(device_id);
         g->comm.assign(1, nullptr);
-        if (ncclCommInitRank(&g->comm[0], world, u, rank) != ncclSuccess) { g->comm.clear(); rc = MI_EHIP; }
+        ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+        cfg.blocking = 0;   // (see "transport 1 with one rank per process: deadlines")
+        g->nonblocking = true;
+        const ncclResult_t r = ncclCommInitRankConfig(&g->comm[0], world, u, rank, &cfg);
+        if (!nccl_ok(r) || !g->comm[0]) { g->comm.clear(); g->err = std::string("ncclCommInitRankConfig: ") + ncclGetErrorString(r); rc = MI_EHIP; }
+        else rc = nccl_settle(g, 0, "while the communicator was coming up (every rank of the group must call mi_group_create_rank)");
     }
     if (rc == MI_OK && transport == MI_GROUP_TRANSPORT_HOST) { (void)hipSetDevice(device_id); rc = shm_attach(g, id); }
     if (rc != MI_OK) { mi_group_destroy(g); return rc; }

@@ -33,7 +33,7 @@ struct MsmKnobs {
     u32 bound_levels = 0;                       // 1: as many item levels as the worst case needs (windows * n entries in one bucket) instead of
                                                 // as many as the fullest bucket of THIS sort needs (tests compare both)
     // named knobs of mi_debug_set_knob (the header lists them): measurement switches that used to be environment variables
-    u32 l1_wg = 1;                              // G1 level-1 29-bit kernel: waves per workgroup, 1 / 2 / 4
+    u32 l1_wg = 4;                              // G1 level-1 29-bit kernel: waves per workgroup, 1 / 2 / 4 (4: +0.7..1.2 % proofs/s in 11 of 12 same-box pairs)
     u32 g2_wg = 1;                              // G2 level-1 29-bit kernel: waves per workgroup, 1 / 2 / 4
     u32 z_waves = 0;                            // 2: the Z MSM's level-1 launch alone on the two-waves-per-SIMD build
     u32 g1_grid_per_cu = 0, g2_grid_per_cu = 0; // resident-grid cap per CU of the level-1 launches (0 = 128)

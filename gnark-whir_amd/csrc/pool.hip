@@ -116,12 +116,20 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
         //  the values' pageable copy holds its thread -- neither should delay the proof's own kernels; slot 5 and ws[19] are the PoK's alone)
         bool pok_pending = false;
         std::future<int32_t> f_pok;
+        std::string pok_enq_err;   // the helper's own error sink (ctx.h mi_err_sink): it works on ctx while this thread proves on it
+        if (rc_pok != MI_OK) pok_err = mi_last_error(ctx);   // (of the synchronous ProveKnowledge calls above, before anything else runs on ctx)
         if (nb && rc_pok == MI_OK) {
             mi_pedersen_pk *key = j->bsb[nb - 1].key; const mi_fr *vals = j->bsb[nb - 1].values; const size_t nv = j->bsb[nb - 1].n; const int dev = p->dev;
-            auto enq = [=]() -> int32_t { try { (void)hipSetDevice(dev); return mi_pedersen_pok_enqueue(ctx, key, vals, nv); } catch (...) { return MI_ENOMEM; } };
-            try { f_pok = std::async(std::launch::async, enq); } catch (...) { rc_pok = enq(); pok_pending = rc_pok == MI_OK; }
+            std::string *sink = &pok_enq_err;
+            auto enq = [=]() -> int32_t {
+                mi_err_sink = sink;
+                int32_t r = MI_ENOMEM;
+                try { (void)hipSetDevice(dev); r = mi_pedersen_pok_enqueue(ctx, key, vals, nv); } catch (...) { }
+                mi_err_sink = nullptr;
+                return r;
+            };
+            try { f_pok = std::async(std::launch::async, enq); } catch (...) { rc_pok = enq(); pok_pending = rc_pok == MI_OK; if (rc_pok != MI_OK) pok_err = pok_enq_err; }
         }
-        if (rc_pok != MI_OK) pok_err = mi_last_error(ctx);
         if (j->gated) {
             InputSet &set = p->sets[j->set];
             const std::function<bool(int)> abc = [&](int k) -> bool {   // blocks until k of a, b, c are resident (or their upload has failed)
@@ -143,7 +151,7 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
             rc = mi_groth16_prove_dev(ctx, j->pk, j->W, j->n_wires, j->a, j->b, j->c, j->n_constraints, &j->r, &j->s, j->out, j->stats);
         }
         prove_err = rc != MI_OK ? mi_last_error(ctx) : "";
-        if (f_pok.valid()) { rc_pok = f_pok.get(); pok_pending = rc_pok == MI_OK; if (rc_pok != MI_OK) pok_err = "prover: enqueueing the ProveKnowledge MSM failed"; }
+        if (f_pok.valid()) { rc_pok = f_pok.get(); pok_pending = rc_pok == MI_OK; if (rc_pok != MI_OK) pok_err = "prover: enqueueing the ProveKnowledge MSM failed: " + pok_enq_err; }
         if (pok_pending) {   // collected whatever the proof did: slot 5 must be idle for the next job
             const int32_t r2 = mi_pedersen_pok_collect(ctx, &poks[nb - 1]);
             if (r2 != MI_OK && rc_pok == MI_OK) { rc_pok = r2; pok_err = mi_last_error(ctx); }
@@ -412,7 +420,12 @@ int32_t mi_prover_trim(mi_prover *p) {
     (void)hipSetDevice(p->dev);
     int32_t rc = MI_OK;
     for (mi_ctx *c : p->ctx) { const int32_t r = mi_ctx_trim(c); if (r != MI_OK && rc == MI_OK) rc = r; }
-    if (p->commit_ctx) { const int32_t r = mi_ctx_trim(p->commit_ctx); if (r != MI_OK && rc == MI_OK) rc = r; }
+    if (p->commit_ctx) {   // a commit counts as activity: mi_prover_commit may be called mid-solve from any thread and is not in the idle check above
+        std::unique_lock<std::mutex> lc(p->commit_m, std::try_to_lock);
+        if (!lc.owns_lock()) { std::lock_guard<std::mutex> lk(p->m); p->err = "prover: trim needs an idle pool (a commit is running)"; return MI_EINVAL; }
+        const int32_t r = mi_ctx_trim(p->commit_ctx);
+        if (r != MI_OK && rc == MI_OK) rc = r;
+    }
     (void)hipStreamSynchronize(p->copy_stream);
     for (InputSet &s : p->sets) if (s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
     return rc;

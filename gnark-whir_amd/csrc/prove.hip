@@ -146,7 +146,7 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
         if (rc == MI_OK) rc = group(pk->c_b, &pk->pre_b1, pk->g1_b, 1, &pk->pre_b2, pk->g2_b, 2, pk->n_b);
         if (rc == MI_OK) rc = group(pk->c_ak, &pk->pre_a, pk->a_full, 1, &pk->pre_k, pk->k_full, 1, pk->nb_wires);
     }
-    if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pk upload sync failed"; rc = MI_EHIP; }
+    if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { mi_set_err(ctx, "pk upload sync failed"); rc = MI_EHIP; }
     if (rc != MI_OK) { if (device_points && !adopt) pk->owns_points = false; mi_pk_free(ctx, pk); return rc; }
     // the compact A and K copies are not needed any more when the library owns them; nor are plain bases that have tables
     if (pk->owns_points) { (void)hipFree(pk->g1_a); (void)hipFree(pk->g1_k); pk->g1_a = pk->g1_k = nullptr; }
@@ -176,13 +176,13 @@ int32_t mi_pk_load_range(mi_ctx *ctx, const mi_pk_desc *d, mi_pk **out, bool dev
             if (pk->c_b) { if (pk->pre_b2 && pk->n_b) g2.to_rprime(ctx->stream, pk->pre_b2, pk->pre_b2, nwin_of(pk->c_b) * pk->n_b); }
             else if (r == MI_OK && pk->g2_b && pk->n_b) {
                 if (pk->owns_points) g2.to_rprime(ctx->stream, pk->g2_b, pk->g2_b, pk->n_b);
-                else if (hipMalloc(&pk->b2_copy, pk->n_b * sizeof(G2Aff)) != hipSuccess) { (void)hipGetLastError(); ctx->err = "pk: no room for the converted copy of pk.G2.B"; r = MI_ENOMEM; }
+                else if (hipMalloc(&pk->b2_copy, pk->n_b * sizeof(G2Aff)) != hipSuccess) { (void)hipGetLastError(); mi_set_err(ctx, "pk: no room for the converted copy of pk.G2.B"); r = MI_ENOMEM; }
                 else { g2.to_rprime(ctx->stream, pk->b2_copy, pk->g2_b, pk->n_b); pk->g2_b = pk->b2_copy; }
             }
         }
         if (pk->c_z) in_place(pk->pre_z, nwin_of(pk->c_z) * pk->n_z_msm);
         else if (r == MI_OK) r = own_or_copy(&pk->g1_z, &pk->z_copy, pk->n_z_msm);
-        if (r == MI_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) { ctx->err = "pk: conversion of the G1 arrays failed"; r = MI_EHIP; }
+        if (r == MI_OK && (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)) { mi_set_err(ctx, "pk: conversion of the G1 arrays failed"); r = MI_EHIP; }
         if (r != MI_OK) { if (device_points && !adopt) pk->owns_points = false; mi_pk_free(ctx, pk); return r; }
         pk->rprime = true;
     }
@@ -262,7 +262,7 @@ int32_t mi_pedersen_pk_load(mi_ctx *ctx, const mi_g1_affine *basis, const mi_g1_
     pk->n = n;
     int32_t rc = upload(ctx, &pk->basis, basis, n * 64);
     if (rc == MI_OK) rc = upload(ctx, &pk->basis_exp_sigma, basis_exp_sigma, n * 64);
-    if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "pedersen key upload failed"; rc = MI_EHIP; }
+    if (rc == MI_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { mi_set_err(ctx, "pedersen key upload failed"); rc = MI_EHIP; }
     if (rc != MI_OK) { mi_pedersen_pk_free(ctx, pk); return rc; }
     pedersen_build_tables(ctx, pk);
     *out = pk;
@@ -374,12 +374,14 @@ int32_t mi_prove_enqueue_b_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent
     MI_CHECK_HIP(ctx, hipGetLastError());
     if (pk->pre_b1) {
         gates.arm(1);
-        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, pk->c_b));
+        // (B1 and K are not timed: their chains interleave on one stream, so the event pair around one's level-1 launch may bracket kernels
+        //  of the other; mi_stats.g1_accum_* then cover A and Z, the two launches with a stream of their own)
+        MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->pre_b1, ctx->ws[17].p, pk->n_b, df | rp, nullptr, false, pk->c_b));
         gates.arm(2);
         return mi_msm_enqueue(ctx, 2, 1, 2, pk->pre_b2, nullptr, pk->n_b, df | rp, nullptr, false, pk->c_b);
     }
     gates.arm(1);
-    MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df | rp, nullptr, true, 0, 0, pk->gen_c_b));
+    MI_TRY(mi_msm_enqueue(ctx, 1, -1, 1, pk->g1_b, ctx->ws[17].p, pk->n_b, df | rp, nullptr, false, 0, 0, pk->gen_c_b));
     gates.arm(2);
     return mi_msm_enqueue(ctx, 2, 1, 2, pk->g2_b, nullptr, pk->n_b, df | rp, nullptr, false);
 }
@@ -394,12 +396,12 @@ int32_t mi_prove_enqueue_ak_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEven
         gates.arm(0);
         MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->pre_a, W, pk->nb_wires, df | rp, ev_w, true, pk->c_ak, pk->n_a));
         gates.arm(3);
-        return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, df | rp, nullptr, true, pk->c_ak, pk->n_k);
+        return mi_msm_enqueue(ctx, 3, 0, 1, pk->pre_k, nullptr, pk->nb_wires, df | rp, nullptr, false, pk->c_ak, pk->n_k);   // (not timed: K and B1 share a stream, msm.hip)
     }
     gates.arm(0);
     MI_TRY(mi_msm_enqueue(ctx, 0, -1, 1, pk->a_full, W, pk->nb_wires, df | rp, ev_w, true, 0, pk->n_a, pk->gen_c_ak));
     gates.arm(3);
-    return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, df | rp, nullptr, true, 0, pk->n_k);
+    return mi_msm_enqueue(ctx, 3, 0, 1, pk->k_full, nullptr, pk->nb_wires, df | rp, nullptr, false, 0, pk->n_k);
 }
 // both groups from two helper threads; returns when everything is enqueued
 int32_t mi_prove_enqueue_wire_msms(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, hipEvent_t ev_w, bool defer) {

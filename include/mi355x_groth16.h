@@ -225,7 +225,8 @@ int32_t mi_pk_table_plan(const mi_pk *pk, uint32_t c_out[3]);
 /* Workspaces only ever grow (no hipMalloc in steady state).  mi_ctx_trim gives them back: every scratch buffer, MSM slot array and NTT
  * table of an IDLE context is freed (streams, events and keys stay); the next call grows what it needs again.  For a service that has
  * proved an N = 2^26 circuit and goes back to 2^23, or before loading a second large key.  mi_prover_trim does the same for every
- * context and input set of an idle pool (MI_EINVAL while jobs are queued or running). */
+ * context and input set of an idle pool (MI_EINVAL while jobs are queued or running, or while a mi_prover_commit is in progress: commits
+ * count as activity). */
 int32_t mi_ctx_trim(mi_ctx *ctx);
 
 /* ---- prover pool: several proofs in flight on one device.
@@ -304,7 +305,18 @@ int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t i
 /* the same with the transport named.  MI_GROUP_TRANSPORT_HOST: the processes meet in a POSIX shared-memory segment named after the 128
  * id bytes (any 128 bytes all ranks share; mi_group_unique_id is not needed) and slices travel device -> segment -> device.  For ranks
  * RCCL cannot connect: two processes on ONE device (RCCL refuses two ranks per device; how a 1-GPU box rehearses this flow) or a box
- * without a working RCCL fabric.  Every wait has a deadline (MI_GROUP_TIMEOUT_MS, default 60000): a peer that died is an error. */
+ * without a working RCCL fabric.
+ * THE DEAD-PEER CONTRACT, both transports: with one rank per process no call of this library waits for another rank without a deadline.
+ * MI_GROUP_TIMEOUT_MS (environment, read when the group is created; default 60000) bounds the time a rank waits for its peers while
+ * NOTHING completes -- joining the group, an exchange, an all-gather.  When it passes (a peer's process ended, a link went down), or
+ * when RCCL reports an asynchronous error, the call returns MI_EHIP with a message that says "timeout", the group is broken (every
+ * later call on it returns MI_EHIP at once) and must be destroyed; mi_group_destroy itself does not wait for anybody.
+ *   RCCL transport: the per-rank communicator is non-blocking (ncclCommInitRankConfig, blocking = 0); joining, every group of sends /
+ *     receives and every all-gather is polled with ncclCommGetAsyncError / hipStreamQuery against the deadline, and ncclCommAbort takes
+ *     the communicator's kernels off the stream when it passes.  An exchange has completed on every rank that returns from it.
+ *   host-staged transport: every wait on the shared segment has the deadline, and a rank that gives up poisons the segment so that the
+ *     others stop waiting at once.  MI_GROUP_SHM_CHUNK_KB (default 1024, 4..65536): bytes per ring slot of the segment.
+ * (Single-process groups, mi_group_create, have no peers in other processes: their communicators stay blocking.) */
 #define MI_GROUP_TRANSPORT_RCCL 1
 #define MI_GROUP_TRANSPORT_HOST 3
 int32_t mi_group_create_rank_ex(int device_id, int rank, int world, const uint8_t id[128], int transport, mi_group **out);
@@ -513,8 +525,8 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
 /* Named measurement / test knobs of one context (the switches that are not worth an entry point each; none changes a result).
  * MI_EINVAL for an unknown name or a value out of range.  The library reads NO environment variable for any of this: the only
  * variables it looks at are MI_GROUP_TIMEOUT_MS and MI_GROUP_SHM_CHUNK_KB of the device groups (documented at mi_group_create_rank_ex).
- *   "l1_wg" 1 | 2 | 4        waves per workgroup of the G1 level-1 bucket-accumulate kernel (a workgroup takes one slot on each SIMD of
- *                            a CU and returns them together, so the other streams' multi-wave workgroups find room)
+ *   "l1_wg" 1 | 2 | 4        waves per workgroup of the G1 level-1 bucket-accumulate kernel, default 4 (a workgroup takes one slot on each
+ *                            SIMD of a CU and returns them together, so the other streams' multi-wave workgroups find room)
  *   "g2_wg" 1 | 2 | 4        the same for the G2 level-1 kernel (each wave has its own 18 KiB LDS accumulator image)
  *   "l1_waves" 2 | 3         = mi_debug_set_msm_l1_waves
  *   "z_waves" 0 | 2          2: the Z MSM's level-1 launch alone on the two-waves-per-SIMD build
@@ -524,6 +536,9 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
  *   "finisher" 0 | 1         1 (default): once no bucket holds more than "finisher_max" partial sums the item levels end in ONE launch
  *                            (k_msm_finish_keys) instead of log_8 more levels of three launches each
  *   "finisher_max" 0..2^20   0 = automatic (G1 4096, G2 1024)
+ *   "finisher_min_level" 0..16   the finisher follows accumulate pass number this + 1 at the earliest (default 2: the first two passes
+ *                            are where every ordinary bucket ends; a finisher over 2^19 buckets of 13 partial sums each measured -5 %)
+ *   "l1_stream" 0 | 1        1: the level-1 launches on lowest-priority streams of their own (measured -6 %: DESIGN.md 8)
  *   "ntt_lds_floor_kb" 0..160   LDS every NTT pass workgroup requests at least (caps the workgroups per CU) */
 int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value);
 /* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of

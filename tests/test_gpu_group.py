@@ -20,9 +20,11 @@ def B():
     return load_binding()
 
 
-@pytest.fixture(scope="module", params=[(0,), (0, 0), (0, 0, 0)], ids=["world1-rccl", "world2-samedev", "world3-samedev"])
+@pytest.fixture(scope="module", params=[(0,), "per-rank", (0, 0), (0, 0, 0)], ids=["world1-rccl", "world1-rccl-per-rank", "world2-samedev", "world3-samedev"])
 def grp(B, request):
-    g = B.Group(list(request.param))
+    # "per-rank": mi_group_create_rank with world 1 -- the NON-BLOCKING communicator of the one-rank-per-process flow: joining, every
+    # grouped send / receive and every all-gather polled against MI_GROUP_TIMEOUT_MS (csrc/group.hip), which is what an 8-GPU node runs
+    g = B.Group.rank(0, 0, 1, B.Group.unique_id(), transport=1) if request.param == "per-rank" else B.Group(list(request.param))
     yield g
     g.close()
 
@@ -249,3 +251,50 @@ def test_sharded_prove_at_2p22_two_ranks_automatic_tables(B):
         g.pk_free(spk)
     finally:
         g.close()
+
+
+def test_rccl_per_rank_group_injected_failures_break_or_spare_the_group_but_never_hang(B):
+    """the per-rank RCCL group (non-blocking communicator, world 1): the n-th checked call of a sharded MSM / prove fails for n = 1, 2, ...
+    Every call returns within seconds; a failure outside an exchange leaves the group usable, a failure inside one (ncclSend, the
+    all-gather, the exchange stream) aborts the communicator and every later call is refused until the group is recreated; the
+    recreated group gives the oracle's bytes."""
+    import time
+    n = 30000
+    pts = cref.gen_g1(n, 51); sc = cref.gen_scalars(n, 52, 1)
+    want = cref.msm_g1(pts, sc)
+    fresh = lambda: B.Group.rank(0, 0, 1, B.Group.unique_id(), transport=1)
+    g = fresh()
+    c = g.ctx(0)
+    dp, ds = c.to_dev(pts), c.to_dev(sc)
+    outcomes = set()
+    try:
+        assert np.array_equal(g.msm_dev([dp.ptr], [ds.ptr], [n], n, mode=1), want)
+        for nth in list(range(1, 40)) + [60, 90, 140]:
+            assert g.lib.mi_debug_inject_hip_failure(nth) == 0
+            t0 = time.time()
+            failed = False
+            try:
+                got = g.msm_dev([dp.ptr], [ds.ptr], [n], n, mode=nth & 1)
+            except B.MiError:
+                failed = True
+            g.lib.mi_debug_inject_hip_failure(0)
+            assert time.time() - t0 < 20, f"call {nth} took {time.time() - t0:.1f} s"
+            if not failed:
+                assert np.array_equal(got, want), nth
+                outcomes.add("beyond")
+                continue
+            try:   # usable or broken?
+                again = g.msm_dev([dp.ptr], [ds.ptr], [n], n, mode=1)
+                assert np.array_equal(again, want), nth
+                outcomes.add("spared")
+            except B.MiError as e:
+                assert "destroy the group" in str(e), str(e)
+                outcomes.add("broken")
+                dp.free(); ds.free(); g.close()
+                g = fresh(); c = g.ctx(0)
+                dp, ds = c.to_dev(pts), c.to_dev(sc)
+                assert np.array_equal(g.msm_dev([dp.ptr], [ds.ptr], [n], n, mode=1), want), nth
+        assert "broken" in outcomes and "beyond" in outcomes, outcomes   # the sweep reached the exchange's calls and ran past the last checked call
+    finally:
+        g.lib.mi_debug_inject_hip_failure(0)
+        dp.free(); ds.free(); g.close()

@@ -20,8 +20,8 @@ def ctx():
 
 
 def _reset(ctx):
-    for k, v in (("l1_wg", 1), ("g2_wg", 1), ("l1_waves", 3), ("z_waves", 0), ("finisher", 1), ("finisher_max", 0), ("plain_scatter", 0), ("count_per", 0),
-                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0)):
+    for k, v in (("l1_wg", 4), ("g2_wg", 1), ("l1_waves", 3), ("z_waves", 0), ("finisher", 1), ("finisher_max", 0), ("plain_scatter", 0), ("count_per", 0),
+                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2), ("l1_stream", 0)):
         ctx.set_knob(k, v)
     assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
 
@@ -77,10 +77,10 @@ def test_finisher_on_off_and_thresholds_agree_with_oracle(ctx, limb29):
         assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, limb29) == 0
         for plan in ((0, 0, 0, 0, 0), (11, 4, 2, 0, 0), (9, 16, 8, 0, 0)):
             assert ctx.lib.mi_debug_set_msm_plan(ctx.h, *plan) == 0
-            for fin, fmax in ((0, 0), (1, 0), (1, 17), (1, 300), (1, 1 << 20)):
-                ctx.set_knob("finisher", fin); ctx.set_knob("finisher_max", fmax)
-                assert np.array_equal(ctx.msm_g1(pts, sc), want1), (limb29, plan, fin, fmax)
-                assert np.array_equal(ctx.msm_g2(p2, s2), want2), (limb29, plan, fin, fmax)
+            for fin, fmax, fmin in ((0, 0, 2), (1, 0, 2), (1, 0, 0), (1, 17, 0), (1, 300, 1), (1, 1 << 20, 0)):   # fmin 0: the finisher right after level 1
+                ctx.set_knob("finisher", fin); ctx.set_knob("finisher_max", fmax); ctx.set_knob("finisher_min_level", fmin)
+                assert np.array_equal(ctx.msm_g1(pts, sc), want1), (limb29, plan, fin, fmax, fmin)
+                assert np.array_equal(ctx.msm_g2(p2, s2), want2), (limb29, plan, fin, fmax, fmin)
     finally:
         _reset(ctx)
 
@@ -98,7 +98,7 @@ def test_finisher_all_pairs_one_point(ctx):
         for plan in ((0, 0, 0, 0, 0), (5, 0, 0, 0, 0)):
             assert ctx.lib.mi_debug_set_msm_plan(ctx.h, *plan) == 0
             for fmax in (0, 40, 1 << 20):
-                ctx.set_knob("finisher_max", fmax)
+                ctx.set_knob("finisher_max", fmax); ctx.set_knob("finisher_min_level", 0)
                 assert np.array_equal(ctx.msm_g1(same, ssc), want1), (plan, fmax)
                 assert np.array_equal(ctx.msm_g2(same2, ssc[:n2]), want2), (plan, fmax)
     finally:
@@ -119,7 +119,7 @@ def test_prove_with_round5_knobs_gives_the_oracle_bytes(ctx):
             assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0
             pkh = ctx.pk_load(pk)
             for cfg in ({}, {"l1_wg": 4}, {"l1_wg": 4, "l1_waves": 2, "g2_wg": 2}, {"finisher": 0}, {"finisher_max": 20, "l1_wg": 2, "z_waves": 2},
-                        {"plain_scatter": 1, "count_per": 8}):
+                        {"plain_scatter": 1, "count_per": 8}, {"l1_wg": 1, "l1_stream": 1}, {"finisher_min_level": 0, "finisher_max": 1 << 20}):
                 _reset(ctx)
                 for k, v in cfg.items():
                     ctx.set_knob(k, v)
