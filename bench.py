@@ -155,7 +155,7 @@ def sharded_prove_section(B, g, rank, world, log_n, steps):
     nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
     seed = 0x57484952 + 4
     ia, ib = masks(nb_wires, seed)
-    lo, hi = B.shard_range(nb_wires, world, rank); zlo, zhi = B.shard_range(N - 1, world, rank)
+    lo, hi = g.wire_range(nb_wires, rank); zlo, zhi = B.shard_range(N - 1, world, rank)   # wires by the group's lead share (automatic), the Z pairs evenly
     na, nb = int((ia[lo:hi] == 0).sum()), int((ib[lo:hi] == 0).sum())
     nk = max(hi, nb_public) - max(lo, nb_public)
     rseed = seed + 1000 * rank

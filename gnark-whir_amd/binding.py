@@ -29,7 +29,7 @@ EXPORTS = [
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
     "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22", "mi_prover_trim", "mi_ctx_trim",
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_create_rank_ex", "mi_group_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
-    "mi_group_last_error", "mi_group_transport", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
+    "mi_group_last_error", "mi_group_transport", "mi_group_set_lead_share", "mi_group_wire_range", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
     "mi_groth16_prove_sharded", "mi_groth16_prove_sharded_dev", "mi_pk_load_sharded_dev", "mi_msm_g1_sharded", "mi_msm_g2_sharded",
     "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
     "mi_pk_raw_inspect", "mi_pk_load_raw",
@@ -536,6 +536,16 @@ class Group:
 
     def rank_index(self):
         return int(self.lib.mi_group_rank(self.h))
+
+    def set_lead_share(self, permille=0xFFFFFFFF):
+        """rank 0's share of the wires, permille of an even share (0xFFFFFFFF = automatic); before pk_load*, the same on every rank"""
+        self._ck(self.lib.mi_group_set_lead_share(self.h, C.c_uint32(permille)))
+
+    def wire_range(self, nb_wires, rank):
+        """wires [lo, hi) of global rank `rank` under the group's lead share (what pk_load_dev slices and W slices must follow)"""
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.mi_group_wire_range(self.h, C.c_uint64(nb_wires), C.c_int(rank), C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
 
     def exchange_selftest(self, nbytes=4096):
         self._ck(self.lib.mi_group_exchange_selftest(self.h, C.c_size_t(nbytes)))

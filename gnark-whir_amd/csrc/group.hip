@@ -80,6 +80,7 @@ struct mi_group {
     std::vector<hipEvent_t> ev_x, ev_in, ev_done, ev_h;
     std::vector<DevBuf> recv;      // per local rank: bucket slices received from the other ranks
     std::vector<DevBuf> stage;     // per local rank: small staging area for the all-gathers (transport 1)
+    uint32_t lead_share = 0xffffffffu;   // permille of an even wire share that rank 0 -- which also runs computeH -- takes (mi_group_set_lead_share; all ones = automatic)
     int timeout_ms = 60000;        // how long a rank waits for its peers without anything completing (MI_GROUP_TIMEOUT_MS; both transports)
     bool nonblocking = false;      // transport 1, one rank per process: the communicator is non-blocking and every wait on it is a deadline poll
     std::string err;
@@ -111,6 +112,26 @@ struct GroupCall {
                    if ((g)->broken) G_FAIL(g, MI_EHIP, "group: an earlier exchange failed half-way; destroy the group and create a new one")
 
 static void range_of(u64 total, int world, int r, u64 &lo, u64 &hi) { lo = total * (u64)r / (u64)world; hi = total * (u64)(r + 1) / (u64)world; }
+// The WIRE cut of a sharded key.  Rank 0 (the lead) also runs computeH, which no other rank can help with (NTT = replicas only, SURVEY
+// 8e), and the other ranks cannot start their Z MSMs before h exists: giving the lead a smaller share of the wire MSMs shortens the
+// proof's critical path (the projection).  share = permille of the even share: the lead takes share / 1000 of
+// nb_wires / world wires, the other ranks split the rest evenly; 1000 = the even cut of range_of, bit for bit.  The N - 1 pairs of the
+// Z MSM stay cut evenly (Z starts on every rank at the same moment, when h arrives).
+// Automatic: 1000 * max(0, 1 - rho (world - 1)) with rho = computeH time / wire-MSM time = 1/2 (measured at N = 2^26 on one MI355X
+// with the WHIR witness mix: 60 of 115 ms) -- 1000 for one rank, 500 for two, 0 from three ranks on.
+static uint32_t lead_share_of(const mi_group *g) {
+    if (g->lead_share <= 1000) return g->lead_share;
+    const int w = g->world;
+    return w <= 1 ? 1000u : w == 2 ? 500u : 0u;
+}
+static void wire_range_of(u64 nb_wires, int world, int r, uint32_t share, u64 &lo, u64 &hi) {
+    if (share >= 1000 || world <= 1) { range_of(nb_wires, world, r, lo, hi); return; }
+    const u64 lead_n = nb_wires * share / (1000ull * (u64)world), rest = nb_wires - lead_n;
+    if (r == 0) { lo = 0; hi = lead_n; return; }
+    u64 a, b;
+    range_of(rest, world - 1, r - 1, a, b);
+    lo = lead_n + a; hi = lead_n + b;
+}
 
 // ---------------------------------------------------------------- transport 3: shared-memory link
 static std::string shm_name_of(const uint8_t id[128]) {
@@ -580,6 +601,19 @@ int32_t mi_group_create_rank_ex(int device_id, int rank, int world, const uint8_
 int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t id[128], mi_group **out) {
     return mi_group_create_rank_ex(device_id, rank, world, id, MI_GROUP_TRANSPORT_RCCL, out);
 }
+int32_t mi_group_set_lead_share(mi_group *g, uint32_t permille) {
+    if (!g || (permille > 1000 && permille != MI_LEAD_SHARE_AUTO)) return MI_EINVAL;
+    G_ENTER(g);
+    g->lead_share = permille;
+    return MI_OK;
+}
+int32_t mi_group_wire_range(const mi_group *g, uint64_t nb_wires, int rank, uint64_t *lo, uint64_t *hi) {
+    if (!g || !lo || !hi || rank < 0 || rank >= g->world) return MI_EINVAL;
+    u64 a, b;
+    wire_range_of(nb_wires, g->world, rank, lead_share_of(g), a, b);
+    *lo = a; *hi = b;
+    return MI_OK;
+}
 int32_t mi_group_world(const mi_group *g) { return g ? g->world : 0; }
 int32_t mi_group_rank(const mi_group *g) { return g ? g->rank0 : -1; }
 int32_t mi_group_local(const mi_group *g) { return g ? g->n_local() : 0; }
@@ -669,7 +703,7 @@ static int32_t exchange_prepare(mi_group *g, BucketExchange &bx, const int *slot
         const MsmCurveOps &ops = mi_msm_ops(curves[k]);
         for (int i = 0; i < nl; i++) {
             G_CTX(g, i, mi_msm_bucket_view(g->ctx[i], slots[k], curves[k], &bx.v[k][i]));
-            if (!bx.v[k][i].bucket) G_FAIL(g, MI_EINVAL, "group: mode 1 (bucket exchange) needs every rank to hold at least one pair of every MSM");
+            if (!bx.v[k][i].bucket) G_FAIL(g, MI_EINVAL, "group: mode 1 (bucket exchange): a rank has no bucket array for one of the MSMs");
             if (bx.v[k][i].nkeys != bx.v[k][0].nkeys || bx.v[k][i].c != bx.v[k][0].c) G_FAIL(g, MI_EINVAL, "group: the ranks disagree on the bucket layout of an MSM");
         }
         const size_t K = bx.v[k][0].nkeys, own_max = (K + W - 1) / W + 1;
@@ -902,27 +936,25 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
             if (descs[i].log_n != d->log_n || descs[i].nb_wires != d->nb_wires || descs[i].nb_public != d->nb_public || !descs[i].infinity_a || !descs[i].infinity_b) {
                 lrc = MI_EINVAL; lerr = "pk: the per-rank descriptors disagree on the key's header";
             }
-        const uint64_t check[3] = {d->log_n, d->nb_wires, d->nb_public};
-        MI_TRY(group_agree(g, lrc, lerr, "while checking the key's header", check, 3));
+        const uint64_t check[4] = {d->log_n, d->nb_wires, d->nb_public, lead_share_of(g)};   // (the lead's wire share must be the same on every rank)
+        MI_TRY(group_agree(g, lrc, lerr, "while checking the key's header", check, 4));
     }
     const u64 N = (u64)1 << d->log_n;
     mi_pk_sharded *spk = new (std::nothrow) mi_pk_sharded();
     if (!spk) return MI_ENOMEM;
     spk->part.assign(nl, nullptr); spk->log_n = d->log_n; spk->nb_wires = d->nb_wires;
     // window widths of the generic path that all parts share (mode 1 needs equal bucket layouts): from the LARGEST part of each MSM
-    // ... and whether EVERY rank holds at least one pair of every MSM: mode 1 exchanges bucket slices rank to rank and a rank without
-    // buckets would leave its peers waiting in the collective -- decided here from the masks every process holds, so that every
-    // process refuses mode 1 alike (spk->uniform) instead of one rank failing while the others hang
+    // (a rank WITHOUT pairs of some MSM -- the lead with a wire share of 0, a tiny key -- still takes part in mode 1: an empty deferred MSM
+    //  leaves a zeroed bucket array of the agreed shape, msm.hip mi_msm_enqueue)
+    const uint32_t share = lead_share_of(g);
     u64 max_w = 0, max_b = 0, max_z = 0;
-    bool all_nonempty = true;
     for (int r = 0; r < W; r++) {
         u64 lo, hi, zlo, zhi, nb = 0;
-        range_of(d->nb_wires, W, r, lo, hi); range_of(N - 1, W, r, zlo, zhi);
+        wire_range_of(d->nb_wires, W, r, share, lo, hi); range_of(N - 1, W, r, zlo, zhi);
         for (u64 j = lo; j < hi; j++) nb += d->infinity_b[j] ? 0 : 1;
         if (hi - lo > max_w) max_w = hi - lo;
         if (nb > max_b) max_b = nb;
         if (zhi - zlo > max_z) max_z = zhi - zlo;
-        if (hi == lo || nb == 0 || zhi == zlo) all_nonempty = false;
     }
     // ONE fixed-base plan for all parts (mode 1 exchanges buckets, so the parts must cut their scalars alike; and a part just
     // under the 2^20-point threshold next to one just over it would otherwise pick different paths): the rule of mi_pk_load
@@ -961,7 +993,7 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
         (void)hipSetDevice(g->dev[i]);
         mi_ctx *ctx = g->ctx[i];
         ShardRange sr;
-        range_of(d->nb_wires, W, g->rank0 + i, sr.w_lo, sr.w_hi); range_of(N - 1, W, g->rank0 + i, sr.z_lo, sr.z_hi);
+        wire_range_of(d->nb_wires, W, g->rank0 + i, share, sr.w_lo, sr.w_hi); range_of(N - 1, W, g->rank0 + i, sr.z_lo, sr.z_hi);
         u32 saved[3];
         for (int k = 0; k < 3; k++) { saved[k] = ctx->fixed_knob[k]; if (!saved[k]) ctx->fixed_knob[k] = plan[k]; }
         rcs[i] = mi_pk_load_range(ctx, device_points ? &descs[i] : d, &spk->part[i], device_points, &sr);
@@ -983,7 +1015,7 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
     if (first_bad != MI_OK) return fail(first_bad);
     if (rc != MI_OK) return fail(rc);
     if (smin == 0) { g->err = "pk: another rank of the group failed to load its part"; return fail(MI_EHIP); }
-    spk->uniform = smin == smax && all_nonempty;
+    spk->uniform = smin == smax;
     *out = spk;
     return MI_OK;
 }
@@ -1016,7 +1048,7 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
     if (!r_m || !s_m || mode > 1 || (host ? (!W_host && n_wires) : !W_dev)) note(MI_EINVAL, "prove: null argument or unknown mode");
     if (lead_here && (!a || !b) && n_constraints) note(MI_EINVAL, "prove: the process that holds rank 0 must pass a and b");
     if (n_wires != spk->nb_wires || (lead_here && n_constraints > N)) note(MI_EINVAL, "prove: witness size does not match the proving key");
-    if (mode == 1 && !spk->uniform) note(MI_EINVAL, "group: mode 1 needs every part to use the same MSM plan and every rank to hold pairs of every MSM");
+    if (mode == 1 && !spk->uniform) note(MI_EINVAL, "group: mode 1 needs every part of the key to use the same MSM plan");
     // workspaces, each on its own device: W slice (+ a, b, c on the lead) for host inputs; h (whole on the lead, a slice elsewhere)
     for (int i = 0; i < nl && lrc == MI_OK; i++) {
         (void)hipSetDevice(g->dev[i]);

@@ -834,7 +834,34 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
     sl.stat_pairs = stat_pairs ? stat_pairs : n;
     const bool defer = (flags & MI_MSM_DEFER_REDUCE) != 0, exact = (flags & MI_MSM_EXACT_SIZE) != 0, rprime = (flags & MI_MSM_PTS_RPRIME) != 0;
     flags &= ~(MI_MSM_DEFER_REDUCE | MI_MSM_EXACT_SIZE | MI_MSM_PTS_RPRIME);
-    if (n == 0) return MI_OK;
+    if (n == 0) {
+        if (!defer) return MI_OK;
+        // An EMPTY deferred MSM (a rank of a point-sharded MSM without pairs: group.hip) still leaves a bucket array of the plan's shape
+        // -- all infinity -- so that the bucket exchange and the reduce treat this rank like every other.
+        const MsmCurveOps &ops = curve == 1 ? msm_g1_ops() : msm_g2_ops();
+        sl.n = 0; sl.G = 1;
+        if (sort_slot >= 0) {   // the shape of the (equally empty) sort it would have shared
+            const MsmSlot &srt = ctx->msm[sort_slot];
+            if (srt.n != 0) MI_FAIL(ctx, MI_EINVAL, "msm: shared sort has a different length");
+            sl.c = srt.c; sl.nwin_digits = srt.nwin_digits; sl.nwin_keys = srt.nwin_keys;
+        } else {
+            sl.c = precomp_c ? precomp_c : (knobs_of(ctx)->c ? knobs_of(ctx)->c : (generic_c >= 2 && generic_c <= 16 ? generic_c : auto_c(1)));
+            sl.nwin_digits = (256 + sl.c - 1) / sl.c;
+            sl.nwin_keys = precomp_c ? 1 : sl.nwin_digits;
+        }
+        sl.entries_cap = 0;
+        const MsmShape s = key_shape(sl);
+        MI_TRY(mi_reserve(ctx, sl.buf[B_BUCKET], (size_t)s.nkeys * ops.xyzz_bytes + 64));
+        if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
+        MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
+        MI_CHECK_HIP(ctx, hipMemsetAsync(sl.buf[B_BUCKET].p, 0, (size_t)s.nkeys * ops.xyzz_bytes + 64, sl.stream));
+        sl.tail_seg = knobs_of(ctx)->seg ? knobs_of(ctx)->seg : (s.nbuckets >= 256 ? 8 : 2);
+        sl.entries_src = (const u32 *)((const char *)sl.buf[B_BUCKET].p + (size_t)s.nkeys * ops.xyzz_bytes);   // a zeroed word: no entries
+        sl.timed = false;
+        sl.deferred = true;
+        MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[5], sl.stream));
+        return MI_OK;
+    }
     if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
     MsmSlot &srt = sort_slot >= 0 ? ctx->msm[sort_slot] : sl;

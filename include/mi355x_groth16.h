@@ -321,6 +321,18 @@ int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t i
 #define MI_GROUP_TRANSPORT_HOST 3
 int32_t mi_group_create_rank_ex(int device_id, int rank, int world, const uint8_t id[128], int transport, mi_group **out);
 int32_t mi_group_destroy(mi_group *g);
+/* The lead's share of the WIRES of a sharded key.  Rank 0 also runs computeH (the NTT does not shard: SURVEY 8e) and no rank can start
+ * its Z MSM before h exists, so a lead that carries an equal share of the wire MSMs lengthens the critical path of the proof.
+ * permille = the fraction of an even share (nb_wires / world) that rank 0 takes, 0..1000; the other ranks split the rest evenly; the
+ * N - 1 pairs of the Z MSM are always cut evenly.  1000 = the even cut.  MI_LEAD_SHARE_AUTO (the default): 1000 for one rank, 500 for
+ * two, 0 from three ranks on -- from the measured ratio computeH : wire MSMs = 1 : 2 at N = 2^26.  Set it -- to the same
+ * value in every process -- BEFORE mi_pk_load_sharded*: the key's parts are cut by it (a disagreement fails that load on every rank),
+ * and a caller that passes device slices (mi_pk_load_sharded_dev, mi_groth16_prove_sharded_dev) cuts its arrays by
+ * mi_group_wire_range.  Same proofs whatever the share. */
+#define MI_LEAD_SHARE_AUTO 0xffffffffu
+int32_t mi_group_set_lead_share(mi_group *g, uint32_t permille);
+/* wires [*lo, *hi) of global rank `rank` under the group's current lead share */
+int32_t mi_group_wire_range(const mi_group *g, uint64_t nb_wires, int rank, uint64_t *lo, uint64_t *hi);
 int32_t mi_group_world(const mi_group *g);
 int32_t mi_group_local(const mi_group *g);                 /* ranks held by this process */
 mi_ctx *mi_group_ctx(mi_group *g, int local_rank);         /* for mi_dev_* / generators on that rank's device */

@@ -29,14 +29,15 @@ def uid_of(seed_hex, k):
     return (h + h)[:128]
 
 
-def slices_of(B, c, pk, world, rank, keep):
+def slices_of(B, c, pk, world, rank, keep, g=None):
     """device copies of rank `rank`'s slices of the five point arrays (what mi_pk_load_sharded_dev adopts)"""
     N = 1 << pk["log_n"]
     ia, ib = np.asarray(pk["infinity_a"]), np.asarray(pk["infinity_b"])
     cw = set(int(x) for x in (pk.get("committed_wires") if pk.get("committed_wires") is not None else []))
     in_k = np.array([j >= pk["nb_public"] and j not in cw for j in range(pk["nb_wires"])])
     ca, cb, ck = np.concatenate([[0], np.cumsum(ia == 0)]), np.concatenate([[0], np.cumsum(ib == 0)]), np.concatenate([[0], np.cumsum(in_k)])
-    lo, hi = B.shard_range(pk["nb_wires"], world, rank); zlo, zhi = B.shard_range(N - 1, world, rank)
+    lo, hi = g.wire_range(pk["nb_wires"], rank) if g is not None else B.shard_range(pk["nb_wires"], world, rank)   # wires by the group's lead share
+    zlo, zhi = B.shard_range(N - 1, world, rank)
     sl = {}
     for name, arr in (("g1_a", pk["g1_a"][ca[lo]:ca[hi]]), ("g1_b", pk["g1_b"][cb[lo]:cb[hi]]), ("g1_k", pk["g1_k"][ck[lo]:ck[hi]]),
                       ("g1_z", pk["g1_z"][zlo:zhi]), ("g2_b", pk["g2_b"][cb[lo]:cb[hi]])):
@@ -89,8 +90,8 @@ def scenario_parity(B, rank, world, seed_hex):
         assert B.proof_write(got["raw"]) == want, "sharded prove with c = a o b formed on the device"
         g.pk_free(spk)
         keep = []
-        spk = g.pk_load_dev(pk, [slices_of(B, c, pk, world, rank, keep)])
-        wlo, whi = B.shard_range(pk["nb_wires"], world, rank)
+        spk = g.pk_load_dev(pk, [slices_of(B, c, pk, world, rank, keep, g)])
+        wlo, whi = g.wire_range(pk["nb_wires"], rank)
         dW = c.to_dev(W[wlo:whi]); keep.append(dW)
         da = db = dc = None
         if lead:
@@ -103,6 +104,37 @@ def scenario_parity(B, rank, world, seed_hex):
         for x in keep:
             x.free()
         checks.append("prove_2p16_host_and_device_both_modes")
+        # ---- the lead's share of the wires (mi_group_set_lead_share): 0 (its wire MSMs are empty), half, the even cut -- same bytes in both
+        #      modes, host arrays and device slices; a rank that sets another share than its peers fails the load on EVERY rank
+        pk, W, a, b, cc, r, s, want = workload(13, 9150, n_committed=5)
+        for share in (0, 500, 1000):
+            g.set_lead_share(share)
+            spk = g.pk_load(pk)
+            for mode in (0, 1):
+                got, _ = g.prove(spk, W, a if lead else None, b if lead else None, cc if lead else None, r, s, mode=mode)
+                assert B.proof_write(got["raw"]) == want, f"lead share {share} mode {mode} (host arrays)"
+            g.pk_free(spk)
+            keep = []
+            spk = g.pk_load_dev(pk, [slices_of(B, c, pk, world, rank, keep, g)])
+            wlo, whi = g.wire_range(pk["nb_wires"], rank)
+            dW = c.to_dev(W[wlo:whi]); keep.append(dW)
+            da = db = None
+            if lead:
+                da, db = c.to_dev(a), c.to_dev(b); keep += [da, db]
+            got, _ = g.prove_dev(spk, [dW.ptr], pk["nb_wires"], ptr(da), ptr(db), None, a.shape[0], r, s, mode=1)
+            assert B.proof_write(got["raw"]) == want, f"lead share {share} (device slices)"
+            g.pk_free(spk)
+            for x in keep:
+                x.free()
+        g.set_lead_share(1000 if rank == 0 else 250)
+        refused = False
+        try:
+            g.pk_load(pk)
+        except B.MiError:
+            refused = True
+        assert refused, "ranks that disagree on the lead share must all be refused the key"
+        g.set_lead_share(0xFFFFFFFF)
+        checks.append("lead_share_0_500_1000_and_disagreement")
     finally:
         g.close()
     return {"ok": True, "checks": checks}

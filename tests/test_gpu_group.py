@@ -83,7 +83,7 @@ def _slices(B, grp, pk, keep):
     out = []
     for r in range(grp.world):
         c = grp.ctx(r)
-        lo, hi = B.shard_range(pk["nb_wires"], grp.world, r); zlo, zhi = B.shard_range(N - 1, grp.world, r)
+        lo, hi = grp.wire_range(pk["nb_wires"], r); zlo, zhi = B.shard_range(N - 1, grp.world, r)   # wires by the group's lead share, Z evenly
         sl = {}
         for name, arr in (("g1_a", pk["g1_a"][ca[lo]:ca[hi]]), ("g1_b", pk["g1_b"][cb[lo]:cb[hi]]), ("g1_k", pk["g1_k"][ck[lo]:ck[hi]]),
                           ("g1_z", pk["g1_z"][zlo:zhi]), ("g2_b", pk["g2_b"][cb[lo]:cb[hi]])):
@@ -108,7 +108,7 @@ def test_sharded_prove_device_slices_and_device_inputs(B, grp, log_n, nb_public,
     spk = grp.pk_load_dev(pk, _slices(B, grp, pk, keep))
     Wp = []
     for rk in range(grp.world):
-        lo, hi = B.shard_range(nb_wires, grp.world, rk)
+        lo, hi = grp.wire_range(nb_wires, rk)
         d = grp.ctx(rk).to_dev(W[lo:hi]); keep.append(d); Wp.append(d.ptr)
     c0 = grp.ctx(0)
     da, db, dc = c0.to_dev(a), c0.to_dev(b), c0.to_dev(c); keep += [da, db, dc]
@@ -208,12 +208,11 @@ def test_group_argument_errors(B, grp):
     with pytest.raises(B.MiError):   # point counts that do not match the masks
         grp.pk_load(bad)
     if grp.world > 1:
-        # a part of a sharded key is not a key: the unsharded prove refuses it... through the public API a part is never exposed,
-        # so the check is that mode 1 refuses an MSM with an empty rank instead of losing that rank's keys
+        # an MSM with an EMPTY rank (one pair, several ranks): rounds 1-4 refused it in mode 1; an empty deferred MSM now leaves an
+        # all-infinity bucket array and the exchange runs like any other
         pts = cref.gen_g1(1, 5); sc = cref.gen_scalars(1, 6, 0)
-        with pytest.raises(B.MiError):
-            grp.msm_g1(pts, sc, mode=1)
-        assert np.array_equal(grp.msm_g1(pts, sc, mode=0), cref.msm_g1(pts, sc))
+        for mode in (1, 0):
+            assert np.array_equal(grp.msm_g1(pts, sc, mode=mode), cref.msm_g1(pts, sc))
 
 
 def test_sharded_prove_at_2p22_two_ranks_automatic_tables(B):
@@ -298,3 +297,57 @@ def test_rccl_per_rank_group_injected_failures_break_or_spare_the_group_but_neve
     finally:
         g.lib.mi_debug_inject_hip_failure(0)
         dp.free(); ds.free(); g.close()
+
+
+@pytest.mark.parametrize("share", [0, 500, 1000, 0xFFFFFFFF])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_lead_share_of_the_wires_gives_the_same_proof(B, grp, share, mode):
+    """mi_group_set_lead_share: rank 0 (which also runs computeH) takes 0, half, all of an even wire share, or the automatic one; host
+    arrays and device slices, both modes (share 0: the lead's wire MSMs are EMPTY and still take part in the bucket exchange); bytes ==
+    oracle; the cut is what mi_group_wire_range says"""
+    log_n = 13
+    N = 1 << log_n
+    nb_wires, n_constraints = N - 50, N - 10
+    pk = synthetic_pk(log_n, nb_wires, 300, 8700, n_committed=11)
+    W = cref.gen_scalars(nb_wires, 21, 1)
+    a = cref.gen_scalars(n_constraints, 22, 1); b = cref.gen_scalars(n_constraints, 23, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 24, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    try:
+        grp.set_lead_share(share)
+        spans = [grp.wire_range(nb_wires, rk) for rk in range(grp.world)]
+        assert spans[0][0] == 0 and spans[-1][1] == nb_wires and all(spans[i][1] == spans[i + 1][0] for i in range(grp.world - 1))
+        if grp.world > 1 and share <= 1000:
+            assert spans[0][1] == nb_wires * share // (1000 * grp.world)
+        if share == 0xFFFFFFFF:
+            assert spans[0][1] == {1: nb_wires, 2: nb_wires * 500 // 2000}.get(grp.world, 0)
+        spk = grp.pk_load(pk)
+        got, _ = grp.prove(spk, W, a, b, c, r, s, mode=mode)
+        grp.pk_free(spk)
+        assert B.proof_write(got["raw"]) == want, (share, mode, "host arrays")
+        keep = []
+        spk = grp.pk_load_dev(pk, _slices(B, grp, pk, keep))
+        Wp = []
+        for rk in range(grp.world):
+            d = grp.ctx(rk).to_dev(W[spans[rk][0]:spans[rk][1]]); keep.append(d); Wp.append(d.ptr)
+        c0 = grp.ctx(0)
+        da, db = c0.to_dev(a), c0.to_dev(b); keep += [da, db]
+        got, _ = grp.prove_dev(spk, Wp, nb_wires, da.ptr, db.ptr, None, n_constraints, r, s, mode=mode)
+        grp.pk_free(spk)
+        for d in keep:
+            d.free()
+        assert B.proof_write(got["raw"]) == want, (share, mode, "device slices")
+    finally:
+        grp.set_lead_share(0xFFFFFFFF)
+
+
+def test_sharded_msm_with_ranks_that_hold_no_pairs(B):
+    """fewer pairs than ranks: some ranks' shares are EMPTY; mode 1 exchanges their (all-infinity) bucket arrays like any other"""
+    g = B.Group([0, 0, 0])
+    try:
+        for n in (1, 2):
+            pts = cref.gen_g1(n, 61); sc = cref.gen_scalars(n, 62, 0)
+            for mode in (0, 1):
+                assert np.array_equal(g.msm_g1(pts, sc, mode=mode), cref.msm_g1(pts, sc)), (n, mode)
+    finally:
+        g.close()

@@ -33,7 +33,7 @@ def test_world2_two_processes_parity_vs_oracle(rank_launcher):
     res = _run(rank_launcher, "parity")
     for rc, j, raw in res:
         assert rc == 0 and j.get("ok"), f"{j} {raw['stderr'][-1500:]}"
-        assert j["checks"] == ["selftest", "msm_g1_g2_both_modes", "prove_2p16_host_and_device_both_modes"]
+        assert j["checks"] == ["selftest", "msm_g1_g2_both_modes", "prove_2p16_host_and_device_both_modes", "lead_share_0_500_1000_and_disagreement"]
 
 
 def test_world3_three_processes_parity_vs_oracle(rank_launcher):
