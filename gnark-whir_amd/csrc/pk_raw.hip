@@ -14,30 +14,11 @@
 //
 // Raw points are big-endian CANONICAL coordinates; the device wants little-endian Montgomery limbs.  The conversion is the one
 // data-parallel piece (one point per thread: byte swap, flag bits, fe_to_mont) and runs on the GPU over the uploaded bytes;
-// the variable-length header walk is host code.
+// the variable-length header walk is host code (csrc/pk_raw_inspect.hip: no HIP in it, so that the CPU build with sanitizers covers it).
 #include "prove_internal.h"
 #include <cstring>
 #include <vector>
 
-namespace {
-struct Cursor {
-    const uint8_t *p;
-    size_t len, off = 0;
-    bool ok = true;
-    const uint8_t *take(size_t n) {
-        if (!ok || n > len - off) { ok = false; return nullptr; }
-        const uint8_t *r = p + off;
-        off += n;
-        return r;
-    }
-    uint64_t be(size_t n) {
-        const uint8_t *b = take(n);
-        uint64_t v = 0;
-        if (b) for (size_t i = 0; i < n; i++) v = (v << 8) | b[i];
-        return v;
-    }
-};
-}  // namespace
 
 // one field element: 32 bytes big-endian canonical -> 8 x u32 little-endian Montgomery; top_mask clears the encoder's flag bits
 template <class P>
@@ -78,46 +59,6 @@ __global__ void k_raw_to_g2(G2Aff *dst, const uint8_t *src, size_t n, u32 *bad) 
 }
 
 extern "C" {
-
-// Host-only walk over the stream: offsets and counts of every section (no device needed; what the CPU tests check).
-int32_t mi_pk_raw_inspect(const uint8_t *buf, size_t len, mi_pk_raw_info *info) {
-    if (!buf || !info) return MI_EINVAL;
-    std::memset(info, 0, sizeof(*info));
-    Cursor c{buf, len};
-    const uint64_t card = c.be(8);
-    c.take(5 * 32);                       // CardinalityInv, Generator, GeneratorInv, FrMultiplicativeGen, FrMultiplicativeGenInv
-    const uint64_t with_pre = c.be(1);    // withPrecompute
-    if (!c.ok || card == 0 || (card & (card - 1)) || card > ((uint64_t)1 << 28) || with_pre > 1) return MI_EINVAL;
-    uint32_t log_n = 0;
-    while (((uint64_t)1 << log_n) < card) log_n++;
-    info->log_n = log_n;
-    info->off_alpha1 = c.off; c.take(3 * 64);
-    auto g1s = [&](uint64_t *off, uint64_t *cnt) { *cnt = c.be(4); *off = c.off; c.take((size_t)*cnt * 64); };
-    g1s(&info->off_g1_a, &info->n_g1_a);
-    g1s(&info->off_g1_b, &info->n_g1_b);
-    g1s(&info->off_g1_z, &info->n_g1_z);
-    g1s(&info->off_g1_k, &info->n_g1_k);
-    info->off_beta2 = c.off; c.take(2 * 128);
-    info->n_g2_b = c.be(4); info->off_g2_b = c.off; c.take((size_t)info->n_g2_b * 128);
-    info->nb_wires = c.be(8);
-    const uint64_t n_inf_a = c.be(8), n_inf_b = c.be(8);
-    const uint64_t la = c.be(4); info->off_infinity_a = c.off; c.take((size_t)((la + 7) / 8));
-    const uint64_t lb = c.be(4); info->off_infinity_b = c.off; c.take((size_t)((lb + 7) / 8));
-    info->n_commitment_keys = (uint32_t)c.be(4);
-    if (!c.ok || la != info->nb_wires || lb != info->nb_wires || info->n_commitment_keys > MI_PK_RAW_MAX_COMMITMENTS) return MI_EINVAL;
-    for (uint32_t k = 0; k < info->n_commitment_keys; k++) {
-        uint64_t n1, n2;
-        g1s(&info->off_basis[k], &n1);
-        g1s(&info->off_basis_exp_sigma[k], &n2);
-        if (!c.ok || n1 != n2) return MI_EINVAL;
-        info->n_basis[k] = n1;
-    }
-    if (!c.ok || c.off != len) return MI_EINVAL;   // trailing bytes = not the layout this parser knows
-    // cross-checks that tie the sections together
-    if (info->n_g1_a + n_inf_a != info->nb_wires || info->n_g1_b + n_inf_b != info->nb_wires || info->n_g2_b != info->n_g1_b) return MI_EINVAL;
-    if (info->n_g1_z + 1 < card || info->n_g1_k > info->nb_wires) return MI_EINVAL;
-    return MI_OK;
-}
 
 // nb_public and the wires removed from K (committed + commitment wires) come from the constraint system, not from the key file
 // (r1cs.GetNbPublicVariables(), CommitmentInfo): the caller passes them as for mi_pk_load.  ped_out (may be null) receives the

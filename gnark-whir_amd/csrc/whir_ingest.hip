@@ -82,85 +82,148 @@ bool dec_to_u256(const std::string &s, uint64_t out[4]) {
     return true;
 }
 
-// ---- a JSON reader for the flat Config object (main.go:41-58): numbers, strings, arrays of numbers / strings
+// ---- a JSON reader for the flat Config object (main.go:41-58): numbers, strings, arrays of numbers / strings.
+// It accepts what encoding/json's Unmarshal accepts for that struct and nothing else that would change a field: strict literals (true,
+// false, null spelled out), strict numbers (no leading zeros; an int field refuses fractions, exponents and values outside int64), strict
+// string escapes (\" \\ \/ \b \f \n \r \t \uXXXX; control characters refused), an unpaired surrogate escape becomes U+FFFD, null leaves a
+// field as it is, keys match ASCII-case-insensitively, the last of duplicate keys wins, nothing but white space may follow the value,
+// nesting deeper than 10000 is refused (Go's limit; skip() keeps its own stack, so the depth of the input costs no call stack).
+// Two differences remain, both on the refusing side and both documented in the header: invalid UTF-8 inside a string is copied as it is
+// (Go substitutes U+FFFD), and Go's fold of the Kelvin sign / long s onto k / s in key names is not reproduced.
 struct Js {
     const char *p, *e; bool ok = true;
     void ws() { while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
     bool eat(char c) { ws(); if (p < e && *p == c) { p++; return true; } return false; }
+    bool lit(const char *word) {   // the exact literal, followed by a delimiter or the end
+        ws();
+        const size_t n = std::strlen(word);
+        if ((size_t)(e - p) < n || std::memcmp(p, word, n) != 0) return false;
+        if ((size_t)(e - p) > n) { const char c = p[n]; if (!(c == ',' || c == '}' || c == ']' || c == ' ' || c == '\n' || c == '\t' || c == '\r')) return false; }
+        p += n;
+        return true;
+    }
+    static void utf8(std::string &out, unsigned v) {
+        if (v < 0x80) out += (char)v;
+        else if (v < 0x800) { out += (char)(0xc0 | (v >> 6)); out += (char)(0x80 | (v & 63)); }
+        else if (v < 0x10000) { out += (char)(0xe0 | (v >> 12)); out += (char)(0x80 | ((v >> 6) & 63)); out += (char)(0x80 | (v & 63)); }
+        else { out += (char)(0xf0 | (v >> 18)); out += (char)(0x80 | ((v >> 12) & 63)); out += (char)(0x80 | ((v >> 6) & 63)); out += (char)(0x80 | (v & 63)); }
+    }
+    // q points at the 'u' of \uXXXX; needs q[1..4] inside the input
+    bool hex4(const char *q, unsigned &v) const {
+        if (e - q < 5) return false;
+        v = 0;
+        for (int k = 1; k <= 4; k++) {
+            const char h = q[k];
+            const unsigned d = h >= '0' && h <= '9' ? (unsigned)(h - '0') : h >= 'a' && h <= 'f' ? (unsigned)(h - 'a' + 10) : h >= 'A' && h <= 'F' ? (unsigned)(h - 'A' + 10) : 99u;
+            if (d > 15) return false;
+            v = v * 16 + d;
+        }
+        return true;
+    }
     bool str(std::string &out) {
         ws();
         if (p >= e || *p != '"') return ok = false;
         p++; out.clear();
         while (p < e && *p != '"') {
-            if (*p == '\\') {
-                if (++p >= e) return ok = false;
-                switch (*p) {
-                    case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break; case 'b': out += '\b'; break; case 'f': out += '\f'; break;
-                    case 'u': {   // \uXXXX -> UTF-8 (a surrogate pair is one code point), as encoding/json does
-                        auto hex4 = [&](const char *q, unsigned &v) -> bool {
-                            if (e - q < 5) return false;
-                            v = 0;
-                            for (int k = 1; k <= 4; k++) {
-                                const char h = q[k];
-                                const unsigned d = h >= '0' && h <= '9' ? (unsigned)(h - '0') : h >= 'a' && h <= 'f' ? (unsigned)(h - 'a' + 10) : h >= 'A' && h <= 'F' ? (unsigned)(h - 'A' + 10) : 99u;
-                                if (d > 15) return false;
-                                v = v * 16 + d;
-                            }
-                            return true;
-                        };
-                        unsigned v = 0, lo = 0;
-                        if (!hex4(p, v)) return ok = false;
-                        p += 4;
-                        if (v >= 0xd800 && v < 0xdc00 && e - p > 6 && p[1] == '\\' && p[2] == 'u' && hex4(p + 2, lo) && lo >= 0xdc00 && lo < 0xe000) {
-                            v = 0x10000 + ((v - 0xd800) << 10) + (lo - 0xdc00);
-                            p += 6;
-                        }
-                        if (v < 0x80) out += (char)v;
-                        else if (v < 0x800) { out += (char)(0xc0 | (v >> 6)); out += (char)(0x80 | (v & 63)); }
-                        else if (v < 0x10000) { out += (char)(0xe0 | (v >> 12)); out += (char)(0x80 | ((v >> 6) & 63)); out += (char)(0x80 | (v & 63)); }
-                        else { out += (char)(0xf0 | (v >> 18)); out += (char)(0x80 | ((v >> 12) & 63)); out += (char)(0x80 | ((v >> 6) & 63)); out += (char)(0x80 | (v & 63)); }
-                        break;
-                    }
-                    default: out += *p;   // \" \\ \/
+            if ((unsigned char)*p < 0x20) return ok = false;   // a control character inside a string literal
+            if (*p != '\\') { out += *p++; continue; }
+            if (++p >= e) return ok = false;
+            switch (*p) {
+                case '"': out += '"'; break; case '\\': out += '\\'; break; case '/': out += '/'; break;
+                case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break; case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                case 'u': {   // \uXXXX -> UTF-8; a surrogate pair is one code point, an unpaired surrogate U+FFFD -- as encoding/json does
+                    unsigned v = 0, lo = 0;
+                    if (!hex4(p, v)) return ok = false;
+                    p += 4;   // on the last hex digit
+                    if (v >= 0xd800 && v < 0xdc00 && e - p > 6 && p[1] == '\\' && p[2] == 'u' && hex4(p + 2, lo) && lo >= 0xdc00 && lo < 0xe000) {
+                        v = 0x10000 + ((v - 0xd800) << 10) + (lo - 0xdc00);
+                        p += 6;
+                    } else if (v >= 0xd800 && v < 0xe000) v = 0xfffd;
+                    utf8(out, v);
+                    break;
                 }
-                p++;
-            } else out += *p++;
+                default: return ok = false;   // no other escape exists
+            }
+            p++;
         }
         if (p >= e) return ok = false;
         p++;
         return true;
     }
-    bool integer(int64_t &v) {
-        ws();
-        const char *s = p;
-        bool neg = false;
-        if (p < e && *p == '-') { neg = true; p++; }
-        if (p >= e || *p < '0' || *p > '9') { p = s; return ok = false; }
-        u128 acc = 0;
-        while (p < e && *p >= '0' && *p <= '9') { acc = acc * 10 + (unsigned)(*p++ - '0'); if (acc > ((u128)1 << 63)) return ok = false; }
-        if (p < e && (*p == '.' || *p == 'e' || *p == 'E')) return ok = false;   // Go refuses a fraction for an int field too
-        v = neg ? -(int64_t)acc : (int64_t)acc;
+    // a JSON number at p: [-] (0 | [1-9][0-9]*) [. digits] [(e|E) [+-] digits]; *plain = it has no fraction and no exponent
+    bool number_span(const char *&end, bool *plain) const {
+        const char *q = p;
+        if (q < e && *q == '-') q++;
+        if (q >= e) return false;
+        if (*q == '0') q++;
+        else if (*q >= '1' && *q <= '9') { while (q < e && *q >= '0' && *q <= '9') q++; }
+        else return false;
+        *plain = true;
+        if (q < e && *q == '.') { *plain = false; q++; if (q >= e || *q < '0' || *q > '9') return false; while (q < e && *q >= '0' && *q <= '9') q++; }
+        if (q < e && (*q == 'e' || *q == 'E')) {
+            *plain = false; q++;
+            if (q < e && (*q == '+' || *q == '-')) q++;
+            if (q >= e || *q < '0' || *q > '9') return false;
+            while (q < e && *q >= '0' && *q <= '9') q++;
+        }
+        if (q < e && !(*q == ',' || *q == '}' || *q == ']' || *q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) return false;
+        end = q;
         return true;
     }
-    bool skip() {   // any value
+    // an int field: *is_null = the value was null (Go leaves the field alone)
+    bool integer(int64_t &v, bool *is_null = nullptr) {
         ws();
-        if (p >= e) return ok = false;
-        if (*p == '"') { std::string t; return str(t); }
-        if (*p == '{' || *p == '[') {
-            const char open = *p, close = open == '{' ? '}' : ']';
-            p++;
-            if (eat(close)) return true;
-            for (;;) {
-                if (open == '{') { std::string k; if (!str(k) || !eat(':')) return ok = false; }
-                if (!skip()) return false;
-                if (eat(',')) continue;
-                return eat(close) ? true : (ok = false);
+        if (is_null) { *is_null = false; if (lit("null")) { *is_null = true; return true; } }
+        const char *end = nullptr;
+        bool plain = false;
+        if (!number_span(end, &plain) || !plain) return ok = false;   // not a number, or a fraction / exponent for an int
+        const bool neg = *p == '-';
+        u128 acc = 0;
+        for (const char *q = p + (neg ? 1 : 0); q < end; q++) {
+            acc = acc * 10 + (unsigned)(*q - '0');
+            if (acc > ((u128)1 << 63)) return ok = false;
+        }
+        if (acc == ((u128)1 << 63) && !neg) return ok = false;   // 9223372036854775808 does not fit an int64
+        v = neg ? (int64_t)(0 - (uint64_t)acc) : (int64_t)acc;
+        p = end;
+        return true;
+    }
+    bool skip() {   // any value; the nesting is kept on a stack of our own
+        std::vector<char> open;
+        for (;;) {
+            ws();
+            if (p >= e) return ok = false;
+            bool value_done = false;
+            if (*p == '"') { std::string t; if (!str(t)) return false; value_done = true; }
+            else if (*p == '{' || *p == '[') {
+                if (open.size() >= 10000) return ok = false;
+                const char o = *p++;
+                open.push_back(o);
+                if (eat(o == '{' ? '}' : ']')) { open.pop_back(); value_done = true; }
+                else if (o == '{') { std::string k; if (!str(k) || !eat(':')) return ok = false; }
+            } else if (lit("true") || lit("false") || lit("null")) value_done = true;
+            else { const char *end = nullptr; bool plain; if (!number_span(end, &plain)) return ok = false; p = end; value_done = true; }
+            while (value_done) {   // what follows a complete value
+                if (open.empty()) return true;
+                if (eat(',')) { if (open.back() == '{') { std::string k; if (!str(k) || !eat(':')) return ok = false; } value_done = false; }
+                else if (eat(open.back() == '{' ? '}' : ']')) open.pop_back();
+                else return ok = false;
             }
         }
-        while (p < e && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n' && *p != '\t' && *p != '\r') p++;   // number / true / false / null
-        return true;
     }
 };
+// ASCII-case-insensitive key match (encoding/json prefers an exact match and falls back to a case-insensitive one; the tags are unique
+// under folding, so the two rules pick the same field)
+bool key_is(const std::string &key, const char *name) {
+    const size_t n = std::strlen(name);
+    if (key.size() != n) return false;
+    for (size_t i = 0; i < n; i++) {
+        char a = key[i], b = name[i];
+        if (a >= 'A' && a <= 'Z') a = (char)(a - 'A' + 'a');
+        if (a != b) return false;
+    }
+    return true;
+}
 int b64v(char c) { return c >= 'A' && c <= 'Z' ? c - 'A' : c >= 'a' && c <= 'z' ? c - 'a' + 26 : c >= '0' && c <= '9' ? c - '0' + 52 : c == '+' ? 62 : c == '/' ? 63 : -1; }
 }  // namespace
 
@@ -203,7 +266,7 @@ int32_t mi_whir_element_shape(const mi_whir_proof *p, int which, uint64_t i, mi_
 }
 void mi_whir_limbs_to_fr(const uint64_t limbs[4], uint64_t out[4]) { reduce_mod_r(limbs, out); }
 int32_t mi_whir_reverse(const void *in, size_t n, size_t elem_bytes, void *out) {
-    if ((!in || !out) && n * elem_bytes) return MI_EINVAL;
+    if ((!in || !out) && n && elem_bytes) return MI_EINVAL;
     if (in == out) return MI_EINVAL;   // (the reference returns a fresh slice)
     for (size_t i = 0; i < n; i++) std::memcpy((char *)out + i * elem_bytes, (const char *)in + (n - 1 - i) * elem_bytes, elem_bytes);
     return MI_OK;
@@ -301,6 +364,13 @@ int32_t mi_whir_config_parse(const char *json, size_t len, mi_whir_config **out)
     auto fail = [&](int32_t rc) { mi_whir_config_free(c); return rc; };
     try {
         Js j{json, json + len};
+        if (j.lit("null")) {   // Unmarshal of a top-level null leaves the struct as it is
+            j.ws();
+            if (j.p != j.e) return fail(MI_EINVAL);
+            c->io_pattern = st->io_pattern.c_str();
+            *out = c;
+            return MI_OK;
+        }
         if (!j.eat('{')) return fail(MI_EINVAL);
         struct IntField { const char *name; int64_t *dst; } ints[] = {
             {"log_num_constraints", &c->log_num_constraints}, {"n_rounds", &c->n_rounds}, {"n_vars", &c->n_vars}, {"final_queries", &c->final_queries},
@@ -312,58 +382,72 @@ int32_t mi_whir_config_parse(const char *json, size_t len, mi_whir_config **out)
             std::string key;
             if (!j.str(key) || !j.eat(':')) return fail(MI_EINVAL);
             bool done = false;
-            for (auto &f : ints) if (key == f.name) { if (!j.integer(*f.dst)) return fail(MI_EINVAL); done = true; }
-            for (auto &f : lists) if (!done && key == f.name) {
+            for (auto &f : ints) if (!done && key_is(key, f.name)) { bool nul; if (!j.integer(*f.dst, &nul)) return fail(MI_EINVAL); done = true; }
+            for (auto &f : lists) if (!done && key_is(key, f.name)) {
                 done = true;
+                if (j.lit("null")) break;   // null: Go leaves the slice as it is
                 *f.n = 0;
-                if (j.eat('n')) { j.p += 3; break; }   // null: Go leaves the slice nil
                 if (!j.eat('[')) return fail(MI_EINVAL);
                 if (!j.eat(']')) for (;;) {
                     if (*f.n >= MI_WHIR_MAX_ROUNDS) return fail(MI_EINVAL);
-                    if (!j.integer(f.dst[(*f.n)++])) return fail(MI_EINVAL);
+                    int64_t v = 0; bool nul;
+                    if (!j.integer(v, &nul)) return fail(MI_EINVAL);   // (a null element is Go's zero value)
+                    f.dst[(*f.n)++] = v;
                     if (j.eat(',')) continue;
                     if (!j.eat(']')) return fail(MI_EINVAL);
                     break;
                 }
             }
-            if (!done && key == "domain_generator") {
-                std::string s;
-                if (!j.str(s)) return fail(MI_EINVAL);
-                if (!dec_to_u256(s, c->domain_generator)) return fail(MI_EINVAL);   // mt.go:310: big.Int SetString(s, 10)
+            if (!done && key_is(key, "domain_generator")) {
                 done = true;
-            }
-            if (!done && key == "io_pattern") { if (!j.str(st->io_pattern)) return fail(MI_EINVAL); done = true; }
-            if (!done && key == "transcript") {   // []byte: a JSON array of numbers (serde_json's Vec<u8>) or a base64 string
-                done = true;
-                st->transcript.clear();
-                j.ws();
-                if (j.p < j.e && *j.p == '"') {
+                if (!j.lit("null")) {
                     std::string s;
                     if (!j.str(s)) return fail(MI_EINVAL);
-                    unsigned acc = 0; int bits = 0;
-                    for (char ch : s) {
-                        if (ch == '=') break;
-                        const int v = b64v(ch);
-                        if (v < 0) return fail(MI_EINVAL);
-                        acc = (acc << 6) | (unsigned)v; bits += 6;
-                        if (bits >= 8) { bits -= 8; st->transcript.push_back((uint8_t)(acc >> bits)); acc &= (1u << bits) - 1; }
+                    if (!dec_to_u256(s, c->domain_generator)) return fail(MI_EINVAL);   // mt.go:310: big.Int SetString(s, 10)
+                }
+            }
+            if (!done && key_is(key, "io_pattern")) { done = true; if (!j.lit("null") && !j.str(st->io_pattern)) return fail(MI_EINVAL); }
+            if (!done && key_is(key, "transcript")) {   // []byte: a JSON array of numbers (serde_json's Vec<u8>), a base64 string, or null
+                done = true;
+                j.ws();
+                if (j.lit("null")) { }
+                else if (j.p < j.e && *j.p == '"') {
+                    st->transcript.clear();
+                    std::string s;
+                    if (!j.str(s)) return fail(MI_EINVAL);
+                    // base64.StdEncoding.DecodeString as encoding/json applies it: \r and \n are skipped, the rest must be whole padded quanta
+                    std::string b;
+                    for (char ch : s) if (ch != '\r' && ch != '\n') b += ch;
+                    if (b.size() % 4 != 0) return fail(MI_EINVAL);
+                    for (size_t q = 0; q < b.size(); q += 4) {
+                        int v[4], pad = 0;
+                        for (int k = 0; k < 4; k++) {
+                            const char ch = b[q + k];
+                            if (ch == '=') { if (q + 4 != b.size() || k < 2) return fail(MI_EINVAL); v[k] = 0; pad++; }
+                            else { if (pad) return fail(MI_EINVAL); v[k] = b64v(ch); if (v[k] < 0) return fail(MI_EINVAL); }
+                        }
+                        const unsigned w = ((unsigned)v[0] << 18) | ((unsigned)v[1] << 12) | ((unsigned)v[2] << 6) | (unsigned)v[3];
+                        st->transcript.push_back((uint8_t)(w >> 16));
+                        if (pad < 2) st->transcript.push_back((uint8_t)(w >> 8));
+                        if (pad < 1) st->transcript.push_back((uint8_t)w);
                     }
                 } else if (j.eat('[')) {
+                    st->transcript.clear();
                     if (!j.eat(']')) for (;;) {
-                        int64_t v;
-                        if (!j.integer(v) || v < 0 || v > 255) return fail(MI_EINVAL);
+                        int64_t v = 0; bool nul;
+                        if (!j.integer(v, &nul) || v < 0 || v > 255) return fail(MI_EINVAL);
                         st->transcript.push_back((uint8_t)v);
                         if (j.eat(',')) continue;
                         if (!j.eat(']')) return fail(MI_EINVAL);
                         break;
                     }
-                } else if (!j.skip()) return fail(MI_EINVAL);
+                } else return fail(MI_EINVAL);   // a number, an object, true / false: not a []byte
             }
-            if (!done && key == "statement_evaluations") {
+            if (!done && key_is(key, "statement_evaluations")) {
                 done = true;
-                st->evals.clear();
-                if (!j.eat('[')) { if (!j.skip()) return fail(MI_EINVAL); }
-                else if (!j.eat(']')) for (;;) {
+                if (j.lit("null")) { }
+                else if (!j.eat('[')) return fail(MI_EINVAL);
+                else if (st->evals.clear(), !j.eat(']')) for (;;) {
                     std::string s;
                     uint64_t v[4];
                     if (!j.str(s) || !dec_to_u256(s, v)) return fail(MI_EINVAL);   // mt.go:352: big.Int SetString(s, 10)
@@ -378,7 +462,8 @@ int32_t mi_whir_config_parse(const char *json, size_t len, mi_whir_config **out)
             if (!j.eat('}')) return fail(MI_EINVAL);
             break;
         }
-        if (!j.ok) return fail(MI_EINVAL);
+        j.ws();
+        if (!j.ok || j.p != j.e) return fail(MI_EINVAL);   // nothing but white space may follow the object
     } catch (...) { return fail(MI_ENOMEM); }
     c->io_pattern = st->io_pattern.c_str(); c->io_pattern_len = st->io_pattern.size();
     c->transcript = st->transcript.data(); c->n_transcript = st->transcript.size();

@@ -422,8 +422,17 @@ int32_t mi_batch_scalar_mul_g2_dev(mi_ctx *ctx, const mi_g2_affine *base, const 
  *   mi_whir_interner_decode     Interner{Values []Fp256}, main.go:74-76,146
  *   mi_whir_matrix_cells        the CSR -> MatrixCell loops of mt.go:358-401 (row i owns entries [row_indices[i], row_indices[i+1] - 1],
  *                               the last row runs to the end; value = LimbsToBigIntMod(interner[values[j]]))
- *   mi_whir_config_parse        json.Unmarshal into Config, main.go:41-58,115 (unknown keys ignored, missing keys zero; `transcript`
- *                               as a JSON array of numbers or a base64 string; decimal strings -> 4 x u64 limbs) ---- */
+ *   mi_whir_config_parse        json.Unmarshal into Config, main.go:41-58,115: unknown keys ignored, missing keys zero, null leaves a field as
+ *                               it is (a top-level null too), keys match ASCII-case-insensitively, the last duplicate wins; strict literals,
+ *                               numbers (no leading zeros; an int refuses fractions, exponents, values outside int64) and string escapes
+ *                               (an unpaired \uD800-\uDFFF escape becomes U+FFFD); nothing but white space may follow the object; nesting
+ *                               deeper than 10000 is refused.  `transcript` as a JSON array of numbers or a padded base64 string (\r, \n
+ *                               skipped); decimal strings -> 4 x u64 limbs.  Refused although Go would accept: more than
+ *                               MI_WHIR_MAX_ROUNDS list entries, a decimal string that is empty / not a number / >= 2^256 (Go keeps the string
+ *                               and fails later, mt.go:310,352).  Copied as they are although Go substitutes U+FFFD: invalid UTF-8 bytes
+ *                               inside a string.
+ * These readers take bytes an outside party wrote: they run under AddressSanitizer / UBSan with a mutation driver on every CPU test run
+ * (gnark-whir_amd/Makefile `sanitize`, tests/test_parsers_sanitized.py), together with mi_pk_raw_inspect. ---- */
 typedef struct mi_whir_proof mi_whir_proof;
 typedef struct mi_whir_shape { uint64_t n_leaves, tree_height, total_leaf_values; } mi_whir_shape;
 int32_t mi_whir_proof_decode(const uint8_t *buf, size_t len, mi_whir_proof **out, size_t *consumed_or_null);
