@@ -56,6 +56,7 @@ struct ShmHeader {
     uint64_t chunk;                   // bytes per ring slot
     std::atomic<uint32_t> attached;   // ranks that have mapped the segment
     std::atomic<uint32_t> poisoned;   // a rank hit a transport error: everyone waiting gives up at once
+    std::atomic<uint64_t> beat;       // rank 0 counts here while it waits for the others to attach: a segment whose count stands still has no creator any more
     ShmAg ag[SHM_MAX_WORLD];
     ShmRing ring[SHM_MAX_WORLD * SHM_MAX_WORLD];   // ring[src * world + dst]
 };
@@ -65,7 +66,7 @@ struct ShmLink {
     size_t map_bytes = 0;
     uint64_t ag_seq = 0;              // collectives of the all-gather area this rank has entered (all ranks in lockstep)
     int timeout_ms = 60000;
-    bool registered = false;          // the data area is pinned for the device (hipHostRegister)
+    std::vector<void *> registered;   // the ring regions pinned for the device (hipHostRegister): this rank's row and column
 };
 
 struct mi_group {
@@ -163,58 +164,87 @@ static int32_t shm_attach(mi_group *g, const uint8_t id[128]) {
     const size_t hdr = (sizeof(ShmHeader) + 4095) & ~(size_t)4095;
     const std::string name = shm_name_of(id);
     const Deadline dl(L.timeout_ms);
-    int fd = -1;
     if (rank == 0) {
         (void)shm_unlink(name.c_str());   // a leftover of a run that died before everyone had attached
-        fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        const int fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
         if (fd < 0) G_FAIL(g, MI_EHIP, "group: shm_open (create) failed");
         L.map_bytes = hdr + (size_t)W * W * nslot * chunk;   // tmpfs allocates a page when it is first touched: rings nobody uses cost nothing
         if (ftruncate(fd, (off_t)L.map_bytes) != 0) { close(fd); (void)shm_unlink(name.c_str()); G_FAIL(g, MI_ENOMEM, "group: ftruncate of the shared segment failed"); }
-    } else {
-        unsigned spins = 0;
-        for (;;) {
-            fd = shm_open(name.c_str(), O_RDWR, 0600);
-            if (fd >= 0) {
-                struct stat sb;
-                if (fstat(fd, &sb) == 0 && (size_t)sb.st_size >= hdr) { L.map_bytes = (size_t)sb.st_size; break; }   // sized: rank 0 is past ftruncate
-                close(fd); fd = -1;
-            }
-            if (dl.passed()) G_FAIL(g, MI_EHIP, "group: rank 0 never created the shared segment (timeout)");
-            shm_pause(spins);
-        }
-    }
-    void *m = mmap(nullptr, L.map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) { if (rank == 0) (void)shm_unlink(name.c_str()); G_FAIL(g, MI_ENOMEM, "group: mmap of the shared segment failed"); }
-    L.h = (ShmHeader *)m;
-    L.data = (unsigned char *)m + hdr;
-    if (rank == 0) {   // (a fresh tmpfs file reads as zeros: rings, sequence numbers and flags start at 0)
+        void *m = mmap(nullptr, L.map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { (void)shm_unlink(name.c_str()); G_FAIL(g, MI_ENOMEM, "group: mmap of the shared segment failed"); }
+        L.h = (ShmHeader *)m;
+        L.data = (unsigned char *)m + hdr;
+        // (a fresh tmpfs file reads as zeros: rings, sequence numbers and flags start at 0)
         L.h->world = (uint32_t)W; L.h->nslot = nslot; L.h->chunk = chunk;
         L.h->magic.store(SHM_MAGIC, std::memory_order_release);
     } else {
+        // The name may still point at the segment of an EARLIER group with the same id (a run that died before rank 0 unlinked it, or rank
+        // 0 of this run has not replaced it yet): its magic and shape look right.  A segment is this group's only if, once its magic shows,
+        // the NAME still leads to the same file -- rank 0 unlinks a leftover before it creates, and unlinks its own only after every rank
+        // (this one included) has attached.  Anything else is unmapped and the name is tried again until the deadline.
         unsigned spins = 0;
-        while (L.h->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
-            if (dl.passed()) G_FAIL(g, MI_EHIP, "group: the shared segment was never initialised (timeout)");
-            shm_pause(spins);
+        for (;;) {
+            if (dl.passed()) G_FAIL(g, MI_EHIP, "group: rank 0 never created (or initialised) the shared segment (timeout)");
+            const int fd = shm_open(name.c_str(), O_RDWR, 0600);
+            struct stat sb;
+            if (fd < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size < hdr) { if (fd >= 0) close(fd); shm_pause(spins); continue; }   // not there / not sized yet
+            const size_t bytes = (size_t)sb.st_size;
+            void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (m == MAP_FAILED) G_FAIL(g, MI_ENOMEM, "group: mmap of the shared segment failed");
+            ShmHeader *h = (ShmHeader *)m;
+            bool mine = false;
+            while (!dl.passed()) {
+                if (h->magic.load(std::memory_order_acquire) == SHM_MAGIC) {
+                    const int fd2 = shm_open(name.c_str(), O_RDWR, 0600);
+                    struct stat sb2;
+                    mine = fd2 >= 0 && fstat(fd2, &sb2) == 0 && sb2.st_ino == sb.st_ino && sb2.st_dev == sb.st_dev;
+                    if (fd2 >= 0) close(fd2);
+                    if (mine) {   // ... and its creator is alive: rank 0 counts h->beat while it waits for us (a leftover's stands still)
+                        const uint64_t b0 = h->beat.load(std::memory_order_acquire);
+                        const Deadline alive(L.timeout_ms < 1000 ? L.timeout_ms : 1000);
+                        while (h->beat.load(std::memory_order_acquire) == b0 && !alive.passed()) shm_pause(spins);
+                        mine = h->beat.load(std::memory_order_acquire) != b0;
+                    }
+                    break;
+                }
+                shm_pause(spins);
+            }
+            if (mine && (int)h->world == W && hdr + (size_t)W * W * h->nslot * h->chunk <= bytes) { L.h = h; L.data = (unsigned char *)m + hdr; L.map_bytes = bytes; break; }
+            (void)munmap(m, bytes);
+            if (mine) G_FAIL(g, MI_EINVAL, "group: the shared segment belongs to a group of another shape");
+            shm_pause(spins);   // a leftover: try the name again
         }
-        if ((int)L.h->world != W || hdr + (size_t)W * W * L.h->nslot * L.h->chunk > L.map_bytes) G_FAIL(g, MI_EINVAL, "group: the shared segment belongs to a group of another shape");
     }
     L.h->attached.fetch_add(1, std::memory_order_acq_rel);
     unsigned spins = 0;
     while ((int)L.h->attached.load(std::memory_order_acquire) < W) {
         if (dl.passed()) { if (rank == 0) (void)shm_unlink(name.c_str()); G_FAIL(g, MI_EHIP, "group: not every rank attached to the shared segment (timeout)"); }
+        if (rank == 0) L.h->beat.fetch_add(1, std::memory_order_release);
         shm_pause(spins);
     }
     if (rank == 0) (void)shm_unlink(name.c_str());
-    // the rings as pinned memory: copies to and from them run at the bus rate and do not stage a second time (best effort)
-    if (hipHostRegister(L.data, L.map_bytes - hdr, hipHostRegisterDefault) == hipSuccess) L.registered = true;
-    else (void)hipGetLastError();
+    // The rings THIS rank sources (row `rank`, contiguous) or sinks (column `rank`) as pinned memory: copies to and from them run at the
+    // bus rate and do not stage a second time (best effort).  Registering pins -- and therefore allocates -- every page it covers: the
+    // whole area would be W * W rings for every rank (256 MB at W = 8, 16 GB at 64), these are 2 W - 1.
+    {
+        const size_t ring_bytes = (size_t)L.h->nslot * L.h->chunk;
+        auto reg = [&](size_t first_ring, size_t n_rings) {
+            void *p = L.data + first_ring * ring_bytes;
+            if (hipHostRegister(p, n_rings * ring_bytes, hipHostRegisterDefault) == hipSuccess) L.registered.push_back(p);
+            else (void)hipGetLastError();
+        };
+        reg((size_t)rank * W, (size_t)W);
+        for (int s = 0; s < W; s++) if (s != rank) reg((size_t)s * W + rank, 1);
+    }
     return MI_OK;
 }
 static void shm_detach(mi_group *g) {
     ShmLink &L = g->shm;
     if (!L.h) return;
-    if (L.registered) (void)hipHostUnregister(L.data);
+    for (void *p : L.registered) (void)hipHostUnregister(p);
+    L.registered.clear();
     (void)munmap((void *)L.h, L.map_bytes);
     L.h = nullptr; L.data = nullptr;
 }

@@ -242,12 +242,24 @@ def scenario_dead_peer(B, rank, world, seed_hex):
         return {"ok": True, "seconds": round(dt, 3), "msg": str(e)[:200], "group_refuses_later_calls": broken}
 
 
+def scenario_stale_segment(B, rank, world, seed_hex):
+    """the test has left a segment of an EARLIER group under this id's name (magic, shape and a full `attached` count in place, no creator
+    alive): the ranks must find their own segment all the same"""
+    g = B.Group.rank(0, rank, world, uid_of(seed_hex, 0), transport=3)
+    try:
+        g.exchange_selftest(4096)
+        g.exchange_selftest((1 << 20) + 3)
+    finally:
+        g.close()
+    return {"ok": True}
+
+
 def main():
     scenario, seed_hex = sys.argv[1], sys.argv[2]
     rank, world = int(os.environ["MI_RANK"]), int(os.environ["MI_WORLD"])
     B = load_binding()
     try:
-        res = {"parity": scenario_parity, "inject": scenario_inject, "dead_peer": scenario_dead_peer}[scenario](B, rank, world, seed_hex)
+        res = {"parity": scenario_parity, "inject": scenario_inject, "dead_peer": scenario_dead_peer, "stale_segment": scenario_stale_segment}[scenario](B, rank, world, seed_hex)
     except BaseException as e:
         import traceback
         res = {"ok": False, "error": f"{type(e).__name__}: {e}", "trace": traceback.format_exc()[-1500:]}

@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(ROOT, "tests", "group_rank_worker.py")
 
 
-def _run(rank_launcher, scenario, world=2, env=None, timeout=420):
-    seed = os.urandom(16).hex()
+def _run(rank_launcher, scenario, world=2, env=None, timeout=420, seed=None):
+    seed = seed or os.urandom(16).hex()
     e = {"OMP_WAIT_POLICY": "passive", "OMP_NUM_THREADS": "8"}   # the oracle in every rank process: its OpenMP barriers under a CPU quota, see oracle/cref.py
     e.update(env or {})
     ranks = rank_launcher.run([sys.executable, WORKER, scenario, seed], world, env=e, timeout=timeout)
@@ -66,3 +66,28 @@ def test_dead_peer_is_a_timeout_not_a_hang(rank_launcher):
     rc0, j0, raw0 = res[0]
     assert rc0 == 0 and j0.get("ok"), f"{j0} {raw0['stderr'][-1500:]}"
     assert j0["seconds"] < 15 and "timeout" in j0["msg"] and j0["group_refuses_later_calls"]
+
+
+def test_a_leftover_segment_under_the_same_id_is_not_mistaken_for_the_groups_own(rank_launcher):
+    """a reused group id after a run that died before rank 0 unlinked its segment -- the leftover's magic and world match and
+    its attached counter already reads W.  The ranks tell it from their own by the name's inode and the creator's heartbeat."""
+    import hashlib
+    import struct
+    seed = os.urandom(16).hex()
+    h = hashlib.sha512((seed + ":0").encode()).digest()
+    uid = (h + h)[:128]
+    f = 1469598103934665603
+    for b in uid:
+        f = ((f ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    path = "/dev/shm/mi355x_grp_%016x" % f
+    world, nslot, chunk = 2, 4, 1 << 20
+    with open(path, "wb") as fh:   # magic | world | nslot | (pad) | chunk | attached | poisoned | beat: ShmHeader of csrc/group.hip
+        fh.write(struct.pack("<IIIIQIIQ", 0x6d693335, world, nslot, 0, chunk, world, 0, 12345))
+        fh.truncate((1 << 20) + world * world * nslot * chunk)
+    try:
+        res = _run(rank_launcher, "stale_segment", env={"MI_GROUP_TIMEOUT_MS": "20000"}, timeout=120, seed=seed)
+        for rc, j, raw in res:
+            assert rc == 0 and j.get("ok"), f"{j} {raw['stderr'][-1500:]}"
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)

@@ -2,7 +2,7 @@
 inputs with a BSB22 commitment (mi_prover_commit + mi_prover_submit_bsb22: the PoK MSM enqueued from a helper thread beside the proof)
 mixed -- every one compared with the proof a plain context computed alone, every commitment and PoK with the first one computed.
 Half the witnesses are UNIFORM wire values (13-15 digits per scalar in the four wire MSMs instead of the WHIR mix's ~4.4), so the rate
-printed here is well below bench.py's (22.8 against 31 proofs/s at 2^23; MI_POOL_EARLY_HANDOVER on or off makes no difference to it).
+printed here is well below bench.py's (22.8 against 31 proofs/s at 2^23).
 usage: python tools/soak_pool.py [log_n] [jobs] [in_flight]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
