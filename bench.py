@@ -844,13 +844,13 @@ def main():
             except Exception:
                 traffic = traffic_ntt = None
         # the level-1 kernel's own instruction-issue floor, from the committed ISA census of its code object (tools/isa_census.py ->
-        # profiles/r04_isa_census_accum_affine29.json: instructions per loop iteration by class x the measured cycles per wave64
+        # profiles/r05_isa_census_accum_affine29.json: instructions per loop iteration by class x the measured cycles per wave64
         # instruction of profiles/r02_probe_instr_rate.txt)
         issue_floor = census_src = None
         try:
-            cen = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_census_accum_affine29.json")))
+            cen = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_census_accum_affine29.json")))
             issue_floor = 2.4e9 / cen["cycles_per_addition"] * 64 * 1024
-            census_src = f"profiles/r04_isa_census_accum_affine29.json: {cen['valu_per_addition']} vector instructions per mixed addition ({cen['mad_u64_u32_per_addition']} v_mad_u64_u32) = {cen['cycles_per_addition']:.0f} cycles per wave-addition"
+            census_src = f"profiles/r05_isa_census_accum_affine29.json: {cen['valu_per_addition']} vector instructions per mixed addition ({cen['mad_u64_u32_per_addition']} v_mad_u64_u32) = {cen['cycles_per_addition']:.0f} cycles per wave-addition"
         except Exception:
             pass
         # roofline of the dominant kernel: achieved = the algorithmic 96 B per pair of ONE launch / that launch's duration.
@@ -868,6 +868,24 @@ def main():
             roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm", "basis": "in-job average launch (the solo Z-shaped launch did not run)",
                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": pmc_src,
                         "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes, "in_job": in_job}
+        # vector-ALU utilisation of the job: wave-instructions per proof (committed PMC pass SQ_INSTS_VALU over four proofs alone on one
+        # context, tools/prof_proof.py; setup kernels excluded) / step time / the 6.4e11 wave-instructions per second the chip sustains on
+        # this instruction mix (1024 SIMDs x 2.4 GHz / 3.84 cycles).  Reported only while the kernel sources the pass ran on are unchanged.
+        valu_util = None
+        try:
+            import csv
+            vfile = os.path.join(ROOT, "profiles", "r05_pmc_valu_proofs.csv")
+            setup = ("k_gen_", "k_xyzz_dbl_c", "k_xyzz_batch_to_affine", "k_xyzz_from_affine", "k_g1_to_rprime", "k_g2_to_rprime", "k_expand_points", "k_field_op", "k_pow_table",
+                     "k_tw_layout", "k_sc_layout", "k_msm2_precompute", "__amd_rocclr_fillBuffer")
+            tot = sum(float(r["Sum"]) for r in csv.DictReader(open(vfile)) if r["Counter"] == "SQ_INSTS_VALU" and not r["Kernel"].split("(")[0].replace("void ", "").startswith(setup))
+            per_proof = tot / 4.0
+            if log_n == 23 and args.dist == "whir" and traffic is not None and per_proof > 0:
+                valu_util = {"wave_instructions_per_proof": per_proof, "sustained_wave_instructions_per_s": 6.4e11, "source": "profiles/r05_pmc_valu_proofs.csv (committed pass, not this run)",
+                             "on_the_callers_path": per_proof / (dt / args.steps) / 6.4e11,
+                             "hbm_resident_inputs": None if dev_ms is None else per_proof / (dev_ms * 1e-3) / 6.4e11,
+                             "note": "an instruction-count figure: multiply-accumulate-heavy kernels (level 1: 4.43 cycles per instruction by the ISA census) weigh more than the 3.84-cycle average"}
+        except Exception:
+            valu_util = None
         line = {
             "metric": "Groth16 proofs/sec for WHIR-verifier circuit (2^20 poly); G1 MSM pts/sec",
             "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -930,7 +948,9 @@ def main():
                      "note": "one XYZZ mixed addition = 8M + 2S Fp products (+ ~7 add/sub); frac = kernel_modmul_per_s / modmul_ceiling_per_s",
                      # the kernel's OWN instruction mix allows a SIMD 2.4e9 / cycles_per_addition wave-additions/s: the kernel alone on the GPU against that floor
                      "issue_floor_adds_per_s": issue_floor, "issue_floor_source": census_src,
-                     "kernel_alone_frac_of_issue_floor": None if issue_floor is None else solo["mixed_adds_per_s"] / issue_floor},
+                     "kernel_alone_frac_of_issue_floor": None if issue_floor is None else solo["mixed_adds_per_s"] / issue_floor,
+                     "z_shaped_launch_alone_frac_of_issue_floor": None if issue_floor is None or not zsolo or "mixed_adds_per_s" not in zsolo else zsolo["mixed_adds_per_s"] / issue_floor,
+                     "job_utilisation": valu_util},
         }
         if cpu_inputs is not None:
             line["cpu_baseline"] = cpu_baseline(*cpu_inputs, rs[0], rs[1], (ped_basis, ped_sigma, values, rs[2]) if n_committed else None, log_n, serial_bytes)

@@ -371,6 +371,7 @@ static u32 auto_c(u32 n) {
     if (c > 16) c = 16;
     return (u32)c;
 }
+static u32 msm_auto_seg(u32 nbuckets) { return nbuckets >= (1u << 16) ? 16u : nbuckets >= 256 ? 8u : 2u; }
 static MsmShape slot_shape(const MsmSlot &sl) { return msm_shape(sl.n, sl.c, sl.G); }
 // shape of the key space the accumulate / reduce stages see: nwin_keys windows of 2^(c-1) buckets
 static MsmShape key_shape(const MsmSlot &sl) {
@@ -712,7 +713,10 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     const MsmShape s = key_shape(srt);
     const u32 n = s.n;
     const u32 L1 = kn->L1 ? kn->L1 : 16, L2 = kn->L2 ? kn->L2 : 8;   // tools/tune.py sweep, N = 2^23
-    const u32 seg = kn->seg ? kn->seg : (s.nbuckets >= 256 ? 8 : 2);
+    // buckets per bucket-reduce thread: a thread spends 2 seg additions on its segment and ~19 addition-equivalents on the multiple of its
+    // running sum by the segment's base, so the one big bucket set of a fixed-base MSM (2^16 .. 2^21 buckets) wants the longer segment
+    // (same-box A/B at N = 2^23: 16 against 8 +0.6 % proofs/s in 7 of 9 pairs; 32 equal, 64 and 4 slower)
+    const u32 seg = kn->seg ? kn->seg : msm_auto_seg(s.nbuckets);
     const u64 T_bound = srt.entries_cap;   // nwin * n, or the counted number of entries (msm2_sort_enqueue, exact)
     hipStream_t st = acc.stream;
     if (&srt != &acc) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, srt.ev[0], 0));
@@ -855,7 +859,7 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
         if (wait_ev) MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.stream, wait_ev, 0));
         MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
         MI_CHECK_HIP(ctx, hipMemsetAsync(sl.buf[B_BUCKET].p, 0, (size_t)s.nkeys * ops.xyzz_bytes + 64, sl.stream));
-        sl.tail_seg = knobs_of(ctx)->seg ? knobs_of(ctx)->seg : (s.nbuckets >= 256 ? 8 : 2);
+        sl.tail_seg = knobs_of(ctx)->seg ? knobs_of(ctx)->seg : msm_auto_seg(s.nbuckets);
         sl.entries_src = (const u32 *)((const char *)sl.buf[B_BUCKET].p + (size_t)s.nkeys * ops.xyzz_bytes);   // a zeroed word: no entries
         sl.timed = false;
         sl.deferred = true;
@@ -1020,6 +1024,10 @@ int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value) {
     else if (is("finisher") && (value == 0 || value == 1)) k->finisher = (u32)value;
     else if (is("finisher_max") && value >= 0 && value <= (1 << 20)) k->finisher_max = (u32)value;
     else if (is("l1_stream") && (value == 0 || value == 1)) k->l1_stream = (u32)value;
+    else if (is("item_l1") && (value == 0 || (value >= 2 && value <= 64))) k->L1 = (u32)value;     // entries per level-1 item (0 = 16)
+    else if (is("item_l2") && (value == 0 || (value >= 2 && value <= 64))) k->L2 = (u32)value;     // partial sums per item of the later levels (0 = 8)
+    else if (is("reduce_seg") && value >= 0 && value <= 256) k->seg = (u32)value;                    // buckets per bucket-reduce thread (0 = 8)
+    else if (is("hold_accum") && (value == 0 || value == 1)) ctx->hold_accum = (uint32_t)value;   // = mi_debug_set_prove_schedule
     else if (is("finisher_min_level") && value >= 0 && value <= 16) k->finisher_min_level = (u32)value;
     else if (mi_ntt_set_knob(ctx, name, value)) return MI_OK;
     else MI_FAIL(ctx, MI_EINVAL, std::string("mi_debug_set_knob: unknown knob or value out of range: ") + name);

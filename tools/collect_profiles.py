@@ -1,4 +1,4 @@
-"""Turns the raw outputs of the round's final measurement run (gpurun_out/r4_*, tools/final_measure.sh) into the committed summaries under
+"""Turns the raw outputs of the round's final measurement run (gpurun_out/r5_*, tools/final_measure.sh) into the committed summaries under
 profiles/.  usage: python tools/collect_profiles.py"""
 import glob
 import hashlib
@@ -21,48 +21,70 @@ def db(d):
     return glob.glob(G + d + "/**/*_results.db", recursive=True)[0]
 
 
+def short(kernel_name):
+    """'void k_msm_accum_affine29<4, 3>(Affine<...> const*, ...)' -> 'k_msm_accum_affine29' (template arguments and the signature dropped)"""
+    k = kernel_name.split("(")[0].replace("void ", "")
+    return k.split("<")[0] if k.startswith(("k_msm_accum_affine29", "k_msm_accum_affine_g2_29")) else k
+
+
 def sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-for src, dst in ((G + "r4_bench_final.log", "profiles/r04_bench_line_final.json"), (G + "r4_prof_def.log", "profiles/r04_bench_line_profiled_default.json"),
-                 (G + "r4_prof_if1.log", "profiles/r04_bench_line_profiled_inflight1.json"), (G + "r4_bench26_final.log", "profiles/r04_bench_line_N2p26.json"),
-                 (G + "r4_rehearse2.log", "profiles/r04_bench_line_rehearsal_2ranks_one_gpu.json")):
+for src, dst in ((G + "r5_bench_final.log", "profiles/r05_bench_line_final.json"), (G + "r5_prof_def.log", "profiles/r05_bench_line_profiled_default.json"),
+                 (G + "r5_prof_if1.log", "profiles/r05_bench_line_profiled_inflight1.json"), (G + "r5_bench26_final.log", "profiles/r05_bench_line_N2p26.json"),
+                 (G + "r5_rehearse2.log", "profiles/r05_bench_line_rehearsal_2ranks_one_gpu.json")):
     if not os.path.exists(src):
         print("missing", src); continue
     l = line(src); open(dst, "w").write(l); d = json.loads(l)
     print(dst, {k: round(d[k], 3) if isinstance(d.get(k), float) else d.get(k) for k in ("value", "ms_per_step", "value_hbm_resident_inputs", "single_proof_latency_ms", "single_proof_latency_host_inputs_ms", "hbm_in_use_gb")},
           "launch_ms", round(d["roofline"]["launch_ms"], 2), "frac", round(d["roofline"]["frac"], 4), "ntt frac", round(d["roofline_ntt"]["frac"], 4))
-for d_, out in (("r4_prof_def", "profiles/r04_kernel_stats_default.csv"), ("r4_prof_if1", "profiles/r04_kernel_stats_inflight1.csv")):
+for d_, out in (("r5_prof_def", "profiles/r05_kernel_stats_default.csv"), ("r5_prof_if1", "profiles/r05_kernel_stats_inflight1.csv")):
     if os.path.isdir(G + d_):
         subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "stats", db(d_), out], stdout=subprocess.DEVNULL)
-if os.path.isdir(G + "r4_pmc_fetch") and os.path.isdir(G + "r4_pmc_write"):
+if os.path.isdir(G + "r5_pmc_fetch") and os.path.isdir(G + "r5_pmc_write"):
     out = {}
-    for name, d_ in (("FETCH_SIZE", "r4_pmc_fetch"), ("WRITE_SIZE", "r4_pmc_write")):
+    for name, d_ in (("FETCH_SIZE", "r5_pmc_fetch"), ("WRITE_SIZE", "r5_pmc_write")):
         c = sqlite3.connect(db(d_))
         agg = defaultdict(lambda: [set(), 0.0])
         for k, did, v in c.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=?", (name,)):
-            k = k.split("(")[0]; agg[k][0].add(did); agg[k][1] += v
+            k = short(k); agg[k][0].add(did); agg[k][1] += v
         out[name] = {k: {"launches": len(v[0]), "kb_total": v[1], "kb_per_launch": v[1] / len(v[0])} for k, v in agg.items()}
     csrc = os.path.join(ROOT, "gnark-whir_amd", "csrc")
     out["_sources"] = {f: sha16(os.path.join(csrc, f)) for f in ("msm.hip", "msm_g1.hip", "msm_core.cuh", "msm2_core.cuh", "curve29.cuh", "field29.cuh", "ntt.hip", "ntt_tile.cuh", "ntt_wave.cuh", "field.cuh")}
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-resident "
-                    "--sharded-msm-log-n 0 --sharded-prove-log-n 0 --n-committed 0` (no commitment: the per-launch averages are those of the proof's own MSMs), N=2^23, final round-4 code (_sources: sha256[:16] of the kernel sources the passes ran on; bench.py withholds "
+                    "--sharded-msm-log-n 0 --sharded-prove-log-n 0 --n-committed 0` (no commitment: the per-launch averages are those of the proof's own MSMs), N=2^23, final round-5 code (_sources: sha256[:16] of the kernel sources the passes ran on; bench.py withholds "
                     "`traffic` when they differ); KB as rocprofv3 reports them, summed over the counter's dimensions; FETCH_SIZE raw (64-B gathers need no correction; 16-B-per-lane streams need x2)")
-    json.dump(out, open("profiles/r04_pmc_bench_traffic.json", "w"), indent=1)
+    if os.path.isdir(G + "r5_pmc_solo_fetch") and os.path.isdir(G + "r5_pmc_solo_write"):   # the solo Z-shaped launch (tools/solo_z_msm.py): the roofline line's basis
+        solo = {}
+        for name, d_ in (("FETCH_SIZE", "r5_pmc_solo_fetch"), ("WRITE_SIZE", "r5_pmc_solo_write")):
+            c = sqlite3.connect(db(d_))
+            tot, ids = 0.0, set()
+            for k, did, v in c.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=?", (name,)):
+                if short(k) == "k_msm_accum_affine29":
+                    tot += v; ids.add(did)
+            solo[name + "_kb"] = tot / max(1, len(ids)); solo["launches_" + name] = len(ids)
+        solo["what"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 tools/solo_z_msm.py 23 2`: KB per launch of k_msm_accum_affine29 (the Z-shaped fixed-base MSM alone on the GPU)"
+        out["solo_z"] = solo
+    json.dump(out, open("profiles/r05_pmc_bench_traffic.json", "w"), indent=1)
     for k in ("k_msm_accum_affine29", "k_ntt_pass_wave", "k_msm2_scatter2_staged"):
         if k not in out["FETCH_SIZE"]:
             continue
         print(k, "fetch MB/launch", round(out["FETCH_SIZE"][k]["kb_per_launch"] / 1e3, 1), "write", round(out["WRITE_SIZE"].get(k, {"kb_per_launch": 0})["kb_per_launch"] / 1e3, 1))
-if os.path.isdir(G + "r4_pmc_valu"):
-    subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "pmc", db("r4_pmc_valu"), "profiles/r04_pmc_valu_proofs.csv"], stdout=subprocess.DEVNULL)
-rows = []
-for nc in (0, 65536, 262144, 1048576):
-    p = G + f"r4_nc_{nc}.log"
-    if os.path.exists(p):
-        d = json.loads(line(p))
-        rows.append(f"n_committed {nc:8d}: value {d['value']:.2f} proofs/s ({d['proof_bytes']} B), HBM-resident {d['value_hbm_resident_inputs']:.2f}, "
-                    f"single proof from host {d['single_proof_latency_host_inputs_ms']:.2f} ms, Commit alone {d['pedersen_commit_latency_ms'] or 0:.2f} ms")
-if rows:
-    open("profiles/r04_n_committed.txt", "w").write("bench.py --no-cpu-baseline --sharded-msm-log-n 0 --sharded-prove-log-n 0 --n-committed X   (N = 2^23, one box, same run set)\n" + "\n".join(rows) + "\n")
-    print("\n".join(rows))
+if os.path.isdir(G + "r5_pmc_valu"):
+    subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "pmc", db("r5_pmc_valu"), "profiles/r05_pmc_valu_proofs.csv"], stdout=subprocess.DEVNULL)
+p = G + "r5_bench_final.log"
+if os.path.exists(p):
+    d = json.loads(line(p))
+    sens = d.get("sensitivity")
+    if sens:
+        g1 = d["g1_msm_solo"]
+        rows = [f"witness `whir`         (45 % {{0,1}} / 25 % bytes / 5 % 64-bit / 25 % uniform): value {d['value']:.2f} proofs/s, HBM-resident {d['value_hbm_resident_inputs']:.2f}, "
+                f"single proof {d['single_proof_latency_ms']:.2f} ms"]
+        for key in ("half_uniform", "uniform"):
+            x = sens[key]
+            rows.append(f"witness `{key}`".ljust(22) + f": value {x['value']:.2f} proofs/s, HBM-resident {x['value_hbm_resident_inputs']:.2f}, single proof {x['single_proof_latency_ms']:.2f} ms, "
+                        f"G1 level-1 additions per proof {x['g1_level1_additions_per_proof'] / 1e6:.1f} M")
+        open("profiles/r05_scalar_mix.txt", "w").write("the `sensitivity` block of profiles/r05_bench_line_final.json (python bench.py, defaults: N = 2^23, three proofs in flight, the step = Commit + host-input prove "
+                                                        "with the PoK; same key, same box, same run; every proof compared with its leg's reference proof)\n" + "\n".join(rows) + "\n")
+        print("\n".join(rows))
