@@ -26,8 +26,11 @@ __global__ void __launch_bounds__(64, AccumWaves<F>::value) k_msm_accum_xyzz(con
     for (u32 item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += stride)
         msm_accum_xyzz_body<F>(partial_in, start, cnt, items, item_start, nkeys, L, bucket, partial_out, item);
 }
+// (G1: three waves per SIMD = 168 VGPRs, the slot a retired level-1 workgroup leaves; the compiler's own choice was 170)
+template <class F> struct ReduceWaves { static constexpr int value = 3; };
+template <> struct ReduceWaves<Fp2> { static constexpr int value = 1; };
 template <class F>
-__global__ void __launch_bounds__(64) k_msm_bucket_reduce(const XYZZ<F> *bucket, u32 nbuckets, u32 seg, u32 tb, XYZZ<F> *out) {
+__global__ void __launch_bounds__(64, ReduceWaves<F>::value) k_msm_bucket_reduce(const XYZZ<F> *bucket, u32 nbuckets, u32 seg, u32 tb, XYZZ<F> *out) {
     u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < tb) msm_bucket_reduce_body<F>(bucket, nbuckets, seg, out, blockIdx.y, t);
 }

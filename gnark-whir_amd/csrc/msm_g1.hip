@@ -133,8 +133,10 @@ struct FinG1rp {
 };
 static void launch_finish_g1(hipStream_t st, unsigned nb_small, unsigned nb_big, void *partials, const u32 *list_small, const u32 *list_big, const u32 *counters,
                              const u32 *item_start, const u32 *items, void *bucket, u32 rp) {
-    if (rp) launch_finish_form<FinG1rp, G1X, 256, 1>(st, nb_small, nb_big, partials, list_small, list_big, counters, item_start, items, bucket);
-    else launch_finish_form<FinStd<Fp>, G1X, 256, 1>(st, nb_small, nb_big, partials, list_small, list_big, counters, item_start, items, bucket);
+    // (three waves per SIMD = 168 VGPRs: a finisher workgroup fits where ONE four-wave level-1 workgroup has retired; with the compiler's
+    //  free choice -- 208 -- it waited for a larger hole: 2.6 ms per launch inside the job, rocprofv3)
+    if (rp) launch_finish_form<FinG1rp, G1X, 256, 3>(st, nb_small, nb_big, partials, list_small, list_big, counters, item_start, items, bucket);
+    else launch_finish_form<FinStd<Fp>, G1X, 256, 3>(st, nb_small, nb_big, partials, list_small, list_big, counters, item_start, items, bucket);
 }
 __global__ void k_g1_to_rprime(G1Aff *dst, const G1Aff *src, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -5,7 +5,7 @@ rounds=${1:-2}; shift
 for r in $(seq 1 $rounds); do
   for v in A B; do
     if [ $v = B ]; then export MI355X_GROTH16_LIB=$PWD/gnark-whir_amd/build_ab/libab.so; else unset MI355X_GROTH16_LIB; fi
-    timeout -k 10 200 python bench.py --no-cpu-baseline --sharded-msm-log-n 0 --steps 20 "$@" > gpurun_out/ab_$v$r.log 2>&1 || exit 1
+    timeout -k 10 200 python bench.py --no-cpu-baseline --sharded-msm-log-n 0 --sharded-prove-log-n 0 --no-sensitivity --steps 24 "$@" > gpurun_out/ab_$v$r.log 2>&1 || exit 1
     python - <<PY
 import json
 l = json.loads(open("gpurun_out/ab_$v$r.log").read().strip().splitlines()[-1])
