@@ -392,6 +392,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=23, help="FFT domain (2^23 = BASELINE configs[1])")
     ap.add_argument("--dist", choices=["whir", "half", "uniform"], default="whir",
                     help="witness (W, a) distribution: the WHIR mix of SURVEY 8d (a documented guess), uniform Fr, or half of each (row by row)")
+    ap.add_argument("--no-solo-legs", action="store_true", help="skip the solo MSM / computeH / probe legs after the proofs (PMC passes: their launches would mix into the per-kernel averages); the roofline line then falls back to the in-job launch")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the `sensitivity` legs (the same key proved with a half-uniform and a uniform witness)")
     ap.add_argument("--knobs", default="", help="tuning: name=value,... for mi_debug_set_knob on every context of the pool (include/mi355x_groth16.h lists the names)")
     ap.add_argument("--n-committed", type=int, default=-1,
@@ -700,7 +701,7 @@ def main():
             raise SystemExit(f"bench.py: an HBM-resident proof of the `{dist}` sensitivity leg differs from its reference proof")
         for d in (W2, a2, b2, c2):
             d.free()
-        return {"value": rate, "value_hbm_resident_inputs": rate_dev, "single_proof_latency_ms": lat, "g1_level1_additions_per_proof": int(st1["g1_accum_entries"]),
+        return {"value": rate, "value_hbm_resident_inputs": rate_dev, "single_proof_latency_ms": lat, "g1_level1_additions_per_proof": int(st1["g1_level1_additions"]),
                 "proofs_validated": 2 * args.steps}
     sensitivity = None
     if rank == 0 and world == 1 and not args.no_sensitivity and args.dist == "whir":
@@ -725,8 +726,8 @@ def main():
         hbm_ledger["bench_inputs_gb"] = (nb_wires + 3 * n_constraints) * 32 / 1e9
         hbm_ledger["bench_key_source_arrays_gb"] = (N * 64 if not args.no_limb29 else (na + nb + nk + N) * 64 + nb * 128) / 1e9   # what bench.py itself still holds of the generated bases
     # the same kernel measured alone (no other stream competing for the CUs): one uniform-scalar G1 MSM over pk.G1.Z
-    solo = None
-    if rank == 0:
+    solo = {"skipped": "--no-solo-legs", "pairs": 0, "msm_total_ms": 0.0, "accum_launch_ms": 0.0, "accum_GBps_algorithmic": 0.0, "mixed_adds_per_s": 0.0, "msm_pts_per_s": 0.0}
+    if rank == 0 and not args.no_solo_legs:
         ctx.msm_g1_dev(g1z.ptr, b.ptr, n_constraints)   # sizes the generic path's workspaces (the proofs above used the fixed-base tables)
         ctx.msm_g1_dev(g1z.ptr, b.ptr, n_constraints)
         st = ctx.stats()
@@ -738,7 +739,7 @@ def main():
     # A solo launch is a basis a better schedule cannot lower: inside the job the same launch shares the CUs with whatever runs beside it,
     # and the more evenly it shares the longer it takes (rounds 1-4 quoted that in-job duration; it stays in the line as `in_job`).
     zsolo = None
-    if rank == 0:
+    if rank == 0 and not args.no_solo_legs:
         try:
             cz = ctx.pk_table_plan(pkh)[2]
             n_z = N - 1

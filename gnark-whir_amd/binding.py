@@ -78,7 +78,7 @@ class Stats(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("h2d_ms", "compute_h_ms", "filter_ms", "msm_a_ms", "msm_b1_ms", "msm_k_ms",
                                          "msm_z_ms", "msm_b2_ms", "assemble_ms", "total_ms")] + [
         ("g1_accum_kernel_ms", C.c_float), ("g1_accum_pairs", C.c_uint64), ("g1_accum_launches", C.c_uint32),
-        ("ntt_kernel_ms", C.c_float), ("ntt_elems", C.c_uint64), ("ntt_launches", C.c_uint32), ("g1_accum_entries", C.c_uint64)]
+        ("ntt_kernel_ms", C.c_float), ("ntt_elems", C.c_uint64), ("ntt_launches", C.c_uint32), ("g1_accum_entries", C.c_uint64), ("g1_level1_additions", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -803,6 +803,7 @@ static int32_t msm_finish(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, void
         ctx->stats.g1_accum_launches += 1;
         ctx->stats.g1_accum_entries += *(const u32 *)((const char *)sl.host_wsum + 128 * 256);
     }
+    if (ops.xyzz_bytes == 128) ctx->stats.g1_level1_additions += *(const u32 *)((const char *)sl.host_wsum + 128 * 256);   // every G1 MSM, timed or not
     sl.active = false;
     return MI_OK;
 }

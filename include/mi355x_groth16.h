@@ -108,6 +108,9 @@ typedef struct mi_stats {
     uint64_t ntt_elems;             /* elements transformed (N per size-N transform)          */
     uint32_t ntt_launches;
     uint64_t g1_accum_entries;      /* non-zero digits = mixed additions those launches performed     */
+    /* (a prove times the level-1 launches of A and Z only -- B1 and K share a stream, so a bracket around one may hold kernels of the
+     *  other: the four g1_accum_* fields above cover those two launches) */
+    uint64_t g1_level1_additions;   /* mixed additions of ALL G1 level-1 launches of the call (A, B1, K, Z), timed or not */
 } mi_stats;
 
 /* ---- lifecycle ---- */

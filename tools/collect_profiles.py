@@ -53,7 +53,7 @@ if os.path.isdir(G + "r5_pmc_fetch") and os.path.isdir(G + "r5_pmc_write"):
     csrc = os.path.join(ROOT, "gnark-whir_amd", "csrc")
     out["_sources"] = {f: sha16(os.path.join(csrc, f)) for f in ("msm.hip", "msm_g1.hip", "msm_core.cuh", "msm2_core.cuh", "curve29.cuh", "field29.cuh", "ntt.hip", "ntt_tile.cuh", "ntt_wave.cuh", "field.cuh")}
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-resident "
-                    "--sharded-msm-log-n 0 --sharded-prove-log-n 0 --n-committed 0` (no commitment: the per-launch averages are those of the proof's own MSMs), N=2^23, final round-5 code (_sources: sha256[:16] of the kernel sources the passes ran on; bench.py withholds "
+                    "--sharded-msm-log-n 0 --sharded-prove-log-n 0 --no-sensitivity --no-solo-legs --n-committed 0` (no commitment: the per-launch averages are those of the proof's own MSMs), N=2^23, final round-5 code (_sources: sha256[:16] of the kernel sources the passes ran on; bench.py withholds "
                     "`traffic` when they differ); KB as rocprofv3 reports them, summed over the counter's dimensions; FETCH_SIZE raw (64-B gathers need no correction; 16-B-per-lane streams need x2)")
     if os.path.isdir(G + "r5_pmc_solo_fetch") and os.path.isdir(G + "r5_pmc_solo_write"):   # the solo Z-shaped launch (tools/solo_z_msm.py): the roofline line's basis
         solo = {}
