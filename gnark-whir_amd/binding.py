@@ -29,7 +29,7 @@ EXPORTS = [
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
     "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22", "mi_prover_trim", "mi_ctx_trim",
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_create_rank_ex", "mi_group_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
-    "mi_group_last_error", "mi_group_transport", "mi_group_set_lead_share", "mi_group_wire_range", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
+    "mi_group_last_error", "mi_group_transport", "mi_group_set_lead_share", "mi_group_wire_range", "mi_group_set_sharded_compute_h", "mi_compute_h_sharded_dev", "mi_groth16_prove_sharded_slices_dev", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
     "mi_groth16_prove_sharded", "mi_groth16_prove_sharded_dev", "mi_pk_load_sharded_dev", "mi_msm_g1_sharded", "mi_msm_g2_sharded",
     "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
     "mi_pk_raw_inspect", "mi_pk_load_raw",
@@ -547,6 +547,15 @@ class Group:
         self._ck(self.lib.mi_group_wire_range(self.h, C.c_uint64(nb_wires), C.c_int(rank), C.byref(lo), C.byref(hi)))
         return int(lo.value), int(hi.value)
 
+    def set_sharded_compute_h(self, on=True):
+        self._ck(self.lib.mi_group_set_sharded_compute_h(self.h, C.c_uint32(1 if on else 0)))
+
+    def compute_h_sharded_dev(self, log_n, a_ptrs, b_ptrs, c_ptrs, n_constraints, h_ptrs):
+        """computeH over the ranks: per LOCAL rank device pointers to its rows of a, b (c_ptrs None: c = a o b) and to its M-element h slice"""
+        arr = lambda ps: (C.c_void_p * len(ps))(*[C.c_void_p(int(p)) for p in ps])
+        self._ck(self.lib.mi_compute_h_sharded_dev(self.h, C.c_uint32(log_n), arr(a_ptrs), arr(b_ptrs), None if c_ptrs is None else arr(c_ptrs),
+                                                   C.c_size_t(n_constraints), arr(h_ptrs)))
+
     def exchange_selftest(self, nbytes=4096):
         self._ck(self.lib.mi_group_exchange_selftest(self.h, C.c_size_t(nbytes)))
 
@@ -595,6 +604,14 @@ class Group:
         ww = (C.c_void_p * len(W_ptrs))(*[int(p) for p in W_ptrs])
         self._ck(self.lib.mi_groth16_prove_sharded_dev(self.h, spk, ww, C.c_size_t(n_wires), _p(a_ptr), _p(b_ptr), _p(c_ptr), C.c_size_t(n_constraints),
                                                        _p(r), _p(s), C.c_uint32(mode), _p(out), C.byref(st)))
+        return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
+
+    def prove_slices_dev(self, spk, W_ptrs, n_wires, a_ptrs, b_ptrs, c_ptrs, n_constraints, r, s, mode=0):
+        """computeH over the ranks: a_ptrs[i] / b_ptrs[i] / c_ptrs[i] = local rank i's ROWS of a, b, c on its device (c_ptrs None: c = a o b)"""
+        out = np.zeros(32, np.uint64); st = Stats(); r, s = _u64(r), _u64(s)
+        arr = lambda ps: (C.c_void_p * len(ps))(*[C.c_void_p(int(p)) for p in ps])
+        self._ck(self.lib.mi_groth16_prove_sharded_slices_dev(self.h, spk, arr(W_ptrs), C.c_size_t(n_wires), arr(a_ptrs), arr(b_ptrs), None if c_ptrs is None else arr(c_ptrs),
+                                                              C.c_size_t(n_constraints), _p(r), _p(s), C.c_uint32(mode), _p(out), C.byref(st)))
         return {"ar": out[:8].copy(), "bs": out[8:24].copy(), "krs": out[24:].copy(), "raw": out}, st.as_dict()
 
     def msm_g1(self, pts, sc, flags=0, mode=0):

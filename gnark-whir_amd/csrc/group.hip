@@ -33,6 +33,7 @@
 //                  enters an exchange or every rank returns an error (its own, or "another rank failed") and its MSM slots are drained.
 #include "prove_internal.h"
 #include "msm_curve_ops.h"
+#include "ntt_cross.h"
 #include <rccl/rccl.h>
 #include <atomic>
 #include <chrono>
@@ -81,6 +82,12 @@ struct mi_group {
     std::vector<hipEvent_t> ev_x, ev_in, ev_done, ev_h;
     std::vector<DevBuf> recv;      // per local rank: bucket slices received from the other ranks
     std::vector<DevBuf> stage;     // per local rank: small staging area for the all-gathers (transport 1)
+    // computeH over the ranks (compute_h_sharded): per local rank the cross-rank tables, three slice vectors + the exchange area + the h
+    // slice with one slot in front (the previous rank's last coefficient: the Z cut of a sharded key starts one element early), two events
+    bool sharded_h = false;        // mi_group_set_sharded_compute_h: mi_groth16_prove_sharded runs computeH over all ranks
+    std::vector<CrossNttTables> xt;
+    std::vector<DevBuf> hx[3], hy, hh;
+    std::vector<hipEvent_t> ev_c0, ev_c1;
     uint32_t lead_share = 0xffffffffu;   // permille of an even wire share that rank 0 -- which also runs computeH -- takes (mi_group_set_lead_share; all ones = automatic)
     int timeout_ms = 60000;        // how long a rank waits for its peers without anything completing (MI_GROUP_TIMEOUT_MS; both transports)
     bool nonblocking = false;      // transport 1, one rank per process: the communicator is non-blocking and every wait on it is a deadline poll
@@ -525,8 +532,12 @@ static int32_t group_finish_init(mi_group *g) {
     const int n = g->n_local();
     g->xs.assign(n, nullptr); g->ev_x.assign(n, nullptr); g->ev_in.assign(n, nullptr); g->ev_done.assign(n, nullptr); g->ev_h.assign(n, nullptr);
     g->recv.assign(n, DevBuf{}); g->stage.assign(n, DevBuf{});
+    g->xt.assign(n, CrossNttTables{}); g->hy.assign(n, DevBuf{}); g->hh.assign(n, DevBuf{}); g->ev_c0.assign(n, nullptr); g->ev_c1.assign(n, nullptr);
+    for (auto &v : g->hx) v.assign(n, DevBuf{});
     for (int i = 0; i < n; i++) {
         (void)hipSetDevice(g->dev[i]);
+        G_HIP(g, hipEventCreateWithFlags(&g->ev_c0[i], hipEventDisableTiming));
+        G_HIP(g, hipEventCreateWithFlags(&g->ev_c1[i], hipEventDisableTiming));
         G_HIP(g, hipStreamCreateWithFlags(&g->xs[i], hipStreamNonBlocking));
         G_HIP(g, hipEventCreateWithFlags(&g->ev_x[i], hipEventDisableTiming));
         G_HIP(g, hipEventCreateWithFlags(&g->ev_in[i], hipEventDisableTiming));
@@ -548,6 +559,9 @@ int32_t mi_group_destroy(mi_group *g) {
         //  communicator neither call holds this thread)
         if (i < (int)g->comm.size() && g->comm[i]) (void)(g->broken ? ncclCommAbort(g->comm[i]) : ncclCommDestroy(g->comm[i]));
         for (auto *v : {&g->ev_x, &g->ev_in, &g->ev_done, &g->ev_h}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
+        for (auto *v : {&g->ev_c0, &g->ev_c1}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
+        for (auto *v : {&g->hx[0], &g->hx[1], &g->hx[2], &g->hy, &g->hh}) if (i < (int)v->size() && (*v)[i].p) (void)hipFree((*v)[i].p);
+        if (i < (int)g->xt.size()) mi_cross_tables_free(&g->xt[i]);
         if (i < (int)g->recv.size() && g->recv[i].p) (void)hipFree(g->recv[i].p);
         if (i < (int)g->stage.size() && g->stage[i].p) (void)hipFree(g->stage[i].p);
     }
@@ -937,6 +951,167 @@ int32_t mi_msm_g2_sharded(mi_group *g, const mi_g2_affine *pts, const mi_fr *sca
     return msm_sharded_host<Fp2>(g, 2, pts, scalars, n, flags, mode, out);
 }
 
+// ---------------------------------------------------------------- computeH over the ranks of the group (csrc/ntt_cross.hip has the maths)
+// Data: rank r holds the natural-order slice [r M, (r + 1) M) of a, b (and c) in g->hx[0..2][local], M = N / world.  Result: the
+// coefficients of h in gnark's bit-reversed order, slice r on rank r, in g->hh[local] + 1 (slot 0 = the previous rank's last coefficient,
+// fetched by one more batch: the Z pairs of a sharded key are cut over N - 1, so every slice but the first starts one element early).
+// Six transforms as on one device (h = den FFT^-1_coset(ca cb) - den FFT^-1(c)); each is a local size-M transform and one cross-rank
+// step between two all-to-alls over the group's transport: 12 batches of (world - 1) / world of a slice per rank.
+// Local failures are CARRIED THROUGH every batch (the peers are in them) and returned at the end; a transport failure breaks the group.
+static bool sharded_h_possible(const mi_group *g, u32 log_n) {
+    const int W = g->world;
+    if (W < 2 || W > 16 || (W & (W - 1))) return false;
+    u32 lw = 0;
+    while ((1 << lw) < W) lw++;
+    return log_n >= 2 * lw && log_n <= 28;
+}
+static int32_t compute_h_sharded(mi_group *g, u32 log_n, bool derive_c) {
+    const int nl = g->n_local(), W = g->world;
+    u32 log_w = 0;
+    while ((1 << log_w) < W) log_w++;
+    const u32 log_m = log_n - log_w;
+    const size_t M = (size_t)1 << log_m, cnt = M >> log_w, row = cnt * sizeof(Fr);
+    int32_t lrc = MI_OK;
+    std::string lerr;
+    auto note = [&](int32_t rc, const std::string &msg) { if (rc != MI_OK && lrc == MI_OK) { lrc = rc; lerr = msg; } };
+    auto each = [&](const std::function<int32_t(int, mi_ctx *)> &fn) {
+        for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); const int32_t rc = fn(i, g->ctx[i]); note(rc, mi_last_error(g->ctx[i])); }
+    };
+    each([&](int i, mi_ctx *c) -> int32_t {
+        MI_TRY(mi_cross_tables_build(c, log_n, log_w, (u32)(g->rank0 + i), &g->xt[i]));
+        MI_TRY(mi_reserve(c, g->hy[i], M * sizeof(Fr)));
+        return mi_reserve(c, g->hh[i], (M + 1) * sizeof(Fr));
+    });
+    // all-to-all: block d of the source rank's buffer -> block s of rank d's buffer (the same rule in both directions)
+    auto a2a = [&](std::vector<DevBuf> &from, std::vector<DevBuf> &to) -> int32_t {
+        std::vector<Xfer> list;
+        for (int s = 0; s < W; s++) for (int d = 0; d < W; d++) {
+            Xfer x{s, d, nullptr, nullptr, row};
+            if (g->local(s)) x.sp = (const char *)from[s - g->rank0].p + (size_t)d * row;
+            if (g->local(d)) x.dp = (char *)to[d - g->rank0].p + (size_t)s * row;
+            list.push_back(x);
+        }
+        for (int i = 0; i < nl; i++) {   // the exchange streams pick up behind the contexts' streams ...
+            (void)hipSetDevice(g->dev[i]);
+            if (hipEventRecord(g->ev_c0[i], g->ctx[i]->stream) != hipSuccess || hipStreamWaitEvent(g->xs[i], g->ev_c0[i], 0) != hipSuccess) note(MI_EHIP, "sharded computeH: stream hand-over failed");
+        }
+        MI_TRY(run_xfers(g, list, g->xs));
+        for (int i = 0; i < nl; i++) {   // ... and hand back
+            (void)hipSetDevice(g->dev[i]);
+            if (hipEventRecord(g->ev_c1[i], g->xs[i]) != hipSuccess || hipStreamWaitEvent(g->ctx[i]->stream, g->ev_c1[i], 0) != hipSuccess) note(MI_EHIP, "sharded computeH: stream hand-over failed");
+        }
+        return MI_OK;
+    };
+    // FFTInverse (natural slices -> coefficient slices in bit-reversed order), every coefficient times 1 / N (den / N)
+    auto inverse = [&](std::vector<DevBuf> &X, bool den_scale) -> int32_t {
+        MI_TRY(a2a(X, g->hy));
+        each([&](int i, mi_ctx *c) { return mi_cross_dft(c, c->stream, g->hy[i].p, g->xt[i], 0, den_scale); });
+        MI_TRY(a2a(g->hy, X));
+        each([&](int i, mi_ctx *c) { return mi_ntt_dev_impl(c, (mi_fr *)X[i].p, log_m, MI_NTT_INVERSE); });
+        return MI_OK;
+    };
+    // FFT on the coset (coefficient slices -> natural-order evaluation slices)
+    auto forward_coset = [&](std::vector<DevBuf> &X) -> int32_t {
+        each([&](int i, mi_ctx *c) -> int32_t {
+            MI_TRY(mi_cross_mul(c, c->stream, X[i].p, X[i].p, g->xt[i].s_fwd, nullptr, M));
+            return mi_ntt_dev_impl(c, (mi_fr *)X[i].p, log_m, MI_NTT_DIT);
+        });
+        MI_TRY(a2a(X, g->hy));
+        each([&](int i, mi_ctx *c) { return mi_cross_dft(c, c->stream, g->hy[i].p, g->xt[i], 1, false); });
+        return a2a(g->hy, X);
+    };
+    if (derive_c) each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, g->hx[2][i].p, g->hx[0][i].p, g->hx[1][i].p, nullptr, M); });
+    MI_TRY(inverse(g->hx[0], false));
+    MI_TRY(inverse(g->hx[1], false));
+    MI_TRY(inverse(g->hx[2], true));          // den * coefficients of c
+    MI_TRY(forward_coset(g->hx[0]));
+    MI_TRY(forward_coset(g->hx[1]));
+    each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, g->hx[0][i].p, g->hx[0][i].p, g->hx[1][i].p, nullptr, M); });
+    MI_TRY(inverse(g->hx[0], false));
+    // h = den g^-k (.) - den c_k, into the h slice behind its front slot
+    each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, (char *)g->hh[i].p + sizeof(Fr), g->hx[0][i].p, g->xt[i].s_inv, g->hx[2][i].p, M); });
+    {   // every rank's last coefficient -> the front slot of the next rank
+        std::vector<Xfer> list;
+        for (int r = 0; r + 1 < W; r++) {
+            Xfer x{r, r + 1, nullptr, nullptr, sizeof(Fr)};
+            if (g->local(r)) x.sp = (const char *)g->hh[r - g->rank0].p + M * sizeof(Fr);
+            if (g->local(r + 1)) x.dp = g->hh[r + 1 - g->rank0].p;
+            list.push_back(x);
+        }
+        for (int i = 0; i < nl; i++) {
+            (void)hipSetDevice(g->dev[i]);
+            if (hipEventRecord(g->ev_c0[i], g->ctx[i]->stream) != hipSuccess || hipStreamWaitEvent(g->xs[i], g->ev_c0[i], 0) != hipSuccess) note(MI_EHIP, "sharded computeH: stream hand-over failed");
+        }
+        MI_TRY(run_xfers(g, list, g->xs));
+        for (int i = 0; i < nl; i++) {
+            (void)hipSetDevice(g->dev[i]);
+            if (hipEventRecord(g->ev_c1[i], g->xs[i]) != hipSuccess || hipStreamWaitEvent(g->ctx[i]->stream, g->ev_c1[i], 0) != hipSuccess) note(MI_EHIP, "sharded computeH: stream hand-over failed");
+        }
+    }
+    if (lrc != MI_OK) g->err = lerr;
+    return lrc;
+}
+// fills g->hx[which][i] with local rank i's slice of a vector of n_valid elements: rows [r M, (r + 1) M), zero beyond n_valid.
+// src: host (whole vector) or device (THIS rank's slice, i.e. the elements [r M, min((r + 1) M, n_valid)))
+static int32_t load_h_slice(mi_group *g, int i, int which, u32 log_m, const mi_fr *src, bool host_whole, size_t n_valid, hipStream_t st) {
+    mi_ctx *c = g->ctx[i];
+    const size_t M = (size_t)1 << log_m, lo = (size_t)(g->rank0 + i) * M;
+    const size_t have = n_valid > lo ? (n_valid - lo < M ? n_valid - lo : M) : 0;
+    MI_TRY(mi_reserve(c, g->hx[which][i], M * sizeof(Fr)));
+    char *dst = (char *)g->hx[which][i].p;
+    if (have) {
+        if (!src) MI_FAIL(c, MI_EINVAL, "sharded computeH: null input vector");
+        if (host_whole) MI_CHECK_HIP(c, hipMemcpyAsync(dst, src + lo, have * sizeof(Fr), hipMemcpyHostToDevice, st));
+        else MI_CHECK_HIP(c, hipMemcpyAsync(dst, src, have * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    }
+    if (have < M) MI_CHECK_HIP(c, hipMemsetAsync(dst + have * sizeof(Fr), 0, (M - have) * sizeof(Fr), st));
+    return MI_OK;
+}
+
+extern "C" {
+int32_t mi_group_set_sharded_compute_h(mi_group *g, uint32_t on) {
+    if (!g || on > 1) return MI_EINVAL;
+    G_ENTER(g);
+    g->sharded_h = on != 0;
+    return MI_OK;
+}
+// computeH alone over the ranks: every local rank passes ITS slices (device pointers; c_sl == NULL: c = a o b) and receives its slice
+// of h (M elements of gnark's bit-reversed order).  A collective: all ranks call it together.
+int32_t mi_compute_h_sharded_dev(mi_group *g, uint32_t log_n, const mi_fr *const *a_sl, const mi_fr *const *b_sl, const mi_fr *const *c_sl,
+                                 size_t n_constraints, mi_fr *const *h_sl) {
+    if (!g || !a_sl || !b_sl || !h_sl) return MI_EINVAL;
+    G_ENTER(g);
+    int32_t lrc = MI_OK;
+    std::string lerr;
+    const bool ok_shape = sharded_h_possible(g, log_n) && n_constraints <= ((size_t)1 << log_n);
+    if (!ok_shape) { lrc = MI_EINVAL; lerr = "sharded computeH: needs 2, 4, 8 or 16 ranks, N >= ranks^2 and n_constraints <= N"; }
+    u32 log_w = 0;
+    while ((1 << log_w) < g->world) log_w++;
+    const u32 log_m = log_n - log_w;
+    for (int i = 0; i < g->n_local() && lrc == MI_OK; i++) {
+        (void)hipSetDevice(g->dev[i]);
+        mi_ctx *c = g->ctx[i];
+        int32_t rc = load_h_slice(g, i, 0, log_m, a_sl[i], false, n_constraints, c->stream);
+        if (rc == MI_OK) rc = load_h_slice(g, i, 1, log_m, b_sl[i], false, n_constraints, c->stream);
+        if (rc == MI_OK) rc = c_sl ? load_h_slice(g, i, 2, log_m, c_sl[i], false, n_constraints, c->stream) : mi_reserve(c, g->hx[2][i], sizeof(Fr) << log_m);
+        if (rc != MI_OK) { lrc = rc; lerr = mi_last_error(c); }
+    }
+    const uint64_t check[3] = {log_n, (uint64_t)n_constraints, c_sl ? 1u : 0u};
+    MI_TRY(group_agree(g, lrc, lerr, "while loading its slices for computeH", check, 3));
+    lrc = compute_h_sharded(g, log_n, c_sl == nullptr);
+    if (g->broken) return lrc;
+    lerr = g->err;
+    for (int i = 0; i < g->n_local() && lrc == MI_OK; i++) {
+        (void)hipSetDevice(g->dev[i]);
+        mi_ctx *c = g->ctx[i];
+        hipError_t e = hipMemcpyAsync(h_sl[i], (const char *)g->hh[i].p + sizeof(Fr), sizeof(Fr) << log_m, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { lrc = MI_EHIP; lerr = std::string("sharded computeH: copying h out failed: ") + hipGetErrorString(e); }
+    }
+    return group_agree(g, lrc, lerr, "in the sharded computeH");
+}
+}  // extern "C"
+
 // ---------------------------------------------------------------- sharded proving key
 int32_t mi_pk_sharded_free(mi_group *g, mi_pk_sharded *spk) {
     if (!g || !spk) return MI_EINVAL;
@@ -1058,9 +1233,11 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
 // Phases: [local: checks, workspaces, uploads, wire MSMs, computeH + Z on the lead] AGREE [h slices over the transport] [local: the other
 // ranks' Z MSMs; mode 1: bucket views] (mode 1: AGREE [bucket slices of A, B1, B2, K] [bucket slices of Z]) [local: collect] ALL-GATHER
 // of every rank's status and five partial sums.
+// abc_sl (may be null): per LOCAL rank device pointers to its rows of a, b, c (abc_sl[2] == null: c = a o b): computeH runs over the ranks
+// (compute_h_sharded); so it does for host arrays when the group asks for it (mi_group_set_sharded_compute_h) and the shape allows.
 static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, const mi_fr *W_host, const mi_fr *const *W_dev, size_t n_wires,
                                   const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m,
-                                  uint32_t mode, mi_proof_out *out, mi_stats *stats) {
+                                  uint32_t mode, mi_proof_out *out, mi_stats *stats, const mi_fr *const *const *abc_sl = nullptr) {
     if (!g || !spk || !out) return MI_EINVAL;
     const int nl = g->n_local(), W = g->world;
     if ((nl != W && nl != 1) || (int)spk->part.size() != nl) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
@@ -1070,13 +1247,20 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
     const auto t_begin = std::chrono::steady_clock::now();
     const size_t cb = n_constraints * sizeof(mi_fr);
     const bool defer = mode == 1;
+    const bool use_sh = (abc_sl != nullptr || (host && g->sharded_h)) && sharded_h_possible(g, spk->log_n);
+    u32 log_w = 0;
+    while ((1 << log_w) < W) log_w++;
     // ---- local phase 1.  Nothing returns from here on without the group having agreed on it (a process that left alone would leave
     //      the others waiting in the next exchange): failures are noted and carried to the agreement.
     int32_t lrc = MI_OK;
     std::string lerr;
     auto note = [&](int32_t rc, const std::string &msg) { if (rc != MI_OK && lrc == MI_OK) { lrc = rc; lerr = msg; } };
     if (!r_m || !s_m || mode > 1 || (host ? (!W_host && n_wires) : !W_dev)) note(MI_EINVAL, "prove: null argument or unknown mode");
-    if (lead_here && (!a || !b) && n_constraints) note(MI_EINVAL, "prove: the process that holds rank 0 must pass a and b");
+    if (abc_sl && !use_sh) note(MI_EINVAL, "prove: row slices of a, b, c need computeH over the ranks: 2, 4, 8 or 16 ranks and N >= ranks^2");
+    if (abc_sl && (!abc_sl[0] || !abc_sl[1])) note(MI_EINVAL, "prove: null slice arrays");
+    if (!abc_sl && (lead_here || use_sh) && (!a || !b) && n_constraints)
+        note(MI_EINVAL, use_sh ? "prove: with computeH over the ranks every process passes a and b" : "prove: the process that holds rank 0 must pass a and b");
+    if (use_sh && n_constraints > N) note(MI_EINVAL, "prove: witness size does not match the proving key");
     if (n_wires != spk->nb_wires || (lead_here && n_constraints > N)) note(MI_EINVAL, "prove: witness size does not match the proving key");
     if (mode == 1 && !spk->uniform) note(MI_EINVAL, "group: mode 1 needs every part of the key to use the same MSM plan");
     // workspaces, each on its own device: W slice (+ a, b, c on the lead) for host inputs; h (whole on the lead, a slice elsewhere)
@@ -1087,8 +1271,8 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
         const bool lead = g->rank0 + i == 0;
         std::memset(&ctx->stats, 0, sizeof(ctx->stats));
         int32_t rc = MI_OK;
-        if (host) rc = mi_reserve(ctx, ctx->ws[16], pk->nb_wires * sizeof(mi_fr) + (lead ? 3 * cb : 0) + 128);
-        if (rc == MI_OK) rc = mi_reserve(ctx, ctx->ws[14], (lead ? N : pk->n_z_msm + 1) * sizeof(Fr));
+        if (host) rc = mi_reserve(ctx, ctx->ws[16], pk->nb_wires * sizeof(mi_fr) + (lead && !use_sh ? 3 * cb : 0) + 128);
+        if (rc == MI_OK && !use_sh) rc = mi_reserve(ctx, ctx->ws[14], (lead ? N : pk->n_z_msm + 1) * sizeof(Fr));
         note(rc, mi_last_error(ctx));
     }
     // every local rank: its slice of W, its wire MSMs; the lead also a, b, c, computeH and its own Z MSM.  One host thread per rank:
@@ -1110,6 +1294,18 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
         }
         MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
         MI_TRY(mi_prove_enqueue_wire_msms(ctx, pk, Wd, ev[2], defer));
+        if (use_sh) {   // this rank's rows of a, b (, c) into the group's slice vectors; computeH itself is a collective and follows the agreement
+            const u32 log_m = pk->log_n - log_w;
+            MI_CHECK_HIP(ctx, hipEventRecord(ev[11], ctx->stream));
+            for (int which = 0; which < 3; which++) {
+                const mi_fr *src = abc_sl ? (abc_sl[which] ? abc_sl[which][i] : nullptr) : (which == 0 ? a : which == 1 ? b : c);
+                const bool given = abc_sl ? abc_sl[which] != nullptr : src != nullptr;
+                if (which == 2 && !given) { MI_TRY(mi_reserve(ctx, g->hx[2][i], sizeof(Fr) << log_m)); continue; }
+                MI_TRY(load_h_slice(g, i, which, log_m, src, !abc_sl, n_constraints, abc_sl ? ctx->stream : ctx->copy_stream));
+            }
+            if (!abc_sl) MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));   // (grown buffers: hipFree inside mi_reserve has synchronised already)
+            return MI_OK;
+        }
         if (!lead) return MI_OK;
         // lead: a, b, c arrive while the wire MSMs run; computeH; its own slice of h feeds its Z MSM straight away
         const mi_fr *da = a, *db = b, *dc = c;
@@ -1133,14 +1329,29 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
     if (lrc == MI_OK) { std::string e; note(for_each_local_rank(g, &e, rank_main), e); }
     auto fail = [&](int32_t rc) { const std::string keep = g->err; drain_slots(g, slots, curves, 5); g->err = keep; return rc; };
     {
-        const uint64_t check[3] = {(uint64_t)n_wires, (uint64_t)mode, (uint64_t)spk->log_n};   // (n_constraints is the lead's alone)
-        const int32_t rc = group_agree(g, lrc, lerr, "before the exchange of the h slices", check, 3);
+        const uint64_t check[5] = {(uint64_t)n_wires, (uint64_t)mode, (uint64_t)spk->log_n, use_sh ? 1u : 0u, use_sh ? (uint64_t)n_constraints : 0u};   // (without computeH over the ranks n_constraints is the lead's alone)
+        const int32_t rc = group_agree(g, lrc, lerr, "before computeH / the exchange of the h slices", check, 5);
         if (rc != MI_OK) return fail(rc);
     }
     // ---- h: rank 0 hands every other rank its slice device to device, as one batch of the group's transport (grouped ncclSend / ncclRecv,
     // same-process copies or the shared-memory rings) on the exchange streams; the events that order the Z MSMs behind it are recorded by
     // each RECEIVER on its own stream (an event is recorded only on a stream of the device it was created on)
-    if (W > 1) {
+    if (use_sh) {
+        // computeH over all ranks; every rank's h slice is born where its Z pairs live (front slot = the previous rank's last coefficient)
+        const bool derive_c = abc_sl ? abc_sl[2] == nullptr : c == nullptr;
+        const int32_t rc = compute_h_sharded(g, spk->log_n, derive_c);
+        if (g->broken) return fail(rc);
+        note(rc, g->err);
+        if (lrc == MI_OK) {
+            std::string e;
+            note(for_each_local_rank(g, &e, [&](int i) -> int32_t {
+                mi_ctx *ctx = g->ctx[i];
+                MI_CHECK_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+                const Fr *hz = (const Fr *)g->hh[i].p + (g->rank0 + i == 0 ? 1 : 0);
+                return mi_prove_enqueue_z_msm(ctx, spk->part[i], (const mi_fr *)hz, ctx->ev[3], defer);
+            }), e);
+        }
+    } else if (W > 1) {
         std::vector<Xfer> list;
         for (int j = 1; j < W; j++) {
             u64 zlo, zhi;
@@ -1225,7 +1436,7 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
     mi_stats &st = g->ctx[0]->stats;
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<float, std::milli>(y - x).count(); };
     // (statistics are best effort: past the last all-gather nothing may fail on one rank alone)
-    if (lead_here && hipEventElapsedTime(&st.compute_h_ms, g->ctx[0]->ev[11], g->ctx[0]->ev[3]) != hipSuccess) { (void)hipGetLastError(); st.compute_h_ms = 0; }
+    if ((lead_here || use_sh) && hipEventElapsedTime(&st.compute_h_ms, g->ctx[0]->ev[11], g->ctx[0]->ev[3]) != hipSuccess) { (void)hipGetLastError(); st.compute_h_ms = 0; }
     st.assemble_ms = ms(t_gpu_done, t_end);
     st.total_ms = ms(t_begin, t_end);
     if (stats) *stats = st;
@@ -1246,6 +1457,13 @@ int32_t mi_groth16_prove_sharded(mi_group *g, mi_pk_sharded *spk, const mi_fr *W
                                  size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, uint32_t mode, mi_proof_out *out, mi_stats *stats) {
     G_ENTER(g);
     return prove_sharded_impl(g, spk, true, W, nullptr, n_wires, a, b, c, n_constraints, r_m, s_m, mode, out, stats);
+}
+int32_t mi_groth16_prove_sharded_slices_dev(mi_group *g, mi_pk_sharded *spk, const mi_fr *const *W_dev, size_t n_wires, const mi_fr *const *a_sl,
+                                            const mi_fr *const *b_sl, const mi_fr *const *c_sl, size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m,
+                                            uint32_t mode, mi_proof_out *out, mi_stats *stats) {
+    G_ENTER(g);
+    const mi_fr *const *abc[3] = {a_sl, b_sl, c_sl};
+    return prove_sharded_impl(g, spk, false, nullptr, W_dev, n_wires, nullptr, nullptr, nullptr, n_constraints, r_m, s_m, mode, out, stats, abc);
 }
 int32_t mi_groth16_prove_sharded_dev(mi_group *g, mi_pk_sharded *spk, const mi_fr *const *W_dev, size_t n_wires, const mi_fr *a_dev, const mi_fr *b_dev,
                                      const mi_fr *c_dev, size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, uint32_t mode, mi_proof_out *out,

@@ -336,6 +336,19 @@ int32_t mi_group_destroy(mi_group *g);
 int32_t mi_group_set_lead_share(mi_group *g, uint32_t permille);
 /* wires [*lo, *hi) of global rank `rank` under the group's current lead share */
 int32_t mi_group_wire_range(const mi_group *g, uint64_t nb_wires, int rank, uint64_t *lo, uint64_t *hi);
+/* computeH OVER the ranks (2, 4, 8 or 16 of them, N >= ranks^2): every transform becomes a local size-N/ranks transform and one
+ * cross-rank step between two all-to-alls over the group's transport (12 batches per computeH, each moving (ranks - 1) / ranks of a
+ * slice per rank), and the h slices are born on the ranks whose Z pairs they multiply -- instead of rank 0 transforming alone while the
+ * others wait for h (the cap of a proof sharded over 8 GPUs moves from ~3x to the MSMs' own 1 / ranks).  Same h, same
+ * proof bytes.  on = 1: mi_groth16_prove_sharded (host arrays) then needs a and b (and c, or NULL) in EVERY process, not on rank 0's
+ * alone, and takes its rank's rows from them; mi_groth16_prove_sharded_dev is unchanged (its a, b, c live on rank 0's device).
+ * The same value in every process.  Default 0. */
+int32_t mi_group_set_sharded_compute_h(mi_group *g, uint32_t on);
+/* computeH alone, as a collective: local rank i passes device pointers to ITS rows of a, b (and c; c_sl == NULL: c = a o b on the
+ * device) -- rows [r M, min((r + 1) M, n_constraints)) of global rank r, M = N / ranks -- and receives its M coefficients of h in
+ * gnark's bit-reversed order (rank r: positions [r M, (r + 1) M) of what mi_compute_h_dev returns). */
+int32_t mi_compute_h_sharded_dev(mi_group *g, uint32_t log_n, const mi_fr *const *a_sl, const mi_fr *const *b_sl, const mi_fr *const *c_sl,
+                                 size_t n_constraints, mi_fr *const *h_sl);
 int32_t mi_group_world(const mi_group *g);
 int32_t mi_group_local(const mi_group *g);                 /* ranks held by this process */
 mi_ctx *mi_group_ctx(mi_group *g, int local_rank);         /* for mi_dev_* / generators on that rank's device */
@@ -365,6 +378,12 @@ int32_t mi_groth16_prove_sharded(mi_group *g, mi_pk_sharded *pk, const mi_fr *W,
 int32_t mi_groth16_prove_sharded_dev(mi_group *g, mi_pk_sharded *pk, const mi_fr *const *W_dev, size_t n_wires,
                                      const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev, size_t n_constraints,
                                      const mi_fr *r, const mi_fr *s, uint32_t mode, mi_proof_out *out, mi_stats *stats_or_null);
+/* the same with a, b, c as ROW SLICES per local rank (rows [r M, min((r + 1) M, n_constraints)) of global rank r on that rank's device,
+ * M = N / ranks; c_sl == NULL: c = a o b): computeH runs over the ranks (mi_group_set_sharded_compute_h says what that means; here it
+ * is the only way, whatever the group's setting).  2, 4, 8 or 16 ranks, N >= ranks^2. */
+int32_t mi_groth16_prove_sharded_slices_dev(mi_group *g, mi_pk_sharded *pk, const mi_fr *const *W_dev, size_t n_wires,
+                                            const mi_fr *const *a_sl, const mi_fr *const *b_sl, const mi_fr *const *c_sl, size_t n_constraints,
+                                            const mi_fr *r, const mi_fr *s, uint32_t mode, mi_proof_out *out, mi_stats *stats);
 /* one MSM over host arrays cut into contiguous slices (single-process groups) */
 int32_t mi_msm_g1_sharded(mi_group *g, const mi_g1_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags,
                           uint32_t mode, mi_g1_jac *out);

@@ -135,6 +135,32 @@ def scenario_parity(B, rank, world, seed_hex):
         assert refused, "ranks that disagree on the lead share must all be refused the key"
         g.set_lead_share(0xFFFFFFFF)
         checks.append("lead_share_0_500_1000_and_disagreement")
+        # ---- computeH over the ranks (worlds 2 and 4; world 3 falls back to the lead's computeH): every process passes a and b, the h
+        #      slices are born where the Z pairs live; host arrays in both modes, row slices on the device with c formed there
+        g.set_sharded_compute_h(True)
+        spk = g.pk_load(pk)
+        for mode in (0, 1):
+            got, _ = g.prove(spk, W, a, b, cc if mode else None, r, s, mode=mode)
+            assert B.proof_write(got["raw"]) == want, f"computeH over the ranks, host arrays, mode {mode}"
+        g.pk_free(spk)
+        if world in (2, 4):
+            N = 1 << pk["log_n"]; M = N // world; ncs = a.shape[0]
+            keep = []
+            spk = g.pk_load_dev(pk, [slices_of(B, c, pk, world, rank, keep, g)])
+            wlo, whi = g.wire_range(pk["nb_wires"], rank)
+            lo, hi = min(rank * M, ncs), min((rank + 1) * M, ncs)
+            dW, da, db = c.to_dev(W[wlo:whi]), c.to_dev(a[lo:hi]), c.to_dev(b[lo:hi]); keep += [dW, da, db]
+            got, _ = g.prove_slices_dev(spk, [dW.ptr], pk["nb_wires"], [da.ptr], [db.ptr], None, ncs, r, s, mode=1)
+            assert B.proof_write(got["raw"]) == want, "computeH over the ranks, row slices"
+            # ... and computeH alone, this rank's slice of h against the oracle's
+            dh = c.alloc(32 * M); keep.append(dh)
+            g.compute_h_sharded_dev(pk["log_n"], [da.ptr], [db.ptr], None, ncs, [dh.ptr])
+            assert np.array_equal(dh.download((M, 4)), cref.compute_h(pk["log_n"], a, b, cc)[rank * M:(rank + 1) * M]), "h slice"
+            g.pk_free(spk)
+            for x in keep:
+                x.free()
+        g.set_sharded_compute_h(False)
+        checks.append("compute_h_over_the_ranks")
     finally:
         g.close()
     return {"ok": True, "checks": checks}

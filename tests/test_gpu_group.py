@@ -351,3 +351,96 @@ def test_sharded_msm_with_ranks_that_hold_no_pairs(B):
                 assert np.array_equal(g.msm_g1(pts, sc, mode=mode), cref.msm_g1(pts, sc)), (n, mode)
     finally:
         g.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("log_n,n_constraints", [(6, 64), (10, 1000), (13, 8192 - 77), (16, 40000)])
+def test_compute_h_over_the_ranks_equals_the_oracle(B, world, log_n, n_constraints):
+    """mi_compute_h_sharded_dev: six transforms as local size-N/W transforms + cross-rank steps between all-to-alls (csrc/ntt_cross.hip):
+    every coefficient of h against the oracle's computeH, with c given and with c = a o b formed on the devices; ragged n_constraints
+    (whole slices of zero padding), 2 / 4 / 8 ranks on device 0 (same-process copies)"""
+    N = 1 << log_n
+    M = N // world
+    a = cref.gen_scalars(n_constraints, 7700 + log_n, 1); b = cref.gen_scalars(n_constraints, 7701 + log_n, 0)
+    c_good = cref.field_op(0, 2, a, b)
+    c_free = cref.gen_scalars(n_constraints, 7702 + log_n, 0)   # computeH does not assume a o b = c
+    g = B.Group([0] * world)
+    try:
+        for c_host in (c_free, None, c_good):
+            want = cref.compute_h(log_n, a, b, c_good if c_host is None else c_host)
+            keep, ap, bp, cp, hp, hd = [], [], [], [], [], []
+            for r in range(world):
+                ctx = g.ctx(r)
+                lo, hi = min(r * M, n_constraints), min((r + 1) * M, n_constraints)
+                for arr, dst in ((a, ap), (b, bp), (c_host, cp)):
+                    if arr is None:
+                        continue
+                    d = ctx.to_dev(arr[lo:hi]) if hi > lo else ctx.alloc(32); keep.append(d); dst.append(d.ptr)
+                h = ctx.alloc(32 * M); keep.append(h); hp.append(h.ptr); hd.append(h)
+            g.compute_h_sharded_dev(log_n, ap, bp, cp if c_host is not None else None, n_constraints, hp)
+            got = np.concatenate([h.download((M, 4)) for h in hd])
+            for d in keep:
+                d.free()
+            assert np.array_equal(got, want), (world, log_n, n_constraints, c_host is None)
+    finally:
+        g.close()
+
+
+def test_compute_h_over_the_ranks_refuses_what_it_cannot_cut(B):
+    for devs, log_n in (([0, 0, 0], 10), ([0, 0, 0, 0], 3), ([0], 10)):
+        g = B.Group(devs)
+        try:
+            ctx = g.ctx(0)
+            d = ctx.alloc(32 << log_n)
+            with pytest.raises(B.MiError):
+                g.compute_h_sharded_dev(log_n, [d.ptr] * len(devs), [d.ptr] * len(devs), None, 1 << log_n, [d.ptr] * len(devs))
+            d.free()
+        finally:
+            g.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_sharded_prove_with_compute_h_over_the_ranks(B, world, mode):
+    """mi_group_set_sharded_compute_h + mi_groth16_prove_sharded (host arrays) and mi_groth16_prove_sharded_slices_dev (row slices of a, b,
+    c per rank): computeH runs over all ranks and every rank's Z MSM reads the h slice born on it; bytes == oracle, with c given and
+    with c formed on the devices; the lead's wire share 0 and even"""
+    log_n = 13
+    N = 1 << log_n
+    M = N // world
+    nb_wires, n_constraints = N - 50, N - 1000
+    pk = synthetic_pk(log_n, nb_wires, 300, 8800 + world, n_committed=7)
+    W = cref.gen_scalars(nb_wires, 31, 1)
+    a = cref.gen_scalars(n_constraints, 32, 1); b = cref.gen_scalars(n_constraints, 33, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 34, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    g = B.Group([0] * world)
+    try:
+        for share in (0, 1000):
+            g.set_lead_share(share)
+            g.set_sharded_compute_h(True)
+            spk = g.pk_load(pk)
+            for cc in (c, None):
+                got, st = g.prove(spk, W, a, b, cc, r, s, mode=mode)
+                assert B.proof_write(got["raw"]) == want, (world, mode, share, cc is None, "host arrays")
+            g.set_sharded_compute_h(False)
+            got, _ = g.prove(spk, W, a, b, c, r, s, mode=mode)   # and the lead's computeH again on the same key
+            assert B.proof_write(got["raw"]) == want
+            g.pk_free(spk)
+            keep = []
+            spk = g.pk_load_dev(pk, _slices(B, g, pk, keep))
+            Wp, ap, bp, cp = [], [], [], []
+            for rk in range(world):
+                ctx = g.ctx(rk)
+                wlo, whi = g.wire_range(nb_wires, rk)
+                lo, hi = min(rk * M, n_constraints), min((rk + 1) * M, n_constraints)
+                for arr, dst, sl in ((W, Wp, slice(wlo, whi)), (a, ap, slice(lo, hi)), (b, bp, slice(lo, hi)), (c, cp, slice(lo, hi))):
+                    d = ctx.to_dev(arr[sl]) if sl.stop > sl.start else ctx.alloc(32); keep.append(d); dst.append(d.ptr)
+            for cps in (cp, None):
+                got, _ = g.prove_slices_dev(spk, Wp, nb_wires, ap, bp, cps, n_constraints, r, s, mode=mode)
+                assert B.proof_write(got["raw"]) == want, (world, mode, share, cps is None, "row slices")
+            g.pk_free(spk)
+            for d in keep:
+                d.free()
+    finally:
+        g.close()

@@ -33,12 +33,19 @@ def test_world2_two_processes_parity_vs_oracle(rank_launcher):
     res = _run(rank_launcher, "parity")
     for rc, j, raw in res:
         assert rc == 0 and j.get("ok"), f"{j} {raw['stderr'][-1500:]}"
-        assert j["checks"] == ["selftest", "msm_g1_g2_both_modes", "prove_2p16_host_and_device_both_modes", "lead_share_0_500_1000_and_disagreement"]
+        assert j["checks"] == ["selftest", "msm_g1_g2_both_modes", "prove_2p16_host_and_device_both_modes", "lead_share_0_500_1000_and_disagreement", "compute_h_over_the_ranks"]
 
 
 def test_world3_three_processes_parity_vs_oracle(rank_launcher):
     """the same with three ranks (a middle rank that is neither the lead nor the last; uneven slices)"""
     res = _run(rank_launcher, "parity", world=3)
+    for rc, j, raw in res:
+        assert rc == 0 and j.get("ok"), f"{j} {raw['stderr'][-1500:]}"
+
+
+def test_world4_four_processes_parity_vs_oracle(rank_launcher):
+    """four ranks: computeH over the ranks with two cross-rank butterfly stages, the lead without wires (automatic share)"""
+    res = _run(rank_launcher, "parity", world=4, timeout=600)
     for rc, j, raw in res:
         assert rc == 0 and j.get("ok"), f"{j} {raw['stderr'][-1500:]}"
 
