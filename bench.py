@@ -165,8 +165,11 @@ def sharded_prove_section(B, g, rank, world, log_n, steps):
            "beta2": small2[0], "delta2": small2[1], "infinity_a": ia, "infinity_b": ib}
     Wd = c.gen_scalars(hi - lo, rseed + 8, 1)
     da = db = dc = None
+    over_ranks = world in (2, 4, 8, 16)   # computeH over the ranks (mi_groth16_prove_sharded_slices_dev): every rank then needs ITS rows of a and b
+    if rank == 0 or over_ranks:           # (every rank generates the whole vectors -- same seeds -- and points into them: simple, and 2 x 2 GB at N = 2^26)
+        da = c.gen_scalars(n_constraints, seed + 9, 1); db = c.gen_scalars(n_constraints, seed + 10, 0)
     if rank == 0:
-        da = c.gen_scalars(n_constraints, seed + 9, 1); db = c.gen_scalars(n_constraints, seed + 10, 0); dc = c.alloc(32 * n_constraints)
+        dc = c.alloc(32 * n_constraints)
         c.field_op_dev(0, 2, dc.ptr, da.ptr, db.ptr, n_constraints)
     c.sync()
     ptr = lambda d: None if d is None else d.ptr
@@ -180,12 +183,26 @@ def sharded_prove_section(B, g, rank, world, log_n, steps):
     spk = g.pk_load_dev(hdr, [{k: (v[0].ptr, v[1]) for k, v in arrs.items()}])
     out["pk_load_sharded_s"] = time.perf_counter() - t0
     got = {}
+    lead_abc = (ptr(da), ptr(db), ptr(dc)) if rank == 0 else (None, None, None)
     for mode in (0, 1):
-        pr, _ = g.prove_dev(spk, [Wd.ptr], nb_wires, ptr(da), ptr(db), ptr(dc), n_constraints, rs[0], rs[1], mode=mode)   # warm-up: sizes the workspaces, lines the ranks up
+        pr, _ = g.prove_dev(spk, [Wd.ptr], nb_wires, *lead_abc, n_constraints, rs[0], rs[1], mode=mode)   # warm-up: sizes the workspaces, lines the ranks up
         t0 = time.perf_counter()
         for _ in range(steps):
-            pr, st = g.prove_dev(spk, [Wd.ptr], nb_wires, ptr(da), ptr(db), ptr(dc), n_constraints, rs[0], rs[1], mode=mode)
+            pr, st = g.prove_dev(spk, [Wd.ptr], nb_wires, *lead_abc, n_constraints, rs[0], rs[1], mode=mode)
         got[mode] = (B.proof_write(pr["raw"]), time.perf_counter() - t0, st)
+    if over_ranks:   # the same proof with computeH over the ranks: this rank's rows of a and b, c formed on the devices
+        M = N // world
+        row0 = min(rank * M, n_constraints)
+        for mode in (0, 1):
+            args = (spk, [Wd.ptr], nb_wires, [da.ptr + 32 * row0], [db.ptr + 32 * row0], None, n_constraints, rs[0], rs[1])
+            pr, _ = g.prove_slices_dev(*args, mode=mode)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                pr, st = g.prove_slices_dev(*args, mode=mode)
+            got[2 + mode] = (B.proof_write(pr["raw"]), time.perf_counter() - t0, st)
+        out.update({"compute_h_over_ranks": True, "dt2": got[2][1], "dt3": got[3][1], "over_ranks_agree": got[2][0] == got[0][0] and got[3][0] == got[0][0]})
+        if not out["over_ranks_agree"]:
+            raise RuntimeError("the proof with computeH over the ranks differs from the proof with computeH on the lead")
     g.pk_free(spk)
     for d in [v[0] for v in arrs.values()] + [Wd, da, db, dc]:
         if d is not None:
@@ -289,12 +306,12 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
     ok = 1.0 if res.get("ok") and m else 0.0
     okp = 1.0 if pv.get("ok") else 0.0
     v = [ok, float(m.get("dt0", 0.0)), float(m.get("dt1", 0.0)), 1.0 if m.get("modes_agree") else 0.0]
-    w = [okp, float(pv.get("dt0", 0.0)), float(pv.get("dt1", 0.0))]
+    w = [okp, float(pv.get("dt0", 0.0)), float(pv.get("dt1", 0.0)), float(pv.get("dt2", 0.0)), float(pv.get("dt3", 0.0))]
     if dist is not None:   # every rank takes part, whatever its helper did: all ok?  slowest rank's times; all agree?
         tmin = torch.tensor([v[0], v[3], w[0]], device=dev, dtype=torch.float64); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        tmax = torch.tensor([v[1], v[2], w[1], w[2]], device=dev, dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = torch.tensor([v[1], v[2], w[1], w[2], w[3], w[4]], device=dev, dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         v = [float(tmin[0]), float(tmax[0]), float(tmax[1]), float(tmin[1])]
-        w = [float(tmin[2]), float(tmax[2]), float(tmax[3])]
+        w = [float(tmin[2]), float(tmax[2]), float(tmax[3]), float(tmax[4]), float(tmax[5])]
     n_msm = 1 << args.sharded_msm_log_n
     sharded["selftest"] = sharded_prove["selftest"] = res.get("selftest", "not run")
     devices = "ONE device shared by all ranks (rehearsal: the multi-process code path, not a scaling measurement)" if args.rehearse_on_one_gpu else f"{world} device(s)"
@@ -314,6 +331,9 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
                               "scaling": "strong", "transport": res.get("transport"), "devices": devices, "steps": steps_prove, "inputs": "resident in HBM (mi_groth16_prove_sharded_dev)",
                               "mode0_partial_sums_ms_per_proof": w[1] / steps_prove * 1e3, "mode0_proofs_per_s": steps_prove / w[1],
                               "mode1_bucket_exchange_ms_per_proof": w[2] / steps_prove * 1e3, "mode1_proofs_per_s": steps_prove / w[2],
+                              "compute_h_over_ranks": None if not (w[3] > 0 and w[4] > 0) else {
+                                  "what": "the same proof through mi_groth16_prove_sharded_slices_dev: computeH as local size-N/ranks transforms + cross-rank steps between all-to-alls, every rank's h slice born where its Z pairs live (DESIGN.md 6)",
+                                  "mode0_ms_per_proof": w[3] / steps_prove * 1e3, "mode1_ms_per_proof": w[4] / steps_prove * 1e3, "bytes_equal_the_lead_computeH_proof": pv.get("over_ranks_agree")},
                               "modes_agree": pv.get("modes_agree"), "equals_unsharded_prove": pv.get("equals_unsharded"),
                               "small_parity": pv.get("small_parity"), "compute_h_ms_on_rank0": pv.get("compute_h_ms_on_rank0"),
                               "pk_load_sharded_s": pv.get("pk_load_sharded_s"),
