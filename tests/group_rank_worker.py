@@ -210,6 +210,32 @@ def scenario_inject(B, rank, world, seed_hex):
         g, spk = fresh()
         got, _ = g.prove(spk, W, a if lead else None, b if lead else None, cc if lead else None, r, s, mode=mode)
         assert B.proof_write(got["raw"]) == want, "the group must prove correctly after a failed call"
+    # the same with computeH OVER THE RANKS (local failures are carried through its twelve all-to-alls: nobody may be left waiting in one)
+    for victim, nth in ((1, 3), (0, 6), (1, 10), (0, 16), (1, 24), (1, 36), (0, 50), (1, 70)):
+        g.set_sharded_compute_h(True)
+        if rank == victim:
+            assert lib.mi_debug_inject_hip_failure(nth) == 0
+        t0 = time.time()
+        failed, msg = False, ""
+        try:
+            got, _ = g.prove(spk, W, a, b, None, r, s, mode=nth & 1)
+        except B.MiError as e:
+            failed, msg = True, str(e)
+        dt = time.time() - t0
+        lib.mi_debug_inject_hip_failure(0)
+        trials.append({"victim": victim, "nth": nth, "compute_h_over_ranks": True, "failed": failed, "seconds": round(dt, 3), "msg": msg[:160]})
+        if not failed:
+            assert B.proof_write(got["raw"]) == want
+        try:
+            g.pk_free(spk)
+        except B.MiError:
+            pass
+        g.close()
+        g, spk = fresh()
+        g.set_sharded_compute_h(True)
+        got, _ = g.prove(spk, W, a, b, None, r, s, mode=1)
+        assert B.proof_write(got["raw"]) == want, "the group must prove correctly (computeH over the ranks) after a failed call"
+        g.set_sharded_compute_h(False)
     # a rank that passes a wrong witness length: refused on every rank, and the SAME group stays usable
     bad_failed = False
     t0 = time.time()
