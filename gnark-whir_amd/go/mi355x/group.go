@@ -47,6 +47,24 @@ func (gr *Group) status(rc C.int32_t) error {
 	return fmt.Errorf("mi355x: rc=%d: %s", int(rc), C.GoString(C.mi_group_last_error(gr.g)))
 }
 
+// SetLeadShare: rank 0 also runs computeH, so it takes permille / 1000 of an even share of the wires (mi_group_set_lead_share;
+// LeadShareAuto = 1000 / 500 / 0 for 1 / 2 / >= 3 devices, the default).  Before LoadKey.
+const LeadShareAuto = 0xffffffff
+
+func (gr *Group) SetLeadShare(permille uint32) error {
+	return gr.status(C.mi_group_set_lead_share(gr.g, C.uint32_t(permille)))
+}
+
+// ShardComputeH makes ProveSolved run computeH over all devices of the group (four-step transforms, mi_group_set_sharded_compute_h)
+// instead of on the first one alone: 2, 4, 8 or 16 devices.  Same proofs.
+func (gr *Group) ShardComputeH(on bool) error {
+	v := C.uint32_t(0)
+	if on {
+		v = 1
+	}
+	return gr.status(C.mi_group_set_sharded_compute_h(gr.g, v))
+}
+
 // LoadKey shards pk over the group's devices.  The descriptor is built in C memory over pinned Go arrays (ProvingKey.withKeyDesc,
 // mi355x.go: a Go struct holding Go pointers must not be passed to C by address).
 func (gr *Group) LoadKey(pk *ProvingKey, r1cs *cs.R1CS) error {
