@@ -86,7 +86,7 @@ struct mi_group {
     // slice with one slot in front (the previous rank's last coefficient: the Z cut of a sharded key starts one element early), two events
     bool sharded_h = false;        // mi_group_set_sharded_compute_h: mi_groth16_prove_sharded runs computeH over all ranks
     std::vector<CrossNttTables> xt;
-    std::vector<DevBuf> hx[3], hy, hh;
+    std::vector<DevBuf> hx[3], hy, hy2, hh;
     std::vector<hipEvent_t> ev_c0, ev_c1;
     uint32_t lead_share = 0xffffffffu;   // permille of an even wire share that rank 0 -- which also runs computeH -- takes (mi_group_set_lead_share; all ones = automatic)
     int timeout_ms = 60000;        // how long a rank waits for its peers without anything completing (MI_GROUP_TIMEOUT_MS; both transports)
@@ -532,7 +532,7 @@ static int32_t group_finish_init(mi_group *g) {
     const int n = g->n_local();
     g->xs.assign(n, nullptr); g->ev_x.assign(n, nullptr); g->ev_in.assign(n, nullptr); g->ev_done.assign(n, nullptr); g->ev_h.assign(n, nullptr);
     g->recv.assign(n, DevBuf{}); g->stage.assign(n, DevBuf{});
-    g->xt.assign(n, CrossNttTables{}); g->hy.assign(n, DevBuf{}); g->hh.assign(n, DevBuf{}); g->ev_c0.assign(n, nullptr); g->ev_c1.assign(n, nullptr);
+    g->xt.assign(n, CrossNttTables{}); g->hy.assign(n, DevBuf{}); g->hy2.assign(n, DevBuf{}); g->hh.assign(n, DevBuf{}); g->ev_c0.assign(n, nullptr); g->ev_c1.assign(n, nullptr);
     for (auto &v : g->hx) v.assign(n, DevBuf{});
     for (int i = 0; i < n; i++) {
         (void)hipSetDevice(g->dev[i]);
@@ -560,7 +560,7 @@ int32_t mi_group_destroy(mi_group *g) {
         if (i < (int)g->comm.size() && g->comm[i]) (void)(g->broken ? ncclCommAbort(g->comm[i]) : ncclCommDestroy(g->comm[i]));
         for (auto *v : {&g->ev_x, &g->ev_in, &g->ev_done, &g->ev_h}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
         for (auto *v : {&g->ev_c0, &g->ev_c1}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
-        for (auto *v : {&g->hx[0], &g->hx[1], &g->hx[2], &g->hy, &g->hh}) if (i < (int)v->size() && (*v)[i].p) (void)hipFree((*v)[i].p);
+        for (auto *v : {&g->hx[0], &g->hx[1], &g->hx[2], &g->hy, &g->hy2, &g->hh}) if (i < (int)v->size() && (*v)[i].p) (void)hipFree((*v)[i].p);
         if (i < (int)g->xt.size()) mi_cross_tables_free(&g->xt[i]);
         if (i < (int)g->recv.size() && g->recv[i].p) (void)hipFree(g->recv[i].p);
         if (i < (int)g->stage.size() && g->stage[i].p) (void)hipFree(g->stage[i].p);
@@ -956,7 +956,8 @@ int32_t mi_msm_g2_sharded(mi_group *g, const mi_g2_affine *pts, const mi_fr *sca
 // coefficients of h in gnark's bit-reversed order, slice r on rank r, in g->hh[local] + 1 (slot 0 = the previous rank's last coefficient,
 // fetched by one more batch: the Z pairs of a sharded key are cut over N - 1, so every slice but the first starts one element early).
 // Six transforms as on one device (h = den FFT^-1_coset(ca cb) - den FFT^-1(c)); each is a local size-M transform and one cross-rank
-// step between two all-to-alls over the group's transport: 12 batches of (world - 1) / world of a slice per rank.
+// step between two all-to-alls over the group's transport -- 9 batches of (world - 1) / world of a slice per rank: the pair between
+// the coset transforms of a, b and the last transform cancels.
 // Local failures are CARRIED THROUGH every batch (the peers are in them) and returned at the end; a transport failure breaks the group.
 static bool sharded_h_possible(const mi_group *g, u32 log_n) {
     const int W = g->world;
@@ -980,6 +981,7 @@ static int32_t compute_h_sharded(mi_group *g, u32 log_n, bool derive_c) {
     each([&](int i, mi_ctx *c) -> int32_t {
         MI_TRY(mi_cross_tables_build(c, log_n, log_w, (u32)(g->rank0 + i), &g->xt[i]));
         MI_TRY(mi_reserve(c, g->hy[i], M * sizeof(Fr)));
+        MI_TRY(mi_reserve(c, g->hy2[i], M * sizeof(Fr)));
         return mi_reserve(c, g->hh[i], (M + 1) * sizeof(Fr));
     });
     // all-to-all: block d of the source rank's buffer -> block s of rank d's buffer (the same rule in both directions)
@@ -1010,24 +1012,26 @@ static int32_t compute_h_sharded(mi_group *g, u32 log_n, bool derive_c) {
         each([&](int i, mi_ctx *c) { return mi_ntt_dev_impl(c, (mi_fr *)X[i].p, log_m, MI_NTT_INVERSE); });
         return MI_OK;
     };
-    // FFT on the coset (coefficient slices -> natural-order evaluation slices)
-    auto forward_coset = [&](std::vector<DevBuf> &X) -> int32_t {
+    // FFT on the coset up to its cross-rank step: coefficient slices -> in Y, for this rank's COLUMNS, all W rows of the natural-order
+    // evaluations.  The all-to-all that would take the rows home and the one that would bring them back for the next (inverse)
+    // transform's cross-rank step cancel: the pointwise product a b is formed on the columns, where both vectors sit alike.
+    auto forward_coset_to_columns = [&](std::vector<DevBuf> &X, std::vector<DevBuf> &Y) -> int32_t {
         each([&](int i, mi_ctx *c) -> int32_t {
             MI_TRY(mi_cross_mul(c, c->stream, X[i].p, X[i].p, g->xt[i].s_fwd, nullptr, M));
             return mi_ntt_dev_impl(c, (mi_fr *)X[i].p, log_m, MI_NTT_DIT);
         });
-        MI_TRY(a2a(X, g->hy));
-        each([&](int i, mi_ctx *c) { return mi_cross_dft(c, c->stream, g->hy[i].p, g->xt[i], 1, false); });
-        return a2a(g->hy, X);
+        return a2a(X, Y);   // (the cross-rank step itself runs in the middle kernel, with b's and the product)
     };
     if (derive_c) each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, g->hx[2][i].p, g->hx[0][i].p, g->hx[1][i].p, nullptr, M); });
     MI_TRY(inverse(g->hx[0], false));
     MI_TRY(inverse(g->hx[1], false));
     MI_TRY(inverse(g->hx[2], true));          // den * coefficients of c
-    MI_TRY(forward_coset(g->hx[0]));
-    MI_TRY(forward_coset(g->hx[1]));
-    each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, g->hx[0][i].p, g->hx[0][i].p, g->hx[1][i].p, nullptr, M); });
-    MI_TRY(inverse(g->hx[0], false));
+    MI_TRY(forward_coset_to_columns(g->hx[0], g->hy));
+    MI_TRY(forward_coset_to_columns(g->hx[1], g->hy2));
+    // the last transform, FFTInverse of the product, entered at its cross-rank step: 9 all-to-alls per computeH instead of 12
+    each([&](int i, mi_ctx *c) { return mi_cross_mid(c, c->stream, g->hy[i].p, g->hy2[i].p, g->xt[i]); });
+    MI_TRY(a2a(g->hy, g->hx[0]));
+    each([&](int i, mi_ctx *c) { return mi_ntt_dev_impl(c, (mi_fr *)g->hx[0][i].p, log_m, MI_NTT_INVERSE); });
     // h = den g^-k (.) - den c_k, into the h slice behind its front slot
     each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, (char *)g->hh[i].p + sizeof(Fr), g->hx[0][i].p, g->xt[i].s_inv, g->hx[2][i].p, M); });
     {   // every rank's last coefficient -> the front slot of the next rank

@@ -14,4 +14,7 @@ void mi_cross_tables_free(CrossNttTables *t);
 // in place on Y = W rows (source ranks) of M / W columns: mode 0 = the inverse transform's cross-rank step (rows in, natural; rows out,
 // bit-reversed; every output times 1 / W, or den / W), mode 1 = the forward transform's (rows in, bit-reversed; rows out, natural)
 int32_t mi_cross_dft(mi_ctx *ctx, hipStream_t st, void *Y, const CrossNttTables &t, int mode, bool den_scale);
+// computeH's middle on the columns: Ya <- inverse step(forward step(Ya) o forward step(Yb)) -- the coset transforms' cross-rank steps
+// of a and b, their product and the last transform's cross-rank step in one kernel
+int32_t mi_cross_mid(mi_ctx *ctx, hipStream_t st, void *Ya, const void *Yb, const CrossNttTables &t);
 int32_t mi_cross_mul(mi_ctx *ctx, hipStream_t st, void *z, const void *x, const void *y, const void *w_or_null, size_t n);

@@ -22,54 +22,85 @@ struct CrossArgs {
     u32 cnt;      // columns this rank owns (M / W)
 };
 
-// Y: W rows of cnt elements (row = the rank the values came from).  One thread per column.
-// mode 0: rows in natural j1 order -> DIF butterflies (outputs in bit-reversed k1 order: row p holds k1 = bitrev(p)) -> times scale * t^k1
-// mode 1: rows in bit-reversed k1 order -> times t^k1 -> DIT butterflies -> rows in natural i1 order
-// t = tw[column] = w^(-j2) / w^(+i2) for this rank's columns.
+// The W values of one column in registers.  (Every loop below has a compile-time trip count and compile-time indices.)
+// DIF half (the inverse transform's cross-rank step): rows in natural j1 order -> butterflies (outputs in bit-reversed k1 order: slot p
+// holds k1 = bitrev(p)) -> times scale * t^k1, t = w^(-j2)
+template <int LOGW>
+MI_D void cross_inverse_step(Fr (&v)[1 << LOGW], const Fr &t, const Fr &scale, const Fr (&wp)[8]) {
+    constexpr int W = 1 << LOGW;
+    Fr pw[W];
+    pw[0] = scale;
+#pragma unroll
+    for (int k = 1; k < W; k++) pw[k] = pw[k - 1] * t;
+#pragma unroll
+    for (int s = 0; s < LOGW; s++) {   // butterflies of span W >> s
+        const int len = W >> s, half = len >> 1, step = 1 << s;
+#pragma unroll
+        for (int i = 0; i < W / 2; i++) {
+            const int k = i % half, lo = (i / half) * len + k, hi = lo + half;
+            const Fr u = v[lo], x = v[hi];
+            v[lo] = u + x;
+            v[hi] = k ? (u - x) * wp[k * step] : (u - x);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < W; p++) v[p] = v[p] * pw[bitrev_u32((u32)p, LOGW)];
+}
+// DIT half (the forward transform's): slots in bit-reversed k1 order -> times t^k1, t = w^(+i2) -> butterflies -> rows in natural i1 order
+template <int LOGW>
+MI_D void cross_forward_step(Fr (&v)[1 << LOGW], const Fr &t, const Fr (&wp)[8]) {
+    constexpr int W = 1 << LOGW;
+    Fr pw[W];
+    pw[0] = Fr::one();
+#pragma unroll
+    for (int k = 1; k < W; k++) pw[k] = pw[k - 1] * t;
+#pragma unroll
+    for (int p = 0; p < W; p++) { const u32 k1 = bitrev_u32((u32)p, LOGW); if (k1) v[p] = v[p] * pw[k1]; }
+#pragma unroll
+    for (int s = LOGW - 1; s >= 0; s--) {   // spans 2, 4, ..., W
+        const int len = W >> s, half = len >> 1, step = 1 << s;
+#pragma unroll
+        for (int i = 0; i < W / 2; i++) {
+            const int k = i % half, lo = (i / half) * len + k, hi = lo + half;
+            const Fr u = v[lo], x = k ? v[hi] * wp[k * step] : v[hi];
+            v[lo] = u + x;
+            v[hi] = u - x;
+        }
+    }
+}
+// Y: W rows of cnt elements (row = the rank the values came from).  One thread per column; mode 0 = inverse step, 1 = forward step.
 template <int LOGW>
 __global__ void __launch_bounds__(256) k_cross_dft(Fr *Y, const Fr *tw, CrossArgs a, int mode) {
     constexpr int W = 1 << LOGW;
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= a.cnt) return;
-    Fr v[W], pw[W];
+    Fr v[W];
 #pragma unroll
     for (int p = 0; p < W; p++) v[p] = Y[(size_t)p * a.cnt + j];
     const Fr t = tw[j];
-    pw[0] = a.scale;
-#pragma unroll
-    for (int k = 1; k < W; k++) pw[k] = pw[k - 1] * t;
-    // (every loop below has a compile-time trip count and compile-time indices: v and pw stay in registers)
-    if (mode == 0) {
-#pragma unroll
-        for (int s = 0; s < LOGW; s++) {   // DIF: butterflies of span W >> s
-            const int len = W >> s, half = len >> 1, step = 1 << s;
-#pragma unroll
-            for (int i = 0; i < W / 2; i++) {
-                const int k = i % half, lo = (i / half) * len + k, hi = lo + half;
-                const Fr u = v[lo], x = v[hi];
-                v[lo] = u + x;
-                v[hi] = k ? (u - x) * a.wp[k * step] : (u - x);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < W; p++) v[p] = v[p] * pw[bitrev_u32((u32)p, LOGW)];
-    } else {
-#pragma unroll
-        for (int p = 0; p < W; p++) { const u32 k1 = bitrev_u32((u32)p, LOGW); if (k1) v[p] = v[p] * pw[k1]; }
-#pragma unroll
-        for (int s = LOGW - 1; s >= 0; s--) {   // DIT: spans 2, 4, ..., W
-            const int len = W >> s, half = len >> 1, step = 1 << s;
-#pragma unroll
-            for (int i = 0; i < W / 2; i++) {
-                const int k = i % half, lo = (i / half) * len + k, hi = lo + half;
-                const Fr u = v[lo], x = k ? v[hi] * a.wp[k * step] : v[hi];
-                v[lo] = u + x;
-                v[hi] = u - x;
-            }
-        }
-    }
+    if (mode == 0) cross_inverse_step<LOGW>(v, t, a.scale, a.wp);
+    else cross_forward_step<LOGW>(v, t, a.wp);
 #pragma unroll
     for (int p = 0; p < W; p++) Y[(size_t)p * a.cnt + j] = v[p];
+}
+// computeH's middle on the columns: the forward step of a and of b, the product a b, the inverse step of the last transform -- one
+// read of the two column blocks and one write instead of three kernels over them (Ya <- result).
+template <int LOGW>
+__global__ void __launch_bounds__(256) k_cross_mid(Fr *Ya, const Fr *Yb, const Fr *tw_fwd, const Fr *tw_inv, CrossArgs f, CrossArgs inv) {
+    constexpr int W = 1 << LOGW;
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= f.cnt) return;
+    Fr va[W], vb[W];
+#pragma unroll
+    for (int p = 0; p < W; p++) { va[p] = Ya[(size_t)p * f.cnt + j]; vb[p] = Yb[(size_t)p * f.cnt + j]; }
+    const Fr t = tw_fwd[j];
+    cross_forward_step<LOGW>(va, t, f.wp);
+    cross_forward_step<LOGW>(vb, t, f.wp);
+#pragma unroll
+    for (int p = 0; p < W; p++) va[p] = va[p] * vb[p];
+    cross_inverse_step<LOGW>(va, tw_inv[j], inv.scale, inv.wp);
+#pragma unroll
+    for (int p = 0; p < W; p++) Ya[(size_t)p * f.cnt + j] = va[p];
 }
 
 // out[j] = c * base^(first + j)
@@ -148,15 +179,19 @@ int32_t mi_cross_tables_build(mi_ctx *ctx, u32 log_n, u32 log_w, u32 rank, Cross
     t->log_n = log_n; t->log_w = log_w; t->rank = rank;
     return MI_OK;
 }
-// in place on Y (W rows of M / W columns) on stream st; den_scale: mode 0's outputs carry den / W instead of 1 / W
-int32_t mi_cross_dft(mi_ctx *ctx, hipStream_t st, void *Y, const CrossNttTables &t, int mode, bool den_scale) {
-    const u32 W = 1u << t.log_w, cnt = 1u << (t.log_n - 2 * t.log_w);
-    CrossArgs a;
+static void cross_args(const CrossNttTables &t, int mode, bool den_scale, CrossArgs *a) {
+    const u32 W = 1u << t.log_w;
     const Fr ww = cross_domain_generator(t.log_w), base = mode == 0 ? fe_inv(ww) : ww;
     Fr p = Fr::one();
-    for (u32 e = 0; e < 8; e++) { a.wp[e] = p; if (e + 1 < W / 2) p = p * base; }
-    a.scale = mode == 0 ? (den_scale ? t.w_inv_scale * t.den : t.w_inv_scale) : Fr::one();
-    a.cnt = cnt;
+    for (u32 e = 0; e < 8; e++) { a->wp[e] = p; if (e + 1 < W / 2) p = p * base; }
+    a->scale = mode == 0 ? (den_scale ? t.w_inv_scale * t.den : t.w_inv_scale) : Fr::one();
+    a->cnt = 1u << (t.log_n - 2 * t.log_w);
+}
+// in place on Y (W rows of M / W columns) on stream st; den_scale: mode 0's outputs carry den / W instead of 1 / W
+int32_t mi_cross_dft(mi_ctx *ctx, hipStream_t st, void *Y, const CrossNttTables &t, int mode, bool den_scale) {
+    CrossArgs a;
+    cross_args(t, mode, den_scale, &a);
+    const u32 cnt = a.cnt;
     const Fr *tw = (const Fr *)(mode == 0 ? t.tw_inv : t.tw_fwd);
     const dim3 grid((cnt + 255) / 256), block(256);
     switch (t.log_w) {
@@ -164,6 +199,21 @@ int32_t mi_cross_dft(mi_ctx *ctx, hipStream_t st, void *Y, const CrossNttTables 
     case 2: hipLaunchKernelGGL(k_cross_dft<2>, grid, block, 0, st, (Fr *)Y, tw, a, mode); break;
     case 3: hipLaunchKernelGGL(k_cross_dft<3>, grid, block, 0, st, (Fr *)Y, tw, a, mode); break;
     default: hipLaunchKernelGGL(k_cross_dft<4>, grid, block, 0, st, (Fr *)Y, tw, a, mode); break;
+    }
+    MI_CHECK_HIP(ctx, hipGetLastError());
+    return MI_OK;
+}
+// Ya <- inverse step(forward step(Ya) o forward step(Yb)), in place on stream st (k_cross_mid)
+int32_t mi_cross_mid(mi_ctx *ctx, hipStream_t st, void *Ya, const void *Yb, const CrossNttTables &t) {
+    CrossArgs f, inv;
+    cross_args(t, 1, false, &f); cross_args(t, 0, false, &inv);
+    const dim3 grid((f.cnt + 255) / 256), block(256);
+    const Fr *tf = (const Fr *)t.tw_fwd, *ti = (const Fr *)t.tw_inv;
+    switch (t.log_w) {
+    case 1: hipLaunchKernelGGL(k_cross_mid<1>, grid, block, 0, st, (Fr *)Ya, (const Fr *)Yb, tf, ti, f, inv); break;
+    case 2: hipLaunchKernelGGL(k_cross_mid<2>, grid, block, 0, st, (Fr *)Ya, (const Fr *)Yb, tf, ti, f, inv); break;
+    case 3: hipLaunchKernelGGL(k_cross_mid<3>, grid, block, 0, st, (Fr *)Ya, (const Fr *)Yb, tf, ti, f, inv); break;
+    default: hipLaunchKernelGGL(k_cross_mid<4>, grid, block, 0, st, (Fr *)Ya, (const Fr *)Yb, tf, ti, f, inv); break;
     }
     MI_CHECK_HIP(ctx, hipGetLastError());
     return MI_OK;

@@ -337,7 +337,7 @@ int32_t mi_group_set_lead_share(mi_group *g, uint32_t permille);
 /* wires [*lo, *hi) of global rank `rank` under the group's current lead share */
 int32_t mi_group_wire_range(const mi_group *g, uint64_t nb_wires, int rank, uint64_t *lo, uint64_t *hi);
 /* computeH OVER the ranks (2, 4, 8 or 16 of them, N >= ranks^2): every transform becomes a local size-N/ranks transform and one
- * cross-rank step between two all-to-alls over the group's transport (12 batches per computeH, each moving (ranks - 1) / ranks of a
+ * cross-rank step between two all-to-alls over the group's transport (9 batches per computeH, each moving (ranks - 1) / ranks of a
  * slice per rank), and the h slices are born on the ranks whose Z pairs they multiply -- instead of rank 0 transforming alone while the
  * others wait for h (the cap of a proof sharded over 8 GPUs moves from ~3x to the MSMs' own 1 / ranks).  Same h, same
  * proof bytes.  on = 1: mi_groth16_prove_sharded (host arrays) then needs a and b (and c, or NULL) in EVERY process, not on rank 0's

@@ -210,7 +210,7 @@ def scenario_inject(B, rank, world, seed_hex):
         g, spk = fresh()
         got, _ = g.prove(spk, W, a if lead else None, b if lead else None, cc if lead else None, r, s, mode=mode)
         assert B.proof_write(got["raw"]) == want, "the group must prove correctly after a failed call"
-    # the same with computeH OVER THE RANKS (local failures are carried through its twelve all-to-alls: nobody may be left waiting in one)
+    # the same with computeH OVER THE RANKS (local failures are carried through its nine all-to-alls: nobody may be left waiting in one)
     for victim, nth in ((1, 3), (0, 6), (1, 10), (0, 16), (1, 24), (1, 36), (0, 50), (1, 70)):
         g.set_sharded_compute_h(True)
         if rank == victim:
