@@ -87,7 +87,7 @@ struct mi_group {
     bool sharded_h = false;        // mi_group_set_sharded_compute_h: mi_groth16_prove_sharded runs computeH over all ranks
     std::vector<CrossNttTables> xt;
     std::vector<DevBuf> hx[3], hy, hy2, hh;
-    std::vector<hipEvent_t> ev_c0, ev_c1;
+    std::vector<hipEvent_t> ev_c0, ev_c1, ev_r;
     uint32_t lead_share = 0xffffffffu;   // permille of an even wire share that rank 0 -- which also runs computeH -- takes (mi_group_set_lead_share; all ones = automatic)
     int timeout_ms = 60000;        // how long a rank waits for its peers without anything completing (MI_GROUP_TIMEOUT_MS; both transports)
     bool nonblocking = false;      // transport 1, one rank per process: the communicator is non-blocking and every wait on it is a deadline poll
@@ -560,6 +560,7 @@ int32_t mi_group_destroy(mi_group *g) {
         if (i < (int)g->comm.size() && g->comm[i]) (void)(g->broken ? ncclCommAbort(g->comm[i]) : ncclCommDestroy(g->comm[i]));
         for (auto *v : {&g->ev_x, &g->ev_in, &g->ev_done, &g->ev_h}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
         for (auto *v : {&g->ev_c0, &g->ev_c1}) if (i < (int)v->size() && (*v)[i]) (void)hipEventDestroy((*v)[i]);
+        for (size_t k = (size_t)i * 7; k < (size_t)(i + 1) * 7 && k < g->ev_r.size(); k++) if (g->ev_r[k]) (void)hipEventDestroy(g->ev_r[k]);
         for (auto *v : {&g->hx[0], &g->hx[1], &g->hx[2], &g->hy, &g->hy2, &g->hh}) if (i < (int)v->size() && (*v)[i].p) (void)hipFree((*v)[i].p);
         if (i < (int)g->xt.size()) mi_cross_tables_free(&g->xt[i]);
         if (i < (int)g->recv.size() && g->recv[i].p) (void)hipFree(g->recv[i].p);
@@ -984,8 +985,27 @@ static int32_t compute_h_sharded(mi_group *g, u32 log_n, bool derive_c) {
         MI_TRY(mi_reserve(c, g->hy2[i], M * sizeof(Fr)));
         return mi_reserve(c, g->hh[i], (M + 1) * sizeof(Fr));
     });
-    // all-to-all: block d of the source rank's buffer -> block s of rank d's buffer (the same rule in both directions)
-    auto a2a = [&](std::vector<DevBuf> &from, std::vector<DevBuf> &to) -> int32_t {
+    // Seven "ready" events per local rank: a transfer waits for the ONE kernel that produced what it moves, not for whatever else has
+    // been enqueued on the context's stream since -- that is what lets the next vector's arithmetic run under this vector's transfer.
+    enum { E_IN, E_DA, E_DB, E_DC, E_FA, E_FB, E_MID, E_COUNT };
+    if (g->ev_r.size() != (size_t)nl * E_COUNT) {
+        for (hipEvent_t e : g->ev_r) if (e) (void)hipEventDestroy(e);
+        g->ev_r.assign((size_t)nl * E_COUNT, nullptr);
+        for (int i = 0; i < nl; i++) {
+            (void)hipSetDevice(g->dev[i]);
+            for (int k = 0; k < E_COUNT; k++) if (hipEventCreateWithFlags(&g->ev_r[(size_t)i * E_COUNT + k], hipEventDisableTiming) != hipSuccess) note(MI_EHIP, "sharded computeH: hipEventCreate failed");
+        }
+    }
+    auto mark = [&](int k) {
+        for (int i = 0; i < nl; i++) {
+            (void)hipSetDevice(g->dev[i]);
+            hipEvent_t e = g->ev_r[(size_t)i * E_COUNT + k];
+            if (!e || hipEventRecord(e, g->ctx[i]->stream) != hipSuccess) note(MI_EHIP, "sharded computeH: hipEventRecord failed");
+        }
+    };
+    // all-to-all: block d of the source rank's buffer -> block s of rank d's buffer (the same rule in both directions); the exchange
+    // streams pick up behind event `after` of their context's stream and hand back to it when the batch is done
+    auto a2a = [&](std::vector<DevBuf> &from, std::vector<DevBuf> &to, int after) -> int32_t {
         std::vector<Xfer> list;
         for (int s = 0; s < W; s++) for (int d = 0; d < W; d++) {
             Xfer x{s, d, nullptr, nullptr, row};
@@ -993,45 +1013,54 @@ static int32_t compute_h_sharded(mi_group *g, u32 log_n, bool derive_c) {
             if (g->local(d)) x.dp = (char *)to[d - g->rank0].p + (size_t)s * row;
             list.push_back(x);
         }
-        for (int i = 0; i < nl; i++) {   // the exchange streams pick up behind the contexts' streams ...
+        for (int i = 0; i < nl; i++) {
             (void)hipSetDevice(g->dev[i]);
-            if (hipEventRecord(g->ev_c0[i], g->ctx[i]->stream) != hipSuccess || hipStreamWaitEvent(g->xs[i], g->ev_c0[i], 0) != hipSuccess) note(MI_EHIP, "sharded computeH: stream hand-over failed");
+            hipEvent_t e = g->ev_r[(size_t)i * E_COUNT + after];
+            if (!e || hipStreamWaitEvent(g->xs[i], e, 0) != hipSuccess) note(MI_EHIP, "sharded computeH: stream hand-over failed");
         }
         MI_TRY(run_xfers(g, list, g->xs));
-        for (int i = 0; i < nl; i++) {   // ... and hand back
+        for (int i = 0; i < nl; i++) {
             (void)hipSetDevice(g->dev[i]);
             if (hipEventRecord(g->ev_c1[i], g->xs[i]) != hipSuccess || hipStreamWaitEvent(g->ctx[i]->stream, g->ev_c1[i], 0) != hipSuccess) note(MI_EHIP, "sharded computeH: stream hand-over failed");
         }
         return MI_OK;
     };
-    // FFTInverse (natural slices -> coefficient slices in bit-reversed order), every coefficient times 1 / N (den / N)
-    auto inverse = [&](std::vector<DevBuf> &X, bool den_scale) -> int32_t {
-        MI_TRY(a2a(X, g->hy));
-        each([&](int i, mi_ctx *c) { return mi_cross_dft(c, c->stream, g->hy[i].p, g->xt[i], 0, den_scale); });
-        MI_TRY(a2a(g->hy, X));
-        each([&](int i, mi_ctx *c) { return mi_ntt_dev_impl(c, (mi_fr *)X[i].p, log_m, MI_NTT_INVERSE); });
-        return MI_OK;
-    };
-    // FFT on the coset up to its cross-rank step: coefficient slices -> in Y, for this rank's COLUMNS, all W rows of the natural-order
-    // evaluations.  The all-to-all that would take the rows home and the one that would bring them back for the next (inverse)
-    // transform's cross-rank step cancel: the pointwise product a b is formed on the columns, where both vectors sit alike.
-    auto forward_coset_to_columns = [&](std::vector<DevBuf> &X, std::vector<DevBuf> &Y) -> int32_t {
+    // the pieces of a transform (csrc/ntt_cross.hip header): cross-rank step of FFTInverse on the columns in Y; local size-M FFTInverse;
+    // coset factor + local size-M FFT (DIT) of a coefficient slice
+    auto cross_inv = [&](std::vector<DevBuf> &Y, bool den_scale) { each([&](int i, mi_ctx *c) { return mi_cross_dft(c, c->stream, Y[i].p, g->xt[i], 0, den_scale); }); };
+    auto local_inv = [&](std::vector<DevBuf> &X) { each([&](int i, mi_ctx *c) { return mi_ntt_dev_impl(c, (mi_fr *)X[i].p, log_m, MI_NTT_INVERSE); }); };
+    auto local_fwd = [&](std::vector<DevBuf> &X) {
         each([&](int i, mi_ctx *c) -> int32_t {
             MI_TRY(mi_cross_mul(c, c->stream, X[i].p, X[i].p, g->xt[i].s_fwd, nullptr, M));
             return mi_ntt_dev_impl(c, (mi_fr *)X[i].p, log_m, MI_NTT_DIT);
         });
-        return a2a(X, Y);   // (the cross-rank step itself runs in the middle kernel, with b's and the product)
     };
-    if (derive_c) each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, g->hx[2][i].p, g->hx[0][i].p, g->hx[1][i].p, nullptr, M); });
-    MI_TRY(inverse(g->hx[0], false));
-    MI_TRY(inverse(g->hx[1], false));
-    MI_TRY(inverse(g->hx[2], true));          // den * coefficients of c
-    MI_TRY(forward_coset_to_columns(g->hx[0], g->hy));
-    MI_TRY(forward_coset_to_columns(g->hx[1], g->hy2));
-    // the last transform, FFTInverse of the product, entered at its cross-rank step: 9 all-to-alls per computeH instead of 12
-    each([&](int i, mi_ctx *c) { return mi_cross_mid(c, c->stream, g->hy[i].p, g->hy2[i].p, g->xt[i]); });
-    MI_TRY(a2a(g->hy, g->hx[0]));
-    each([&](int i, mi_ctx *c) { return mi_ntt_dev_impl(c, (mi_fr *)g->hx[0][i].p, log_m, MI_NTT_INVERSE); });
+    std::vector<DevBuf> &Xa = g->hx[0], &Xb = g->hx[1], &Xc = g->hx[2], &Y0 = g->hy, &Y1 = g->hy2;
+    // The six transforms, interleaved so that a batch of the transport moves one vector while the kernels of another run (a batch
+    // blocks this thread until it is complete -- the transports' deadline rule -- so what should overlap it is enqueued BEFORE it):
+    //   FFTInverse(a), (b), (c) = [rows -> columns] cross-rank step [columns -> rows] local transform;  FFT_coset(a), (b) = factor, local
+    //   transform [rows -> columns];  then the middle kernel (cross-rank steps of a and b, product, cross-rank step of the last
+    //   FFTInverse: the all-to-all pair in between cancels)  [columns -> rows]  local transform.   9 batches.
+    if (derive_c) each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, Xc[i].p, Xa[i].p, Xb[i].p, nullptr, M); });
+    mark(E_IN);
+    MI_TRY(a2a(Xa, Y0, E_IN));
+    cross_inv(Y0, false); mark(E_DA);
+    MI_TRY(a2a(Xb, Y1, E_IN));                 // under a's cross-rank step
+    cross_inv(Y1, false); mark(E_DB);
+    MI_TRY(a2a(Y0, Xa, E_DA));                 // under b's cross-rank step
+    local_inv(Xa); local_fwd(Xa); mark(E_FA);
+    MI_TRY(a2a(Xc, Y0, E_IN));                 // under a's two local transforms
+    cross_inv(Y0, true); mark(E_DC);           // den * coefficients of c
+    MI_TRY(a2a(Y1, Xb, E_DB));
+    local_inv(Xb); local_fwd(Xb); mark(E_FB);
+    MI_TRY(a2a(Y0, Xc, E_DC));                 // under b's two local transforms
+    local_inv(Xc);
+    MI_TRY(a2a(Xa, Y0, E_FA));                 // under c's local transform
+    MI_TRY(a2a(Xb, Y1, E_FB));
+    each([&](int i, mi_ctx *c) { return mi_cross_mid(c, c->stream, Y0[i].p, Y1[i].p, g->xt[i]); });
+    mark(E_MID);
+    MI_TRY(a2a(Y0, Xa, E_MID));
+    local_inv(Xa);
     // h = den g^-k (.) - den c_k, into the h slice behind its front slot
     each([&](int i, mi_ctx *c) { return mi_cross_mul(c, c->stream, (char *)g->hh[i].p + sizeof(Fr), g->hx[0][i].p, g->xt[i].s_inv, g->hx[2][i].p, M); });
     {   // every rank's last coefficient -> the front slot of the next rank
