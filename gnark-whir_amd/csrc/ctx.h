@@ -16,8 +16,6 @@ struct DevBuf {             // growable device scratch owned by the ctx (no hipM
 #define MI_MSM_SLOTS 6
 struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, workspaces, pinned result
     hipStream_t stream = nullptr;
-    hipStream_t l1_stream = nullptr;   // knob "l1_stream": the level-1 accumulate launch alone runs here (lowest priority), between two events
-    hipEvent_t ev_l1[2]{};
     hipEvent_t ev[7]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job, 5: bucket sums ready (deferred reduce),
                             // 6: the largest bucket's size has landed in host memory (exact level count, msm.hip)
     bool max_pending = false;       // this slot's sort has a "largest bucket" word on its way to the host (ev[6])

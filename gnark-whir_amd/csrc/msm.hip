@@ -41,7 +41,6 @@ struct MsmKnobs {
     u32 plain_scatter = 0;                      // fixed-base sort: 1 = pass 2 by the plain scatter instead of the staged one
     u32 finisher = 1;                           // 1: item levels whose fullest key holds <= finisher_max partial sums end in ONE launch (k_msm_finish_keys)
     u32 finisher_max = 0;                       // 0 = automatic
-    u32 l1_stream = 0;                          // 1: the level-1 accumulate launches run on streams of their own at the lowest priority
     u32 finisher_min_level = 2;                 // the finisher may follow accumulate pass number finisher_min_level + 1 at the earliest
 };
 static_assert(sizeof(MsmKnobs) <= sizeof(mi_ctx::msm_knobs), "mi_ctx::msm_knobs is too small");
@@ -421,8 +420,6 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     (void)hipStreamDestroy(ctx->msm[3].stream);
     ctx->msm[3].stream = ctx->msm[1].stream;
     for (auto &sl : ctx->msm) {
-        MI_CHECK_HIP(ctx, hipStreamCreateWithPriority(&sl.l1_stream, hipStreamNonBlocking, prio_lo));
-        for (auto &e : sl.ev_l1) MI_CHECK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : sl.ev) MI_CHECK_HIP(ctx, hipEventCreate(&e));
         MI_CHECK_HIP(ctx, hipHostMalloc(&sl.host_wsum, 128 * 256 + 64));
     }
@@ -432,8 +429,6 @@ void mi_msm_state_free(mi_ctx *ctx) {
     for (int i = 0; i < MI_MSM_SLOTS; i++) for (int j = i + 1; j < MI_MSM_SLOTS; j++) if (ctx->msm[j].stream == ctx->msm[i].stream) ctx->msm[j].stream = nullptr;   // aliases
     for (auto &sl : ctx->msm) {
         if (sl.stream) { (void)hipStreamSynchronize(sl.stream); (void)hipStreamDestroy(sl.stream); }
-        if (sl.l1_stream) { (void)hipStreamSynchronize(sl.l1_stream); (void)hipStreamDestroy(sl.l1_stream); }
-        for (auto &e : sl.ev_l1) if (e) (void)hipEventDestroy(e);
         for (auto &e : sl.ev) if (e) (void)hipEventDestroy(e);
         if (sl.host_wsum) (void)hipHostFree(sl.host_wsum);
         for (auto &b : sl.buf) if (b.p) (void)hipFree(b.p);
@@ -506,7 +501,6 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
         // the timed span (mi_stats.g1_accum_kernel_ms) brackets the accumulate kernel alone: on the 29-bit path the launcher records the
         // opening event AFTER its item-table kernel (0.1 ms alone, up to 0.5 ms waiting for CUs with three proofs in flight)
         const bool rp_path = level == 0 && pts && rprime && ops.accum_affine_rp;
-        hipStream_t lst = st;   // the stream of this level's accumulate launch
         if (time_first && level == 0 && !rp_path) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[1], st));
         const u32 ba_rounds = knobs_of(ctx)->ba_rounds;
         // batch-affine rounds (msm_ba_g1.cuh) where the buckets hold a few items each (>= 32 entries on average) and the scratch fits
@@ -528,24 +522,15 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
             const bool g2 = ops.xyzz_bytes == 256;
             const bool two = !g2 && (kn->l1_waves == 2 || (kn->z_waves == 2 && &sl == &ctx->msm[4]));
             const u32 wg = g2 ? kn->g2_wg : kn->l1_wg, wg_log = wg == 4 ? 2u : wg == 2 ? 1u : 0u;   // waves per workgroup
-            // knob "l1_stream": this one launch on the slot's lowest-priority stream -- the accumulation is what fills the GPU; everything
-            // else (sorts, NTT passes, upper levels, reduces) is dispatched ahead of it whenever a workgroup of it retires
-            if (kn->l1_stream) {
-                MI_CHECK_HIP(ctx, hipEventRecord(sl.ev_l1[0], st));
-                MI_CHECK_HIP(ctx, hipStreamWaitEvent(sl.l1_stream, sl.ev_l1[0], 0));
-                lst = sl.l1_stream;
-            }
-            ops.accum_affine_rp(lst, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p,
+            // (the level-1 launches on lowest-priority streams of their own -- "the accumulation is what fills the GPU, everything else is
+            //  dispatched ahead of it" -- measured -6 % proofs/s, profiles/r05_ab_evidence.txt: removed)
+            ops.accum_affine_rp(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout, sl.buf[B_ITEMTAB].p,
                                 (rp_partials ? 1u : 0u) | (two ? 2u : 0u) | (wg_log << 2), time_first ? sl.ev[1] : nullptr);
         } else if (level == 0 && pts) ops.accum_affine(st, grid, pts, sorted, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else if (rp_partials) ops.accum_xyzz_rp(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         else ops.accum_xyzz(st, grid, pin, cur.start, cur.cnt, cur.items, cur.item_start, nkeys, L, final_out, pout);
         MI_CHECK_HIP(ctx, hipGetLastError());
-        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], lst));
-        if (lst != st) {
-            MI_CHECK_HIP(ctx, hipEventRecord(sl.ev_l1[1], lst));
-            MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, sl.ev_l1[1], 0));
-        }
+        if (time_first && level == 0) MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[2], st));
         u64 m_next = (m + L - 1) / L;  // entries of the largest key at the next level
         if (m_next <= 1) break;
         // the finisher: no key holds more than finish_max partial sums -> one list launch + one launch end the machinery (the lists live in
@@ -1024,7 +1009,6 @@ int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value) {
     else if (is("plain_scatter") && (value == 0 || value == 1)) k->plain_scatter = (u32)value;
     else if (is("finisher") && (value == 0 || value == 1)) k->finisher = (u32)value;
     else if (is("finisher_max") && value >= 0 && value <= (1 << 20)) k->finisher_max = (u32)value;
-    else if (is("l1_stream") && (value == 0 || value == 1)) k->l1_stream = (u32)value;
     else if (is("item_l1") && (value == 0 || (value >= 2 && value <= 64))) k->L1 = (u32)value;     // entries per level-1 item (0 = 16)
     else if (is("item_l2") && (value == 0 || (value >= 2 && value <= 64))) k->L2 = (u32)value;     // partial sums per item of the later levels (0 = 8)
     else if (is("reduce_seg") && value >= 0 && value <= 256) k->seg = (u32)value;                    // buckets per bucket-reduce thread (0 = 8)

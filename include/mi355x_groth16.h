@@ -583,7 +583,6 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
  *                            are where every ordinary bucket ends; a finisher over 2^19 buckets of 13 partial sums each measured -5 %)
  *   "item_l1", "item_l2", "reduce_seg"   = the L1, L2, seg of mi_debug_set_msm_plan, one at a time
  *   "hold_accum" 0 | 1       = mi_debug_set_prove_schedule
- *   "l1_stream" 0 | 1        1: the level-1 launches on lowest-priority streams of their own (measured -6 %: DESIGN.md 8)
  *   "ntt_lds_floor_kb" 0..160   LDS every NTT pass workgroup requests at least (caps the workgroups per CU) */
 int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value);
 /* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
