@@ -414,6 +414,7 @@ def main():
                     help="witness (W, a) distribution: the WHIR mix of SURVEY 8d (a documented guess), uniform Fr, or half of each (row by row)")
     ap.add_argument("--no-solo-legs", action="store_true", help="skip the solo MSM / computeH / probe legs after the proofs (PMC passes: their launches would mix into the per-kernel averages); the roofline line then falls back to the in-job launch")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the `sensitivity` legs (the same key proved with a half-uniform and a uniform witness)")
+    ap.add_argument("--stream-plan", type=int, default=-1, help="tuning: mi_debug_set_stream_plan before the pool is created (0, 1, 2; -1 = the library's default)")
     ap.add_argument("--knobs", default="", help="tuning: name=value,... for mi_debug_set_knob on every context of the pool (include/mi355x_groth16.h lists the names)")
     ap.add_argument("--n-committed", type=int, default=-1,
                     help="private wires under the proof's ONE BSB22 commitment (lookup operands; default 2^18 = N / 32, a documented estimate like the infinity ratios; 0 = a circuit without lookups: 164-byte proofs)")
@@ -480,6 +481,8 @@ def main():
     numa = bind_to_gpu_numa_node(torch, local_rank) if world > 1 and not args.rehearse_on_one_gpu else None   # (N = 1 keeps every core: the CPU baseline wants them)
 
     B = _binding()
+    if args.stream_plan >= 0:
+        assert B.load().mi_debug_set_stream_plan(args.stream_plan) == 0
     # the prover pool: --in-flight contexts on this rank's GPU (own streams, workspaces, host worker thread), one shared key
     pool = B.Prover(local_rank, args.in_flight if args.in_flight > 0 else (3 if args.log_n <= 24 else 1))
     ctx = pool.ctx(0)

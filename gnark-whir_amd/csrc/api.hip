@@ -7,6 +7,12 @@
 thread_local std::string *mi_err_sink = nullptr;
 std::atomic<int> mi_fault_countdown{0};
 
+int32_t mi_copy_stream(mi_ctx *ctx, hipStream_t *out) {
+    if (!ctx->copy_stream) MI_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    *out = ctx->copy_stream;
+    return MI_OK;
+}
+
 extern "C" {
 
 int32_t mi_debug_inject_hip_failure(int32_t nth) { mi_fault_countdown.store(nth > 0 ? nth : 0); return MI_OK; }
@@ -34,7 +40,8 @@ int32_t mi_init_prio(int device_id, int prio_scheme, mi_ctx **out) {
         if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ph) != hipSuccess) { (void)hipGetLastError(); delete ctx; return MI_EHIP; }
     }
     ctx->own_stream = true;
-    if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(ctx->stream); delete ctx; return MI_EHIP; }
+    // (ctx->copy_stream is created by its first user, mi_copy_stream: a stream takes a share of a hardware queue from the moment it
+    //  exists, and the contexts of a prover pool never copy through theirs)
     mi_ntt_state_init(ctx);
     // from here on a failure unwinds through mi_shutdown: it frees exactly what exists (null handles are skipped)
     int32_t rc = mi_msm_state_init(ctx);
@@ -64,7 +71,7 @@ int32_t mi_ctx_trim(mi_ctx *ctx) {
     if (!ctx) return MI_EINVAL;
     MI_CHECK_HIP(ctx, hipSetDevice(ctx->dev));
     MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+    if (ctx->copy_stream) MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
     for (auto &sl : ctx->msm) if (sl.stream) MI_CHECK_HIP(ctx, hipStreamSynchronize(sl.stream));
     for (auto &b : ctx->ws) if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
     for (auto &sl : ctx->msm) for (auto &b : sl.buf) if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }

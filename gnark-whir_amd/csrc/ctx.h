@@ -116,6 +116,8 @@ static inline bool mi_try_reserve(DevBuf &b, size_t bytes) {
     return true;
 }
 
+// ctx->copy_stream, created on first use (api.hip)
+int32_t mi_copy_stream(mi_ctx *ctx, hipStream_t *out);
 // internal entry points implemented across translation units
 int32_t mi_ntt_dev_impl(mi_ctx *ctx, mi_fr *inout_dev, uint32_t log_n, uint32_t flags);
 int32_t mi_compute_h_dev_impl(mi_ctx *ctx, uint32_t log_n, const mi_fr *a, const mi_fr *b, const mi_fr *c,

@@ -1321,9 +1321,11 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
         // host inputs: pageable copies on the context's copy stream (which carries nothing else), ordered by synchronising it on this
         // thread -- no event between two of them (prove.hip, pool.hip: a marker slows every copy behind it)
         const auto t_up = std::chrono::steady_clock::now();
+        hipStream_t cps = nullptr;
+        if (host) MI_TRY(mi_copy_stream(ctx, &cps));
         if (host && wb) {
-            MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)Wd, W_host + pk->wire_lo, wb, hipMemcpyHostToDevice, ctx->copy_stream));
-            MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+            MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)Wd, W_host + pk->wire_lo, wb, hipMemcpyHostToDevice, cps));
+            MI_CHECK_HIP(ctx, hipStreamSynchronize(cps));
         }
         MI_CHECK_HIP(ctx, hipEventRecord(ev[2], ctx->stream));
         MI_TRY(mi_prove_enqueue_wire_msms(ctx, pk, Wd, ev[2], defer));
@@ -1334,9 +1336,9 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
                 const mi_fr *src = abc_sl ? (abc_sl[which] ? abc_sl[which][i] : nullptr) : (which == 0 ? a : which == 1 ? b : c);
                 const bool given = abc_sl ? abc_sl[which] != nullptr : src != nullptr;
                 if (which == 2 && !given) { MI_TRY(mi_reserve(ctx, g->hx[2][i], sizeof(Fr) << log_m)); continue; }
-                MI_TRY(load_h_slice(g, i, which, log_m, src, !abc_sl, n_constraints, abc_sl ? ctx->stream : ctx->copy_stream));
+                MI_TRY(load_h_slice(g, i, which, log_m, src, !abc_sl, n_constraints, abc_sl ? ctx->stream : cps));
             }
-            if (!abc_sl) MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));   // (grown buffers: hipFree inside mi_reserve has synchronised already)
+            if (!abc_sl) MI_CHECK_HIP(ctx, hipStreamSynchronize(cps));   // (grown buffers: hipFree inside mi_reserve has synchronised already)
             return MI_OK;
         }
         if (!lead) return MI_OK;
@@ -1346,10 +1348,10 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
             char *base = (char *)ctx->ws[16].p;
             da = (mi_fr *)(base + wb); db = (mi_fr *)(base + wb + cb); dc = c ? (mi_fr *)(base + wb + 2 * cb) : nullptr;
             if (cb) {
-                MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)da, a, cb, hipMemcpyHostToDevice, ctx->copy_stream));
-                MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)db, b, cb, hipMemcpyHostToDevice, ctx->copy_stream));
-                if (c) MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dc, c, cb, hipMemcpyHostToDevice, ctx->copy_stream));
-                MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+                MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)da, a, cb, hipMemcpyHostToDevice, cps));
+                MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)db, b, cb, hipMemcpyHostToDevice, cps));
+                if (c) MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dc, c, cb, hipMemcpyHostToDevice, cps));
+                MI_CHECK_HIP(ctx, hipStreamSynchronize(cps));
             }
             ctx->stats.h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_up).count();
         }

@@ -379,6 +379,16 @@ static MsmShape key_shape(const MsmSlot &sl) {
     return s;
 }
 
+// Process-wide, read by mi_msm_state_init (experiments on which chains share a hardware queue: the runtime gives a new stream the
+// least-loaded of its priority class's four queues, ties to the newest -- tools/probes/stream_queue_probe.py):
+//   0  slot 3 (K) created, then destroyed and pointed at slot 1's stream (rounds 4-5)          1  slot 3 never created
+//   2  as 1, and slot 1 (B1 + K) on slot 0's stream (A): three wire chains instead of four
+static std::atomic<int> g_stream_plan{1};
+extern "C" int32_t mi_debug_set_stream_plan(int32_t plan) {
+    if (plan < 0 || plan > 2) return MI_EINVAL;
+    g_stream_plan.store(plan);
+    return MI_OK;
+}
 int32_t mi_msm_state_init(mi_ctx *ctx) {
     new (ctx->msm_knobs) MsmKnobs();
     // the c = 16 histogram / cursor image is 128 KiB of LDS (gfx950 allows 160 KiB per workgroup)
@@ -402,7 +412,10 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     // order in which the slots' streams are created decides WHICH two MSMs of a proof share a queue (rocprofv3: with the natural order
     // K (slot 3) queued behind B2's whole G2 chain (slot 2) and ended a single proof; every other order measured within 0.3 ms of
     // this one or worse).
+    const int plan = g_stream_plan.load();
     for (int idx = 0; idx < MI_MSM_SLOTS; idx++) {
+        if (plan >= 1 && idx == 3) continue;   // K's slot borrows a stream below
+        if (plan >= 2 && idx == 1) continue;
         MsmSlot &sl = ctx->msm[idx];
         int pw = 0, pz = prio_lo;   // wires, Z: MI_PRIO_SOLO, MI_PRIO_POOL_SECOND
         if (ctx->prio_scheme == MI_PRIO_POOL_FIRST) { pw = prio_hi; pz = 0; }
@@ -417,7 +430,8 @@ int32_t mi_msm_state_init(mi_ctx *ctx) {
     // (whose sort K shares) 0.8 ms.  The two chains are enqueued from two host threads (mi_prove_enqueue_b_msms / _ak_msms) and so
     // interleave on the one stream: their buffers are disjoint, every wait one of them inserts also holds the other, and the event
     // pair around K's level-1 launch may bracket a kernel of B1's chain (the stats of slot 3 are then an upper bound).
-    (void)hipStreamDestroy(ctx->msm[3].stream);
+    if (ctx->msm[3].stream) (void)hipStreamDestroy(ctx->msm[3].stream);
+    if (plan >= 2) ctx->msm[1].stream = ctx->msm[0].stream;
     ctx->msm[3].stream = ctx->msm[1].stream;
     for (auto &sl : ctx->msm) {
         for (auto &e : sl.ev) MI_CHECK_HIP(ctx, hipEventCreate(&e));

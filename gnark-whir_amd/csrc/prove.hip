@@ -575,9 +575,11 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         // -- the wire MSMs' 14 ms of work then start 5 ms later and nothing else can fill the bus time.)
         const size_t wb = n_wires * sizeof(mi_fr), cb = n_constraints * sizeof(mi_fr);
         const auto t_up = std::chrono::steady_clock::now();
+        hipStream_t cps = nullptr;
+        MI_TRY(mi_copy_stream(ctx, &cps));
         auto upload = [&](const mi_fr *dst, const mi_fr *src, size_t bytes) -> int32_t {
-            if (bytes) MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
-            MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+            if (bytes) MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dst, src, bytes, hipMemcpyHostToDevice, cps));
+            MI_CHECK_HIP(ctx, hipStreamSynchronize(cps));
             return MI_OK;
         };
         MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the staging area may still be read by an earlier call's kernels
