@@ -79,6 +79,52 @@ def cpu_baseline(pk_host, W, a, b, c, r, s, ped, log_n, gpu_proof_bytes):
             "proof_bytes_match": True, "proof_bytes_compared": len(cpu_bytes)}
 
 
+def _kernel_short(name):
+    """'void k_msm_accum_affine29<4, 3>(Affine<...> const*, ...)' -> 'k_msm_accum_affine29' (signature dropped; template arguments of the level-1 kernels too)"""
+    k = name.split("(")[0].replace("void ", "")
+    return k.split("<")[0] if k.startswith(("k_msm_accum_affine29", "k_msm_accum_affine_g2_29")) else k
+
+
+def live_pmc(script, script_args, counters, timeout_s=240):
+    """Hardware counters MEASURED BY THIS RUN: one child `rocprofv3 --pmc <counter>` per counter (separate passes, as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes; the program itself right after `--`) over tools/<script>.  Returns
+    {counter: {kernel: {"launches", "total", "per_launch"}}, "seconds": s} (values as rocprofv3 reports them, summed over the counter's dimensions:
+    KB for FETCH_SIZE / WRITE_SIZE) or {"error": ...}.  Children of a process that holds the GPU are started, never exec'ed into; the parent
+    is idle meanwhile (called after the timed regions)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    t0 = time.time()
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="live_pmc_", dir="/tmp")
+    try:
+        for counter in counters:
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", script)] + [str(x) for x in script_args]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            if r.returncode != 0:
+                return {"error": f"{counter} pass over {script}: rc {r.returncode}: {r.stdout.decode(errors='replace')[-200:]}"}
+            dbs = glob.glob(d + "/**/*_results.db", recursive=True)
+            if not dbs:
+                return {"error": f"{counter} pass over {script} wrote no rocpd database"}
+            agg = defaultdict(lambda: [set(), 0.0])
+            for k, did, v in sqlite3.connect(dbs[0]).execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=?", (counter,)):
+                k = _kernel_short(k); agg[k][0].add(did); agg[k][1] += v
+            out[counter] = {k: {"launches": len(v[0]), "total": v[1], "per_launch": v[1] / len(v[0])} for k, v in agg.items()}
+        out["seconds"] = time.time() - t0
+        return out
+    except Exception as e:   # a timeout, a refused profiler, an unreadable database: the line falls back to the committed passes and says so
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def sharded_msm_section(B, g, rank, world, log_n_msm, steps):
     """BASELINE configs[4]: ONE G1 MSM of 2^log_n_msm pairs, bases point-sharded over the ranks (one per GPU), through the C-ABI's
     device group g (mi_group_create_rank + mi_msm_g1_sharded_dev, csrc/group.hip): mode 0 = all-gather of per-rank partial sums,
@@ -419,6 +465,7 @@ def main():
     ap.add_argument("--n-committed", type=int, default=-1,
                     help="private wires under the proof's ONE BSB22 commitment (lookup operands; default 2^18 = N / 32, a documented estimate like the infinity ratios; 0 = a circuit without lookups: 164-byte proofs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the roofline launch's HBM traffic in THIS run (then: the committed passes)")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the second timed region (inputs already in HBM, no commitment: the GPU-side rate)")
     ap.add_argument("--in-flight", type=int, default=0,
                     help="proofs kept in flight per GPU by the prover pool (mi_prover_*); 1 = strictly one proof at a time; "
@@ -821,6 +868,13 @@ def main():
     for d in (g1a, g1b, g1k, g1z, g2b, W, a, b, c):
         d.free()   # (DevArray.free is idempotent)
     pool.close()
+    # the roofline launch's HBM traffic, measured now that this process holds nothing on the GPU (rank 0 of a one-GPU run only)
+    live_solo = live_proofs = None
+    under_profiler = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)   # never nest profilers
+    if rank == 0 and world == 1 and not args.no_live_pmc and not under_profiler and not args.no_solo_legs and log_n <= 24 and zsolo and "accum_launch_ms" in zsolo:
+        live_solo = live_pmc("solo_z_msm.py", [log_n, 2], ("FETCH_SIZE", "WRITE_SIZE"))
+        if "error" not in live_solo and args.dist == "whir":   # (tools/prof_proof.py proves this workload with the WHIR mix: four proofs alone on one context)
+            live_proofs = live_pmc("prof_proof.py", [log_n, 4], ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"))
     sharded, sharded_prove = {"done": False}, {"done": False}
     if helper is not None:
         sharded, sharded_prove = run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args)
@@ -831,42 +885,59 @@ def main():
         per_launch_bytes = 96.0 * accum_pairs / max(accum_launches, 1)
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
         g1_pairs_per_proof = na + nb + nk + (N - 1)
-        # HBM traffic per launch: NOT measured by this run -- read from the committed rocprofv3 --pmc passes of this same workload
-        # (profiles/r04_pmc_bench_traffic.json: FETCH_SIZE and WRITE_SIZE in separate passes, KB units; the file records the sha256 of the
-        # kernel sources it was collected on), and only reported when this run has the profiled shape (N = 2^23, WHIR mix, automatic
-        # plans) AND those sources are unchanged: a file older than the kernels reads as traffic: null, never as stale bytes.  The
-        # accumulate kernel gathers 64-B points, so its FETCH_SIZE is taken raw; the NTT passes stream 16 B per lane, so theirs gets
-        # the guide's x2 correction.
+        # HBM traffic per launch.  MEASURED BY THIS RUN when it can be (one GPU, no profiler around this process): child runs of
+        # `rocprofv3 --pmc` (live_pmc above) over the solo Z-shaped launch and over four proofs of this workload alone on one context.
+        # Otherwise -- and only for the profiled shape (N = 2^23, WHIR mix, automatic plans) with unchanged kernel sources -- the
+        # committed passes of profiles/r05_pmc_bench_traffic.json (sha256 of the sources recorded in it): a file older than the kernels
+        # reads as traffic: null, never as stale bytes.  The accumulate kernel gathers 64-B points, so its FETCH_SIZE is taken raw; the
+        # NTT passes stream 16 B per lane, so theirs gets the guide's x2 correction.
         traffic = traffic_ntt = traffic_solo = None
+        kname = "k_msm_accum_affine29"
         pmc_file = os.path.join("profiles", "r05_pmc_bench_traffic.json")
-        pmc_src = f"{pmc_file} (committed PMC passes of this workload, not this run; file sha256 {_sha16(os.path.join(ROOT, pmc_file))})"
         csrc = os.path.join(ROOT, "gnark-whir_amd", "csrc")
-        if log_n == 23 and args.dist == "whir" and not (args.msm_plan or args.fixed_base or args.ntt_plan or args.msm_group_bits or args.msm_chunk):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, pmc_file)))
-                src_now = {f: _sha16(os.path.join(csrc, f)) for f in pmc["_sources"]}
-                fresh_msm = all(src_now[f] == h for f, h in pmc["_sources"].items() if f.startswith(("msm", "curve29", "field29")))
-                fresh_ntt = all(src_now[f] == h for f, h in pmc["_sources"].items() if f.startswith(("ntt", "field.")))
-                kname = "k_msm_accum_affine29"
-                if fresh_msm:
-                    traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
-                    if "solo_z" in pmc:   # the same two counters over the solo Z-shaped launch (tools/solo_z_msm.py under --pmc)
-                        traffic_solo = (pmc["solo_z"]["FETCH_SIZE_kb"] + pmc["solo_z"]["WRITE_SIZE_kb"]) * 1024.0
-                else:
-                    pmc_src += "; STALE for the MSM kernels (their sources changed since the passes): traffic withheld"
-                if fresh_ntt:
-                    # per pass launch (the fused contiguous pair -- two launches per computeH -- and the fused strided triple -- one -- counted
-                    # with their own figures); one transform = a sixth of computeH's traffic
-                    per = lambda kn: (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0
-                    n_pair = 2 if "k_ntt_contig_pair" in pmc["FETCH_SIZE"] else 0
-                    n_triple = 1 if "k_ntt_strided_triple" in pmc["FETCH_SIZE"] else 0
-                    n_last = 1 if "k_ntt_contig_last_sub" in pmc["FETCH_SIZE"] else 0
-                    traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair - n_triple - n_last) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0) +
-                                   (per("k_ntt_strided_triple") if n_triple else 0.0) + (per("k_ntt_contig_last_sub") if n_last else 0.0)) / 6.0
-                else:
-                    pmc_src += "; STALE for the NTT kernels: traffic withheld"
-            except Exception:
-                traffic = traffic_ntt = None
+        pmc = None
+        fresh_msm = fresh_ntt = False
+        live_err = "; ".join(f"live passes failed: {x['error']}" for x in (live_solo, live_proofs) if x and "error" in x)
+        if live_proofs and "error" not in live_proofs:
+            pmc = {c_: {k: {"kb_per_launch": v["per_launch"], "launches": v["launches"]} for k, v in live_proofs[c_].items()} for c_ in ("FETCH_SIZE", "WRITE_SIZE")}
+            fresh_msm = fresh_ntt = True
+            pmc_src = (f"THIS RUN: child runs `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` / `--pmc SQ_INSTS_VALU` (separate passes) over tools/prof_proof.py {log_n} 4 "
+                       f"(four proofs of this workload alone on one context, {live_proofs['seconds']:.0f} s)")
+        else:
+            pmc_src = f"{pmc_file} (committed PMC passes of this workload, not this run; file sha256 {_sha16(os.path.join(ROOT, pmc_file))})" + (f"; {live_err}" if live_err else "")
+            if log_n == 23 and args.dist == "whir" and not (args.msm_plan or args.fixed_base or args.ntt_plan or args.msm_group_bits or args.msm_chunk):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, pmc_file)))
+                    src_now = {f: _sha16(os.path.join(csrc, f)) for f in pmc["_sources"]}
+                    fresh_msm = all(src_now[f] == h for f, h in pmc["_sources"].items() if f.startswith(("msm", "curve29", "field29")))
+                    fresh_ntt = all(src_now[f] == h for f, h in pmc["_sources"].items() if f.startswith(("ntt", "field.")))
+                    if not fresh_msm:
+                        pmc_src += "; STALE for the MSM kernels (their sources changed since the passes): traffic withheld"
+                    if not fresh_ntt:
+                        pmc_src += "; STALE for the NTT kernels: traffic withheld"
+                except Exception:
+                    pmc = None
+        try:
+            if pmc and fresh_msm:
+                traffic = (pmc["FETCH_SIZE"][kname]["kb_per_launch"] + pmc["WRITE_SIZE"][kname]["kb_per_launch"]) * 1024.0
+                if "solo_z" in pmc:   # the same two counters over the solo Z-shaped launch (tools/solo_z_msm.py under --pmc)
+                    traffic_solo = (pmc["solo_z"]["FETCH_SIZE_kb"] + pmc["solo_z"]["WRITE_SIZE_kb"]) * 1024.0
+            if pmc and fresh_ntt:
+                # per pass launch (the fused contiguous pair -- two launches per computeH -- and the fused strided triple -- one -- counted
+                # with their own figures); one transform = a sixth of computeH's traffic
+                per = lambda kn: (2.0 * pmc["FETCH_SIZE"][kn]["kb_per_launch"] + pmc["WRITE_SIZE"][kn]["kb_per_launch"]) * 1024.0
+                n_pair = 2 if "k_ntt_contig_pair" in pmc["FETCH_SIZE"] else 0
+                n_triple = 1 if "k_ntt_strided_triple" in pmc["FETCH_SIZE"] else 0
+                n_last = 1 if "k_ntt_contig_last_sub" in pmc["FETCH_SIZE"] else 0
+                traffic_ntt = (per("k_ntt_pass_wave") * (ntt_solo["pass_launches"] - n_pair - n_triple - n_last) + (per("k_ntt_contig_pair") * n_pair if n_pair else 0.0) +
+                               (per("k_ntt_strided_triple") if n_triple else 0.0) + (per("k_ntt_contig_last_sub") if n_last else 0.0)) / 6.0
+        except Exception:
+            traffic = traffic_ntt = None
+        pmc_src_solo = pmc_src
+        if live_solo and "error" not in live_solo and kname in live_solo["FETCH_SIZE"]:
+            traffic_solo = (live_solo["FETCH_SIZE"][kname]["per_launch"] + live_solo["WRITE_SIZE"][kname]["per_launch"]) * 1024.0
+            pmc_src_solo = (f"THIS RUN: child runs `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) over tools/solo_z_msm.py {log_n} 2 "
+                            f"({live_solo['FETCH_SIZE'][kname]['launches']} launches each, {live_solo['seconds']:.0f} s)")
         # the level-1 kernel's own instruction-issue floor, from the committed ISA census of its code object (tools/isa_census.py ->
         # profiles/r05_isa_census_accum_affine29.json: instructions per loop iteration by class x the measured cycles per wave64
         # instruction of profiles/r02_probe_instr_rate.txt)
@@ -886,27 +957,42 @@ def main():
             roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm",
                         "basis": f"solo launch: the proof's largest level-1 launch (Z MSM: {zsolo['pairs']} uniform scalars, {zsolo['windows']} windows of {zsolo['window_bits']} bits, fixed-base tables) alone on the GPU",
                         "achieved": zsolo["accum_GBps_algorithmic"], "peak": 8000.0, "unit": "GB/s", "frac": zsolo["accum_GBps_algorithmic"] / 8000.0,
-                        "traffic": traffic_solo, "traffic_source": pmc_src, "launch_ms": zsolo["accum_launch_ms"], "algorithmic_bytes_per_launch": 96.0 * zsolo["pairs"],
-                        "in_job": dict(in_job, traffic=traffic)}
+                        "traffic": traffic_solo, "traffic_source": pmc_src_solo, "launch_ms": zsolo["accum_launch_ms"], "algorithmic_bytes_per_launch": 96.0 * zsolo["pairs"],
+                        "in_job": dict(in_job, traffic=traffic, traffic_source=pmc_src)}
         else:
             roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm", "basis": "in-job average launch (the solo Z-shaped launch did not run)",
                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": pmc_src,
                         "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes, "in_job": in_job}
-        # vector-ALU utilisation of the job: wave-instructions per proof (committed PMC pass SQ_INSTS_VALU over four proofs alone on one
-        # context, tools/prof_proof.py; setup kernels excluded) / step time / the 6.4e11 wave-instructions per second the chip sustains on
-        # this instruction mix (1024 SIMDs x 2.4 GHz / 3.84 cycles).  Reported only while the kernel sources the pass ran on are unchanged.
+        # vector-ALU utilisation of the job: wave-instructions per proof (SQ_INSTS_VALU over four proofs alone on one context,
+        # tools/prof_proof.py; setup kernels excluded) / step time / the 6.4e11 wave-instructions per second the chip sustains on this
+        # instruction mix (1024 SIMDs x 2.4 GHz / 3.84 cycles).  From this run's own pass when it ran; else from the committed pass, and
+        # then only while the kernel sources are unchanged.
         valu_util = None
         try:
-            import csv
-            vfile = os.path.join(ROOT, "profiles", "r05_pmc_valu_proofs.csv")
             setup = ("k_gen_", "k_xyzz_dbl_c", "k_xyzz_batch_to_affine", "k_xyzz_from_affine", "k_g1_to_rprime", "k_g2_to_rprime", "k_expand_points", "k_field_op", "k_pow_table",
                      "k_tw_layout", "k_sc_layout", "k_msm2_precompute", "__amd_rocclr_fillBuffer")
-            tot = sum(float(r["Sum"]) for r in csv.DictReader(open(vfile)) if r["Counter"] == "SQ_INSTS_VALU" and not r["Kernel"].split("(")[0].replace("void ", "").startswith(setup))
-            per_proof = tot / 4.0
-            if log_n == 23 and args.dist == "whir" and traffic is not None and per_proof > 0:
-                valu_util = {"wave_instructions_per_proof": per_proof, "sustained_wave_instructions_per_s": 6.4e11, "source": "profiles/r05_pmc_valu_proofs.csv (committed pass, not this run)",
+            if live_proofs and "error" not in live_proofs:
+                per_kernel = {k: v["total"] / 4.0 for k, v in live_proofs["SQ_INSTS_VALU"].items() if not k.startswith(setup)}
+                valu_src = pmc_src
+            else:
+                import csv
+                per_kernel = {}
+                for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_pmc_valu_proofs.csv"))):
+                    k = _kernel_short(r["Kernel"])
+                    if r["Counter"] == "SQ_INSTS_VALU" and not k.startswith(setup):
+                        per_kernel[k] = per_kernel.get(k, 0.0) + float(r["Sum"]) / 4.0
+                valu_src = "profiles/r05_pmc_valu_proofs.csv (committed pass, not this run)"
+                if not (log_n == 23 and args.dist == "whir" and traffic is not None):
+                    per_kernel = {}
+            per_proof = sum(per_kernel.values())
+            if per_proof > 0:
+                share = lambda *names: sum(v for k, v in per_kernel.items() if k.startswith(names)) / per_proof
+                valu_util = {"wave_instructions_per_proof": per_proof, "sustained_wave_instructions_per_s": 6.4e11, "source": valu_src,
                              "on_the_callers_path": per_proof / (dt / args.steps) / 6.4e11,
                              "hbm_resident_inputs": None if dev_ms is None else per_proof / (dev_ms * 1e-3) / 6.4e11,
+                             "shares": {"g1_level1": share("k_msm_accum_affine29"), "g2_level1": share("k_msm_accum_affine_g2_29"), "ntt": share("k_ntt_"),
+                                        "upper_levels_and_finisher": share("k_msm_accum_xyzz", "k_msm_finish"), "sorts": share("k_msm2_", "k_scan_"),
+                                        "reduces": share("k_msm_bucket_reduce", "k_msm_sum_tree")},
                              "note": "an instruction-count figure: multiply-accumulate-heavy kernels (level 1: 4.43 cycles per instruction by the ISA census) weigh more than the 3.84-cycle average"}
         except Exception:
             valu_util = None

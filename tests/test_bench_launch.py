@@ -29,3 +29,29 @@ def test_launcher_given_ranks_are_used_as_they_are():
     assert json.loads(out.stdout.strip().splitlines()[-1])["world"] == 1
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_tests", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+def test_kernel_names_of_the_counter_passes_are_folded_like_the_committed_summaries():
+    b = _bench_module()
+    assert b._kernel_short("void k_msm_accum_affine29<4, 3>(Affine<Fe<FpParams> > const*, unsigned int const*)") == "k_msm_accum_affine29"
+    assert b._kernel_short("void k_msm_accum_affine_g2_29<1>(Affine<Fp2> const*)") == "k_msm_accum_affine_g2_29"
+    assert b._kernel_short("void k_msm2_partition<20u>(Msm2Shape, Fe<FrParams> const*)") == "k_msm2_partition<20u>"
+    assert b._kernel_short("k_ntt_pass_wave(Fe<FrParams>*, Fe<FrParams> const*, NttPass, NttTables)") == "k_ntt_pass_wave"
+
+
+@pytest.mark.gpu
+def test_live_counter_pass_sees_the_level1_launch():
+    """bench.py's `roofline.traffic` is measured by the run itself: a child `rocprofv3 --pmc FETCH_SIZE` over tools/solo_z_msm.py (small here)"""
+    b = _bench_module()
+    r = b.live_pmc("solo_z_msm.py", [16, 1], ("FETCH_SIZE",), timeout_s=300)
+    assert "error" not in r, r
+    k = r["FETCH_SIZE"]["k_msm_accum_affine29"]
+    # the fixed-base launch gathers one 64-B point per addition: at least the scalars' 32 B per pair reach the kernel (KB units)
+    assert k["launches"] == 2 and k["per_launch"] * 1024.0 > 32.0 * ((1 << 16) - 1)

@@ -8,7 +8,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
-Q="--no-cpu-baseline --sharded-msm-log-n 0 --sharded-prove-log-n 0"
+Q="--no-cpu-baseline --no-live-pmc --sharded-msm-log-n 0 --sharded-prove-log-n 0"
 case "$1" in
 1)  timeout -k 10 600 python3 bench.py > $O/r5_bench_final.log 2>&1; tail -c 300 $O/r5_bench_final.log ;;
 1b) rm -rf $O/r5_prof_def
