@@ -3,9 +3,32 @@
 #include "ctx.h"
 #include "curve.cuh"
 #include <cstring>
+#include <dlfcn.h>
 
 thread_local std::string *mi_err_sink = nullptr;
 std::atomic<int> mi_fault_countdown{0};
+
+// ---------------------------------------------------------------- roctx ranges ("roctx ranges around NTT/MSM phases")
+std::atomic<int> mi_ranges_on{0};
+static int (*g_range_push)(const char *) = nullptr;
+static int (*g_range_pop)() = nullptr;
+void mi_range_push(const char *name) { if (g_range_push) (void)g_range_push(name); }
+void mi_range_pop() { if (g_range_pop) (void)g_range_pop(); }
+static bool ranges_load() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // rocprofv3's marker trace reads the SDK's roctx; roctracer's libroctx64 is the older name of the same two entry points
+        for (const char *lib : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            g_range_push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            g_range_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (g_range_push && g_range_pop) return;
+            g_range_push = nullptr; g_range_pop = nullptr;
+        }
+    });
+    return g_range_push && g_range_pop;
+}
 
 int32_t mi_copy_stream(mi_ctx *ctx, hipStream_t *out) {
     if (!ctx->copy_stream) MI_CHECK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -15,6 +38,11 @@ int32_t mi_copy_stream(mi_ctx *ctx, hipStream_t *out) {
 
 extern "C" {
 
+int32_t mi_debug_set_trace_ranges(int32_t on) {
+    if (on && !ranges_load()) return MI_ENODEV;   // no roctx library on this machine
+    mi_ranges_on.store(on ? 1 : 0);
+    return MI_OK;
+}
 int32_t mi_debug_inject_hip_failure(int32_t nth) { mi_fault_countdown.store(nth > 0 ? nth : 0); return MI_OK; }
 int32_t mi_init(int device_id, mi_ctx **out) { return mi_init_prio(device_id, MI_PRIO_SOLO, out); }
 int32_t mi_init_prio(int device_id, int prio_scheme, mi_ctx **out) {

@@ -89,6 +89,18 @@ static inline void mi_set_err(struct mi_ctx *ctx, const std::string &msg);
 // A helper thread that works on a context beside the thread that owns the call (the prover pool's ProveKnowledge enqueue, pool.hip)
 // records its failures in a string of its own: set for the duration of its work, it replaces ctx->err for THIS thread, so the two
 // threads never write one std::string and each failure reaches the job with the message of the thread that met it.
+// roctx ranges around the host-side phases of a call (mi_debug_set_trace_ranges; off by default: one relaxed load per site).  rocprofv3
+// --marker-trace shows them beside the kernel trace.  api.hip loads the roctx library on first use; nothing links against it.
+extern std::atomic<int> mi_ranges_on;
+void mi_range_push(const char *name);
+void mi_range_pop();
+struct MiRange {
+    bool on;
+    explicit MiRange(const char *name) : on(mi_ranges_on.load(std::memory_order_relaxed) != 0) { if (on) mi_range_push(name); }
+    ~MiRange() { if (on) mi_range_pop(); }
+    MiRange(const MiRange &) = delete;
+    MiRange &operator=(const MiRange &) = delete;
+};
 extern thread_local std::string *mi_err_sink;
 static inline void mi_set_err(struct mi_ctx *ctx, const std::string &msg) {
     if (mi_err_sink) { *mi_err_sink = msg; return; }

@@ -396,6 +396,7 @@ static int32_t run_xfers_shm(mi_group *g, const std::vector<Xfer> &list, const s
 // Runs the batch on the exchange streams xs[local rank].  Afterwards xs[i] is ordered after every transfer rank i sends or receives.
 // A failure inside a batch leaves the transport in an unknown state (some ranks may be waiting in it): the group is marked broken.
 static int32_t run_xfers_impl(mi_group *g, const std::vector<Xfer> &xs_list, const std::vector<hipStream_t> &xs) {
+    const MiRange range_fn("mi.group.exchange");
     if (g->transport == 3) return run_xfers_shm(g, xs_list, xs);
     if (g->transport == 1) {
         // every ncclGroupStart is closed by its ncclGroupEnd whatever happens in between (an open group would swallow this thread's next
@@ -468,6 +469,7 @@ static int32_t run_xfers(mi_group *g, const std::vector<Xfer> &xs_list, const st
 // local: n_local x bytes (this process's ranks, in order); all: world x bytes in rank order.  Single process: a copy.  One rank
 // per process: ncclAllGather(ncclUint8) through a staging area (transport 1) or the shared segment (transport 3).
 static int32_t group_allgather(mi_group *g, const void *local, size_t bytes, void *all) {
+    const MiRange range_fn("mi.group.allgather");
     // (a per-rank RCCL group of ONE rank goes through its communicator all the same: that is how a 1-GPU box runs the polled path)
     if (g->n_local() == g->world && !g->nonblocking) { std::memcpy(all, local, bytes * (size_t)g->world); return MI_OK; }
     if (g->n_local() != 1) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");
@@ -968,6 +970,7 @@ static bool sharded_h_possible(const mi_group *g, u32 log_n) {
     return log_n >= 2 * lw && log_n <= 28;
 }
 static int32_t compute_h_sharded(mi_group *g, u32 log_n, bool derive_c) {
+    const MiRange range_fn("mi.group.computeH.enqueue");
     const int nl = g->n_local(), W = g->world;
     u32 log_w = 0;
     while ((1 << log_w) < W) log_w++;
@@ -1271,6 +1274,7 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
 static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, const mi_fr *W_host, const mi_fr *const *W_dev, size_t n_wires,
                                   const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m,
                                   uint32_t mode, mi_proof_out *out, mi_stats *stats, const mi_fr *const *const *abc_sl = nullptr) {
+    const MiRange range_fn("mi.group.prove");
     if (!g || !spk || !out) return MI_EINVAL;
     const int nl = g->n_local(), W = g->world;
     if ((nl != W && nl != 1) || (int)spk->part.size() != nl) G_FAIL(g, MI_EINVAL, "group: a process holds either all ranks or exactly one");

@@ -829,6 +829,8 @@ int32_t mi_msm_precompute(mi_ctx *ctx, int curve, const void *base_dev, void *pr
 int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const void *pts_dev, const void *scalars_dev, size_t n,
                        uint32_t flags, hipEvent_t wait_ev, bool timed, uint32_t precomp_c, size_t stat_pairs, uint32_t generic_c) {
     if (slot < 0 || slot >= MI_MSM_SLOTS || sort_slot >= MI_MSM_SLOTS) return MI_EINVAL;
+    static const char *const range_names[MI_MSM_SLOTS] = {"mi.msm.A.enqueue", "mi.msm.B1.enqueue", "mi.msm.B2.enqueue", "mi.msm.K.enqueue", "mi.msm.Z.enqueue", "mi.msm.PoK.enqueue"};
+    const MiRange range(range_names[slot]);
     if (n > ((size_t)1 << 27)) MI_FAIL(ctx, MI_EINVAL, "msm: n > 2^27 pairs per device not supported (shard the points)");
     MsmSlot &sl = ctx->msm[slot];
     const std::function<hipEvent_t()> *gate_once = sl.accum_gate;   // valid for this call only, whatever path it takes
@@ -897,6 +899,8 @@ int32_t mi_msm_bucket_view(mi_ctx *ctx, int slot, int curve, MsmBucketView *v) {
 }
 int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host) {
     if (slot < 0 || slot >= MI_MSM_SLOTS) return MI_EINVAL;
+    static const char *const range_names[MI_MSM_SLOTS] = {"mi.msm.A.collect", "mi.msm.B1.collect", "mi.msm.B2.collect", "mi.msm.K.collect", "mi.msm.Z.collect", "mi.msm.PoK.collect"};
+    const MiRange range(range_names[slot]);
     return msm_finish(ctx, curve == 1 ? msm_g1_ops() : msm_g2_ops(), ctx->msm[slot], out_xyzz_host);
 }
 

@@ -599,6 +599,8 @@ static int32_t compute_h_plan(mi_ctx *ctx, uint32_t log_n, Fr *A, ComputeHPlan &
     return MI_OK;
 }
 int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *src, size_t n_constraints, mi_fr *h_out, const mi_fr *src2) {
+    static const char *const range_names[4] = {"mi.computeH.a.enqueue", "mi.computeH.b.enqueue", "mi.computeH.c.enqueue", "mi.computeH.last.enqueue"};
+    const MiRange range(range_names[part & 3]);
     const size_t n = (size_t)1 << log_n;
     // gnark's computeH (7 transforms): a, b, c <- FFTInverse; a, b, c <- FFT on the coset; a <- (a b - c) den; h <- FFTInverse on
     // the coset.  The last transform is linear and undoes the coset FFT of c exactly:

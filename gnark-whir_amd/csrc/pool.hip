@@ -103,6 +103,7 @@ static void worker_main(mi_prover *p, mi_ctx *ctx) {
             p->queue.pop_front();
             p->busy++;
         }
+        const MiRange range_job("mi.pool.job");
         int32_t rc = MI_ENOMEM, rc_pok = MI_OK;
         std::string prove_err;
         try {   // (nothing may leave a worker thread: an allocation failure in the bookkeeping below is this job's MI_ENOMEM, not std::terminate)
@@ -197,6 +198,7 @@ static void uploader_main(mi_prover *p) {
             j->set = si;
         }
         InputSet &set = p->sets[si];
+        const MiRange range_up("mi.pool.upload");
         const size_t wb = j->n_wires * sizeof(mi_fr), cb = j->n_constraints * sizeof(mi_fr), need = wb + 3 * cb + 128;
         hipError_t e = hipSuccess;
         const char *what = "";
@@ -401,6 +403,7 @@ int32_t mi_prover_submit_bsb22(mi_prover *p, mi_pk *pk, const mi_fr *W, size_t n
 // Pedersen Commit inside the solve (gnark's BSB22 hint override): synchronous, from any thread; one commitment at a time on a context of
 // its own whose streams rank with the pool's first context, so that a blocked solver waits for one small MSM, not for a proof
 int32_t mi_prover_commit(mi_prover *p, mi_pedersen_pk *key, const mi_fr *values, size_t n, mi_g1_affine *commitment) {
+    const MiRange range_fn("mi.pool.commit");
     if (!p || !key || !commitment || (!values && n)) return MI_EINVAL;
     std::lock_guard<std::mutex> lk(p->commit_m);
     (void)hipSetDevice(p->dev);

@@ -485,6 +485,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
                             size_t n_constraints, const mi_fr *r_m, const mi_fr *s_m, mi_proof_out *out, mi_stats *stats, const HostInputs *host,
                             const AbcGate *gate = nullptr) {
     if (!ctx || !pk || !r_m || !s_m || !out) return MI_EINVAL;
+    const MiRange range_all("mi.prove");
     // null W / a / b only where the matching count is 0 (the header's rule, as the pool's submit applies it); c == null: c = a o b on the device
     if ((!W && n_wires) || ((!a || !b) && n_constraints)) MI_FAIL(ctx, MI_EINVAL, "prove: null W, a or b with a non-zero count");
     if (host && ((!host->W && n_wires) || ((!host->a || !host->b) && n_constraints))) MI_FAIL(ctx, MI_EINVAL, "prove: null host W, a or b with a non-zero count");
@@ -578,6 +579,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         hipStream_t cps = nullptr;
         MI_TRY(mi_copy_stream(ctx, &cps));
         auto upload = [&](const mi_fr *dst, const mi_fr *src, size_t bytes) -> int32_t {
+            const MiRange range("mi.prove.upload");
             if (bytes) MI_CHECK_HIP(ctx, hipMemcpyAsync((void *)dst, src, bytes, hipMemcpyHostToDevice, cps));
             MI_CHECK_HIP(ctx, hipStreamSynchronize(cps));
             return MI_OK;
@@ -617,7 +619,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     }
     // step 6 while the GPU works: blinding multiples of delta on the host (O(1) points)
     ProofAssembler as;
-    as.start(pk, r_m, s_m);
+    { const MiRange range("mi.prove.blinding"); as.start(pk, r_m, s_m); }
     // step 7: collect the five MSMs
     G1X msm_a, msm_b1, msm_k, msm_z;
     G2X msm_b2;
@@ -630,7 +632,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     MI_TRY(mi_msm_finish(ctx, 4, 1, &msm_z));
     MI_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const auto t_gpu_done = std::chrono::steady_clock::now();
-    as.finish(msm_k, msm_b2, msm_z, out);
+    { const MiRange range("mi.prove.assemble"); as.finish(msm_k, msm_b2, msm_z, out); }
     const auto t_end = std::chrono::steady_clock::now();
     mi_stats &st = ctx->stats;
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {

@@ -589,6 +589,11 @@ int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value);
  * pointed at B1's, as rounds 4-5 did; 1, the default: never created; 2: A, B1 and K on one stream).  Same results; an experiment on which
  * chains end up on one hardware queue. */
 int32_t mi_debug_set_stream_plan(int32_t plan);
+/* Tracing: on != 0 wraps the host-side phases of every call -- uploads, computeH's enqueue, each MSM's enqueue and
+ * collection, the pool's stages, the device groups' exchanges -- in roctx ranges ("mi.prove", "mi.computeH.enqueue", "mi.msm.Z.enqueue", ...),
+ * which `rocprofv3 --marker-trace --kernel-trace` shows beside the kernels.  Process-wide; off by default (one relaxed load per site).
+ * MI_ENODEV when no roctx library can be loaded (librocprofiler-sdk-roctx / libroctx64, looked up at the first call; nothing links it). */
+int32_t mi_debug_set_trace_ranges(int32_t on);
 /* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
  * running; 0 disarms.  Used to prove that init / load / prove unwind without leaks or crashes. */
 int32_t mi_debug_inject_hip_failure(int32_t nth);

@@ -1,4 +1,4 @@
-"""Per-proof kernel profile at the benchmark shape: `rocprofv3 --kernel-trace -d DIR -o p -- python3 tools/prof_proof.py [log_n] [proofs]`
+"""Per-proof kernel profile at the benchmark shape: `rocprofv3 --kernel-trace -d DIR -o p -- python3 tools/prof_proof.py [log_n] [proofs] [ranges]`
 proves the bench.py workload (same seeds, committed wires removed from K, no Pedersen MSMs) `proofs` times on ONE context, one proof at a
 time, inputs in HBM; `python tools/prof_proof.py --summary DIR/p_results.db [proofs]` prints the per-kernel time PER PROOF (sum of launch
 durations / proofs; kernels on different streams overlap, so the column does not add up to the proof's latency)."""
@@ -35,6 +35,8 @@ def main():
     log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 23
     proofs = int(sys.argv[2]) if len(sys.argv) > 2 else 12
     N = 1 << log_n
+    if len(sys.argv) > 3 and sys.argv[3] == "ranges":   # roctx ranges around the host-side phases (rocprofv3 --marker-trace --kernel-trace)
+        assert B.load().mi_debug_set_trace_ranges(1) == 0
     ctx = B.Context(0)
     seed = 0x57484952 + 1
     nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
