@@ -85,6 +85,49 @@ def _kernel_short(name):
     return k.split("<")[0] if k.startswith(("k_msm_accum_affine29", "k_msm_accum_affine_g2_29")) else k
 
 
+class ClockSampler:
+    """Reads the GPU's shader clock and package power (rocm-smi, read-only; a child process every ~0.2 s from a thread of rank 0) while the
+    timed regions run: the roofline figures assume 2.4 GHz, the chip decides what it sustains under this instruction mix."""
+
+    def __init__(self, device):
+        import threading
+        self.device, self.samples, self._stop = device, [], threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _once(self):
+        import re
+        import subprocess
+        try:
+            out = subprocess.run(["rocm-smi", "-d", str(self.device), "--showclocks", "--showpower", "--csv"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=5).stdout
+            rows = [r for r in out.splitlines() if r.strip()]
+            d = dict(zip(rows[0].split(","), rows[1].split(",")))
+            sclk = int(re.sub(r"[^0-9]", "", d.get("sclk clock speed:", "")) or 0)
+            pw = float(d.get("Current Socket Graphics Package Power (W)", "0") or 0)
+            if sclk > 0:
+                self.samples.append((sclk, pw))
+        except Exception:
+            pass
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._once()
+            self._stop.wait(0.2)
+
+    def start(self):
+        self._th.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        self._th.join(timeout=10)
+        if not self.samples:
+            return None
+        sc = [x[0] for x in self.samples]; pw = [x[1] for x in self.samples]
+        return {"sclk_mhz_mean": sum(sc) / len(sc), "sclk_mhz_min": min(sc), "sclk_mhz_max": max(sc), "package_power_w_mean": sum(pw) / len(pw), "samples": len(sc),
+                "how": "rocm-smi --showclocks --showpower every ~0.2 s over the HBM-resident timed region (rank 0's GPU; the host is idle there)",
+                "note": "every roofline / issue-floor figure of this line assumes 2.4 GHz; the chip sustains what its power management allows for the instruction mix"}
+
+
 def live_pmc(script, script_args, counters, timeout_s=240):
     """Hardware counters MEASURED BY THIS RUN: one child `rocprofv3 --pmc <counter>` per counter (separate passes, as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes; the program itself right after `--`) over tools/<script>.  Returns
@@ -465,6 +508,7 @@ def main():
     ap.add_argument("--n-committed", type=int, default=-1,
                     help="private wires under the proof's ONE BSB22 commitment (lookup operands; default 2^18 = N / 32, a documented estimate like the infinity ratios; 0 = a circuit without lookups: 164-byte proofs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-samples", action="store_true", help="do not sample rocm-smi (shader clock, package power) during the timed regions")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure the roofline launch's HBM traffic in THIS run (then: the committed passes)")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the second timed region (inputs already in HBM, no commitment: the GPU-side rate)")
     ap.add_argument("--in-flight", type=int, default=0,
@@ -708,11 +752,14 @@ def main():
 
     # second timed region: the same key with W, a, b, c ALREADY in HBM and no commitment (mi_prover_submit_dev, 164-byte proof body): the
     # GPU-side rate no caller of the reference can reach (its solver is CPU code) -- reported next to `value`, never as `value`
-    dev_rate = dev_ms = None
+    dev_rate = dev_ms = clocks = None
     if not args.no_hbm_resident:
         sub = lambda: pool.submit(pkh, W.ptr, a.ptr, b.ptr, c.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)
         for t in [sub() for _ in range(args.warmup)]:
             pool.wait(t)
+        # (the clock samples are taken HERE, where the host is idle: a rocm-smi child every 0.2 s beside the caller threads and the upload
+        #  stage of the first region cost it 4 % -- 32.4 against 33.7 proofs/s on one box -- and the kernels are the same)
+        sampler = ClockSampler(local_rank).start() if rank == 0 and not args.no_clock_samples else None
         fence()
         t0d = time.perf_counter()
         dev_done = [pool.wait(t)[0]["raw"] for t in [sub() for _ in range(args.steps)]]
@@ -725,6 +772,7 @@ def main():
         for raw in dev_done:
             if B.proof_write(raw) != body_bytes:
                 raise SystemExit("bench.py: a device-input proof differs from the reference proof of the same inputs")
+        clocks = sampler.stop() if sampler is not None else None
         dev_rate, dev_ms = args.steps * world / dtd, dtd / args.steps * 1e3
 
     # `sensitivity`: the headline rests on ONE guessed input, the witness distribution ("a documented guess").  The same key, the
@@ -990,6 +1038,9 @@ def main():
                 valu_util = {"wave_instructions_per_proof": per_proof, "sustained_wave_instructions_per_s": 6.4e11, "source": valu_src,
                              "on_the_callers_path": per_proof / (dt / args.steps) / 6.4e11,
                              "hbm_resident_inputs": None if dev_ms is None else per_proof / (dev_ms * 1e-3) / 6.4e11,
+                             # the same two at the shader clock the chip sustained during the HBM-resident region (1024 SIMDs x sclk / 3.84 cycles)
+                             "at_measured_sclk": None if not clocks else {"sclk_mhz": clocks["sclk_mhz_mean"], "on_the_callers_path": per_proof / (dt / args.steps) / (1024 * clocks["sclk_mhz_mean"] * 1e6 / 3.84),
+                                                                          "hbm_resident_inputs": None if dev_ms is None else per_proof / (dev_ms * 1e-3) / (1024 * clocks["sclk_mhz_mean"] * 1e6 / 3.84)},
                              "shares": {"g1_level1": share("k_msm_accum_affine29"), "g2_level1": share("k_msm_accum_affine_g2_29"), "ntt": share("k_ntt_"),
                                         "upper_levels_and_finisher": share("k_msm_accum_xyzz", "k_msm_finish"), "sorts": share("k_msm2_", "k_scan_"),
                                         "reduces": share("k_msm_bucket_reduce", "k_msm_sum_tree")},
@@ -1032,6 +1083,7 @@ def main():
             # inside a proof the five MSMs overlap on five streams, so per-MSM spans there are not rates
             "g1_msm_pts_per_s": solo["msm_pts_per_s"], "g1_pairs_per_proof": g1_pairs_per_proof,
             "phase_ms": {k: last[k] for k in ("compute_h_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "msm_k_ms", "msm_z_ms", "assemble_ms", "total_ms")},
+            "clocks_under_load": clocks,
             "roofline": roofline,
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
             # time = computeH alone on the GPU / its 6 transforms (gnark's 7th, the coset FFT of c, is never needed: DESIGN.md 4)
