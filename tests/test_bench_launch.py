@@ -55,3 +55,29 @@ def test_live_counter_pass_sees_the_level1_launch():
     k = r["FETCH_SIZE"]["k_msm_accum_affine29"]
     # the fixed-base launch gathers one 64-B point per addition: at least the scalars' 32 B per pair reach the kernel (KB units)
     assert k["launches"] == 2 and k["per_launch"] * 1024.0 > 32.0 * ((1 << 16) - 1)
+
+
+def test_clock_sampler_reads_rocm_smi_csv(monkeypatch):
+    """bench.py's ClockSampler: one sample per rocm-smi answer (csv header + one row), nothing on garbage or a missing tool"""
+    b = _bench_module()
+    import subprocess as sp
+    good = ("device,fclk clock speed:,fclk clock level:,mclk clock speed:,mclk clock level:,sclk clock speed:,sclk clock level:,socclk clock speed:,socclk clock level:,"
+            "Current Socket Graphics Package Power (W)\ncard0,(1250Mhz),0,(2000Mhz),0,(2177Mhz),1,(1200Mhz),0,1284.0\n")
+    answers = [good, "", "no such tool", good.replace("2177", "2201").replace("1284.0", "1300.0")]
+
+    class R:
+        def __init__(self, out): self.stdout = out
+
+    def fake_run(cmd, **kw):
+        assert cmd[:3] == ["rocm-smi", "-d", "0"]
+        if not answers:
+            raise FileNotFoundError("rocm-smi")
+        return R(answers.pop(0))
+    monkeypatch.setattr(sp, "run", fake_run)
+    s = b.ClockSampler(0)
+    for _ in range(5):
+        s._once()
+    assert s.samples == [(2177, 1284.0), (2201, 1300.0)]
+    s._stop.set(); s._th.start()
+    r = s.stop()
+    assert r["samples"] == 2 and r["sclk_mhz_min"] == 2177 and r["sclk_mhz_max"] == 2201 and abs(r["package_power_w_mean"] - 1292.0) < 1e-9
