@@ -39,7 +39,8 @@ for src, dst in ((G + "r5_bench_final.log", "profiles/r05_bench_line_final.json"
     l = line(src); open(dst, "w").write(l); d = json.loads(l)
     print(dst, {k: round(d[k], 3) if isinstance(d.get(k), float) else d.get(k) for k in ("value", "ms_per_step", "value_hbm_resident_inputs", "single_proof_latency_ms", "single_proof_latency_host_inputs_ms", "hbm_in_use_gb")},
           "launch_ms", round(d["roofline"]["launch_ms"], 2), "frac", round(d["roofline"]["frac"], 4), "ntt frac", round(d["roofline_ntt"]["frac"], 4))
-for d_, out in (("r5_prof_def", "profiles/r05_kernel_stats_default.csv"), ("r5_prof_if1", "profiles/r05_kernel_stats_inflight1.csv")):
+for d_, out in (("r5_prof_def", "profiles/r05_kernel_stats_default.csv"), ("r5_prof_if1", "profiles/r05_kernel_stats_inflight1.csv"),
+                ("r5_prof_solo_z", "profiles/r05_kernel_stats_solo_z.csv")):   # (solo_z: the launch the roofline line is quoted on, alone: its average must agree with roofline.launch_ms)
     if os.path.isdir(G + d_):
         subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "stats", db(d_), out], stdout=subprocess.DEVNULL)
 if os.path.isdir(G + "r5_pmc_fetch") and os.path.isdir(G + "r5_pmc_write"):

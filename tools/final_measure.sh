@@ -27,5 +27,7 @@ case "$1" in
     timeout -k 10 200 python3 tools/solo_z_msm.py 23 3 > $O/r5_solo_z.log 2>&1
     timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/r5_pmc_solo_fetch -o f -- python3 tools/solo_z_msm.py 23 2 > $O/r5_pmc_solo_fetch.log 2>&1
     timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/r5_pmc_solo_write -o w -- python3 tools/solo_z_msm.py 23 2 > $O/r5_pmc_solo_write.log 2>&1
+    rm -rf $O/r5_prof_solo_z
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/r5_prof_solo_z -o s -- python3 tools/solo_z_msm.py 23 5 > $O/r5_prof_solo_z.log 2>&1
     tail -2 $O/r5_solo_z.log ;;
 esac
