@@ -14,6 +14,7 @@ struct DevBuf {             // growable device scratch owned by the ctx (no hipM
 };
 
 #define MI_MSM_SLOTS 6
+#define MI_ZHOOK_SLOT 4    // the slot whose sort may take its count from computeH's last launch (mi_ctx::zhook)
 struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, workspaces, pinned result
     hipStream_t stream = nullptr;
     hipEvent_t ev[7]{};     // 0: sort done, 1/2: around the level-1 accumulate launch, 3/4: whole job, 5: bucket sums ready (deferred reduce),
@@ -55,6 +56,13 @@ struct mi_ctx {
     int cu_count = 256;
     int prio_scheme = 0;      // MI_PRIO_*: how the context's streams rank (api.hip, msm.hip)
     uint32_t fixed_knob[3] = {0, 0, 0};  // prove's fixed-base tables for A+K / B / Z: 0 = automatic, 1 = never, 17..22 = forced (prove.hip)
+    // The Z MSM's digit count riding in computeH's LAST launch ("the count pass of Z could ride in computeH's last store"):
+    // prove.hip arms it right before that launch (mi_msm_z_count_arm: the sort's shape and its count matrix C1), ntt.hip's fused last
+    // kernel counts every h coefficient it stores -- its contiguous tile IS a slice (or two) of the sort -- and sets `done`; the Z sort
+    // (msm2_sort_enqueue) then skips its own count pass: h is read once less.  Disarmed again as soon as the launch is enqueued.
+    // Behind the knob "z_count_fused" (off by default: measured neutral).
+    // (only slot MI_ZHOOK_SLOT -- prove's Z MSM -- ever looks at it, and the thread that arms it is the one that enqueues that slot)
+    struct ZCountHook { bool armed = false, done = false; int slot = -1; uint32_t n = 0, c = 0; alignas(8) unsigned char shape[64]; uint32_t *C1 = nullptr; } zhook;
     uint32_t hold_accum = 0;             // prove: 1 = the wire MSMs' bucket accumulations wait for computeH (mi_debug_set_prove_schedule; measured: no gain)
 };
 
@@ -163,6 +171,9 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
 // pre[w][i] = 2^(c*w) * base[i] for w < ceil(256/c) (affine), on ctx->stream.  pre must hold ceil(256/c) * n points.
 int32_t mi_msm_precompute(mi_ctx *ctx, int curve, const void *base_dev, void *pre_dev, size_t n, uint32_t c);
 int32_t mi_msm_finish(mi_ctx *ctx, int slot, int curve, void *out_xyzz_host);
+// arms ctx->zhook for the fixed-base MSM that `slot` is about to run over n scalars with c-bit windows (no-op when the knob is off or the
+// shape does not fit: the sort then counts by itself, as always)
+int32_t mi_msm_z_count_arm(mi_ctx *ctx, int slot, size_t n, uint32_t c);
 // Internal flag of mi_msm_enqueue (next to MI_MSM_SCALARS_CANONICAL): stop at the bucket sums.  mi_msm_bucket_view then
 // exposes them, mi_msm_reduce_enqueue runs the rest (bucket reduce, window sums, copy to the host) and mi_msm_finish collects.
 #define MI_MSM_DEFER_REDUCE 0x100u

@@ -12,6 +12,7 @@
 // per butterfly) for the stages -- see DESIGN.md for the measured split.
 #include "ctx.h"
 #include "ntt_wave.cuh"
+#include "msm2_core.cuh"   // the Z MSM's digit count rides in computeH's last launch (mi_ctx::zhook)
 #include <cstring>
 #include <cstdlib>
 
@@ -56,6 +57,7 @@ __global__ void k_ntt_contig_pair(Fr *data, NttPass pi, NttTables ti, NttPass pf
 __global__ void k_ntt_strided_triple(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl);
 __global__ void k_ntt_strided_triple8(Fr *a, const Fr *b, NttPass pc, NttTables tc, NttPass pl, NttTables tl);
 __global__ void k_ntt_contig_last_sub(Fr *A, const Fr *Cin, NttPass pa, NttTables ta, NttPass pc, NttTables tc);
+template <int CC> __global__ void k_ntt_contig_last_sub_count(Fr *A, const Fr *Cin, NttPass pa, NttTables ta, NttPass pc, NttTables tc, Msm2Shape zs, u32 *C1);
 void mi_ntt_state_init(mi_ctx *ctx) {
     static_assert(sizeof(NttState) <= sizeof(ctx->ntt_state), "NttState lives in ctx->ntt_state");
     new (ctx->ntt_state) NttState();
@@ -65,6 +67,12 @@ void mi_ntt_state_init(mi_ctx *ctx) {
     (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_strided_triple8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub_count<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub_count<18>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub_count<19>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub_count<20>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub_count<21>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_ntt_contig_last_sub_count<22>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 bool mi_ntt_set_knob(mi_ctx *ctx, const char *name, int64_t value) {
     if (!std::strcmp(name, "ntt_lds_floor_kb") && value >= 0 && value <= 160) { state_of(ctx)->lds_floor = (u32)value * 1024u; return true; }
@@ -327,10 +335,18 @@ __device__ __forceinline__ void ntt_wave_pass_to_lds(const NttPass &p, const Ntt
     }
     __syncthreads();
 }
-__global__ void __launch_bounds__(256) k_ntt_contig_last_sub(Fr *A, const Fr *Cin, NttPass pa, NttTables ta, NttPass pc, NttTables tc) {
+// CC >= 17: the same launch also COUNTS the digits of every h coefficient it stores, for the fixed-base sort of the Z MSM that follows
+// (msm2_core.cuh: a contiguous tile of E elements is E / MSM2_SLICE whole slices of that sort; counters in LDS behind the tile's two planes,
+// written to C1[group][slice] exactly as k_msm2_count would have).  CC = -1: no count (the kernel every other caller gets).
+template <int CC>
+__device__ __forceinline__ void ntt_contig_last_sub_body(Fr *A, const Fr *Cin, const NttPass &pa, const NttTables &ta, const NttPass &pc, const NttTables &tc,
+                                                         const Msm2Shape &zs, u32 *C1) {
     extern __shared__ U4 lds[];
     const u64 tile = blockIdx.x;
     const u32 E = 1u << (pa.log_r + pa.log_c), PL = ntt_plane_slots(pa);
+    u32 *cnt = reinterpret_cast<u32 *>(lds + 2 * PL);
+    const u32 nsl = E / MSM2_SLICE;
+    if (CC >= 0) for (u32 k = threadIdx.x; k < nsl * zs.ngroups; k += blockDim.x) cnt[k] = 0;   // (barriers follow before the first count)
     Fr keep[4];
     ntt_wave_pass_to_lds(pc, tc, Cin, tile, lds);
 #pragma unroll
@@ -352,8 +368,29 @@ __global__ void __launch_bounds__(256) k_ntt_contig_last_sub(Fr *A, const Fr *Ci
         const u64 g = ntt_global_index(pa, tile, rho, col);
         Fr v = lds_get(lds, PL, ntt_lds_slot(pa, rho, col)), f;
         if (ntt_edge_factor(pa, ta, rho, g, 1, f)) v = fe_mul_lazy(v, f);
-        A[g] = fe_canon(fe_sub_plus2p(fe_condsub_2p(v), fe_condsub_2p(keep[k])));
+        const Fr hv = fe_canon(fe_sub_plus2p(fe_condsub_2p(v), fe_condsub_2p(keep[k])));
+        A[g] = hv;
+        if (CC >= 0 && g < zs.n) {
+            Msm2Digits dg;
+            dg.start(hv, true);
+            msm2_count_one<(CC >= 0 ? (u32)CC : 0u)>(zs, dg, cnt + (e / MSM2_SLICE) * zs.ngroups);
+        }
     }
+    if (CC >= 0) {
+        __syncthreads();
+        const u32 s0 = (u32)tile * nsl;
+        for (u32 k = threadIdx.x; k < nsl * zs.ngroups; k += blockDim.x) {
+            const u32 j = k / zs.ngroups, gq = k % zs.ngroups;
+            if (s0 + j < zs.nslices) C1[(size_t)gq * zs.nslices + s0 + j] = cnt[k];
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_ntt_contig_last_sub(Fr *A, const Fr *Cin, NttPass pa, NttTables ta, NttPass pc, NttTables tc) {
+    ntt_contig_last_sub_body<-1>(A, Cin, pa, ta, pc, tc, Msm2Shape{}, nullptr);
+}
+template <int CC>
+__global__ void __launch_bounds__(256) k_ntt_contig_last_sub_count(Fr *A, const Fr *Cin, NttPass pa, NttTables ta, NttPass pc, NttTables tc, Msm2Shape zs, u32 *C1) {
+    ntt_contig_last_sub_body<CC>(A, Cin, pa, ta, pc, tc, zs, C1);
 }
 
 // direct factor tables (NttPass::tw_direct / sc_direct), one thread per entry, square-and-multiply
@@ -648,7 +685,27 @@ int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *sr
         MI_TRY(ntt_run(ctx, A, A, (u32)n, log_n, MI_NTT_INVERSE | MI_NTT_COSET, 3, nullptr, nullptr, 2 | 4, &pa, &ta));
         if (pa.log_r != pcl.log_r || pa.log_c != pcl.log_c || pa.log_s || pcl.log_s || pa.dit || pcl.dit || pa.lds_pad != pcl.lds_pad)
             MI_FAIL(ctx, MI_EINVAL, "internal: the two last passes of computeH do not match");
-        hipLaunchKernelGGL(k_ntt_contig_last_sub, dim3(1u << (log_n - pa.log_r - pa.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pa), ctx->stream, A, (const Fr *)C, pa, ta, pcl, tcl);
+        // the Z MSM's digit count rides along when prove.hip armed the hook and this launch's tiles are whole slices of that sort
+        const u32 E = 1u << (pa.log_r + pa.log_c);
+        Msm2Shape zs{};
+        bool count = ctx->zhook.armed && ctx->zhook.C1;
+        if (count) {
+            std::memcpy(&zs, ctx->zhook.shape, sizeof(zs));
+            count = E % MSM2_SLICE == 0 && E / MSM2_SLICE <= 4 && zs.n <= n && (u64)zs.nslices * MSM2_SLICE == n && zs.c >= 17 && zs.c <= 22 && !zs.wkeys &&
+                    (size_t)32 * ntt_plane_slots(pa) + (size_t)(E / MSM2_SLICE) * zs.ngroups * 4 <= 160 * 1024;
+        }
+        ctx->zhook.armed = false;
+        if (count) {
+            const size_t lds_bytes = (size_t)32 * ntt_plane_slots(pa) + (size_t)(E / MSM2_SLICE) * zs.ngroups * 4;
+#define MI_LAST_COUNT(CW) do { \
+            hipLaunchKernelGGL(k_ntt_contig_last_sub_count<CW>, dim3(1u << (log_n - pa.log_r - pa.log_c)), dim3(256), lds_bytes, ctx->stream, A, (const Fr *)C, pa, ta, pcl, tcl, zs, ctx->zhook.C1); } while (0)
+            switch (zs.c) { case 17: MI_LAST_COUNT(17); break; case 18: MI_LAST_COUNT(18); break; case 19: MI_LAST_COUNT(19); break; case 20: MI_LAST_COUNT(20); break;
+                            case 21: MI_LAST_COUNT(21); break; default: MI_LAST_COUNT(22); break; }
+#undef MI_LAST_COUNT
+            ctx->zhook.done = true;
+        } else {
+            hipLaunchKernelGGL(k_ntt_contig_last_sub, dim3(1u << (log_n - pa.log_r - pa.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pa), ctx->stream, A, (const Fr *)C, pa, ta, pcl, tcl);
+        }
         MI_CHECK_HIP(ctx, hipGetLastError());
         ctx->stats.ntt_launches++;
         return MI_OK;

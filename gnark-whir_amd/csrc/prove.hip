@@ -508,8 +508,19 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
     bool h_promised = false;
     const std::shared_future<hipEvent_t> h_fut = h_recorded.get_future().share();
     const std::function<hipEvent_t()> h_gate = [h_fut] { return h_fut.get(); };
+    // the Z MSM's digit count rides in computeH's last launch (mi_ctx::zhook): armed for exactly that launch
+    auto arm_z_count = [&]() -> int32_t { return pk->pre_z ? mi_msm_z_count_arm(ctx, MI_ZHOOK_SLOT, pk->n_z_msm, pk->c_z) : MI_OK; };
+    auto last_part_of_h = [&]() -> int32_t {
+        MI_TRY(arm_z_count());
+        const int32_t rc_h = mi_compute_h_part(ctx, pk->log_n, 3, nullptr, n_constraints, (mi_fr *)h);
+        ctx->zhook.armed = false;
+        return rc_h;
+    };
     auto enqueue_h_and_z = [&]() -> int32_t {
-        MI_TRY(mi_compute_h_dev_impl(ctx, pk->log_n, a, b, derive_c ? nullptr : c, n_constraints, (mi_fr *)h));
+        MI_TRY(arm_z_count());
+        const int32_t rc_h = mi_compute_h_dev_impl(ctx, pk->log_n, a, b, derive_c ? nullptr : c, n_constraints, (mi_fr *)h);
+        ctx->zhook.armed = false;
+        MI_TRY(rc_h);
         MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
         h_recorded.set_value(ev[3]); h_promised = true;
         return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);
@@ -555,7 +566,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
             MI_TRY(mi_compute_h_part(ctx, pk->log_n, 1, b, n_constraints, (mi_fr *)h));
             if (derive_c) MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, a, n_constraints, (mi_fr *)h, b));
             else { MI_TRY(need(3)); MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, c, n_constraints, (mi_fr *)h)); }
-            MI_TRY(mi_compute_h_part(ctx, pk->log_n, 3, nullptr, n_constraints, (mi_fr *)h));
+            MI_TRY(last_part_of_h());
             MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
             h_recorded.set_value(ev[3]); h_promised = true;
             return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);
@@ -596,7 +607,7 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         ctx->stats.h2d_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_up).count();
         if (derive_c) MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, a, n_constraints, (mi_fr *)h, b));
         else MI_TRY(mi_compute_h_part(ctx, pk->log_n, 2, c, n_constraints, (mi_fr *)h));
-        MI_TRY(mi_compute_h_part(ctx, pk->log_n, 3, nullptr, n_constraints, (mi_fr *)h));
+        MI_TRY(last_part_of_h());
         MI_CHECK_HIP(ctx, hipEventRecord(ev[3], ctx->stream));
         h_recorded.set_value(ev[3]); h_promised = true;
         return mi_prove_enqueue_z_msm(ctx, pk, (const mi_fr *)h, ev[3]);

@@ -21,7 +21,7 @@ def ctx():
 
 def _reset(ctx):
     for k, v in (("l1_wg", 4), ("g2_wg", 1), ("l1_waves", 3), ("z_waves", 0), ("finisher", 1), ("finisher_max", 0), ("plain_scatter", 0), ("count_per", 0),
-                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2)):
+                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2), ("z_count_fused", 0)):
         ctx.set_knob(k, v)
     assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
 
@@ -119,12 +119,39 @@ def test_prove_with_round5_knobs_gives_the_oracle_bytes(ctx):
             assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0
             pkh = ctx.pk_load(pk)
             for cfg in ({}, {"l1_wg": 4}, {"l1_wg": 4, "l1_waves": 2, "g2_wg": 2}, {"finisher": 0}, {"finisher_max": 20, "l1_wg": 2, "z_waves": 2},
-                        {"plain_scatter": 1, "count_per": 8}, {"l1_wg": 1}, {"finisher_min_level": 0, "finisher_max": 1 << 20}):
+                        {"plain_scatter": 1, "count_per": 8}, {"l1_wg": 1}, {"finisher_min_level": 0, "finisher_max": 1 << 20}, {"z_count_fused": 1}):
                 _reset(ctx)
                 for k, v in cfg.items():
                     ctx.set_knob(k, v)
                 got, _ = ctx.prove(pkh, W, a, b, c, r, s)
                 assert B.proof_write(got["raw"]) == want, (knob, cfg)
+            ctx.pk_free(pkh)
+    finally:
+        _reset(ctx)
+        assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
+
+
+@pytest.mark.parametrize("log_n", [13, 16, 18])
+def test_z_digit_count_from_compute_h_equals_the_count_pass(ctx, log_n):
+    """the Z MSM's digit count taken from computeH's last launch (mi_ctx::zhook) against the sort's own count pass and the oracle: c given
+    and c = NULL (formed on the device), fewer constraints than the domain (zero padding), window widths 17 and 20 for Z"""
+    B = load_binding()
+    N = 1 << log_n
+    nw, nc = N - 37, N - 5
+    pk = synthetic_pk(log_n, nw, 40, 7000 + log_n)
+    W = cref.gen_scalars(nw, 1, 1); a = cref.gen_scalars(nc, 2, 0); b = cref.gen_scalars(nc, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    try:
+        for cz in (17, 20):
+            assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 17, 17, cz) == 0
+            pkh = ctx.pk_load(pk)
+            for fused in (1, 0, 1):
+                ctx.set_knob("z_count_fused", fused)
+                got, _ = ctx.prove(pkh, W, a, b, c, r, s)
+                assert B.proof_write(got["raw"]) == want, (cz, fused, "c given")
+                got, _ = ctx.prove(pkh, W, a, b, None, r, s)
+                assert B.proof_write(got["raw"]) == want, (cz, fused, "c formed on the device")
             ctx.pk_free(pkh)
     finally:
         _reset(ctx)
