@@ -734,9 +734,18 @@ def main():
     # ---- the timed region: K steps
     fence()
     t0 = time.perf_counter()
-    done = list(ex.map(lambda _: one_step(), range(args.steps)))
+    done_at = []
+    def timed_step(_):
+        r_ = one_step()
+        done_at.append(time.perf_counter())   # (list.append is atomic under the GIL)
+        return r_
+    done = list(ex.map(timed_step, range(args.steps)))
     fence()
     dt = time.perf_counter() - t0
+    # how evenly the steps completed: one stall of the host or the GPU inside a ~1 s region moves `value` by its whole length
+    gaps = sorted((y - x) * 1e3 for x, y in zip([t0] + sorted(done_at)[:-1], sorted(done_at)))
+    step_gaps = {"median_ms": gaps[len(gaps) // 2], "p90_ms": gaps[min(len(gaps) - 1, (len(gaps) * 9) // 10)], "max_ms": gaps[-1],
+                 "note": "intervals between consecutive step completions inside the timed region (the first one includes the pipeline fill)"} if gaps else None
     if dist is not None:
         t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1083,6 +1092,7 @@ def main():
             # inside a proof the five MSMs overlap on five streams, so per-MSM spans there are not rates
             "g1_msm_pts_per_s": solo["msm_pts_per_s"], "g1_pairs_per_proof": g1_pairs_per_proof,
             "phase_ms": {k: last[k] for k in ("compute_h_ms", "msm_a_ms", "msm_b1_ms", "msm_b2_ms", "msm_k_ms", "msm_z_ms", "assemble_ms", "total_ms")},
+            "step_completion_gaps": step_gaps,
             "clocks_under_load": clocks,
             "roofline": roofline,
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
