@@ -3,7 +3,7 @@ inputs with a BSB22 commitment (mi_prover_commit + mi_prover_submit_bsb22: the P
 mixed -- every one compared with the proof a plain context computed alone, every commitment and PoK with the first one computed.
 Half the witnesses are UNIFORM wire values (13-15 digits per scalar in the four wire MSMs instead of the WHIR mix's ~4.4), so the rate
 printed here is well below bench.py's (22.8 against 31 proofs/s at 2^23).
-usage: python tools/soak_pool.py [log_n] [jobs] [in_flight]"""
+usage: python tools/soak_pool.py [log_n] [jobs] [in_flight] [knobs: name=value,...]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import numpy as np
@@ -15,6 +15,9 @@ depth = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 N = 1 << log_n
 nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
 pool = B.Prover(0, depth); c0 = pool.ctx(0)
+for part in [x for x in (sys.argv[4] if len(sys.argv) > 4 else "").split(",") if x]:   # mi_debug_set_knob on every context of the pool
+    k_, _, v_ = part.partition("=")
+    pool.set_knob(k_.strip(), int(v_))
 rng = np.random.default_rng(5)
 inf_a = (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8); inf_b = (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
 na, nb, nk = int((inf_a == 0).sum()), int((inf_b == 0).sum()), nb_wires - nb_public
