@@ -25,7 +25,7 @@ EXPORTS = [
     "mi_batch_scalar_mul_g1", "mi_batch_scalar_mul_g1_dev", "mi_batch_scalar_mul_g2", "mi_batch_scalar_mul_g2_dev",
     "mi_pedersen_pk_load", "mi_pedersen_pk_free", "mi_pedersen_commit", "mi_pedersen_prove_knowledge", "mi_pedersen_fold",
     "mi_debug_set_prove_fixed_base", "mi_debug_set_prove_schedule", "mi_debug_set_msm_batch_affine", "mi_debug_set_msm_group_bits", "mi_debug_inject_hip_failure", "mi_debug_set_ntt_plan", "mi_debug_set_ntt_threads", "mi_debug_set_ntt_wave_stages",
-    "mi_debug_set_msm_plan", "mi_debug_set_msm_chunk", "mi_debug_set_msm_one_pass_sort", "mi_debug_set_msm_bound_levels", "mi_debug_set_msm_limb29", "mi_debug_set_msm_l1_waves", "mi_debug_set_msm_precompute_batched", "mi_debug_set_ntt_fuse_pair", "mi_debug_set_knob", "mi_debug_set_stream_plan", "mi_debug_set_trace_ranges",
+    "mi_debug_set_msm_plan", "mi_debug_set_msm_chunk", "mi_debug_set_msm_one_pass_sort", "mi_debug_set_msm_bound_levels", "mi_debug_set_msm_limb29", "mi_debug_set_msm_l1_waves", "mi_debug_set_msm_precompute_batched", "mi_debug_set_ntt_fuse_pair", "mi_debug_set_knob", "mi_debug_get_counter", "mi_debug_set_stream_plan", "mi_debug_set_trace_ranges",
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
     "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22", "mi_prover_trim", "mi_ctx_trim",
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_create_rank_ex", "mi_group_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
@@ -175,6 +175,12 @@ class Context:
     def set_knob(self, name, value):
         """mi_debug_set_knob: a named measurement / test knob of this context (the header lists them)"""
         self._ck(self.lib.mi_debug_set_knob(self.h, C.c_char_p(name.encode()), C.c_int64(int(value))))
+
+    def counter(self, name):
+        """mi_debug_get_counter: how often an optional path ran on this context"""
+        v = C.c_uint64()
+        self._ck(self.lib.mi_debug_get_counter(self.h, C.c_char_p(name.encode()), C.byref(v)))
+        return int(v.value)
 
     def alloc(self, nbytes):
         return DevArray(self, nbytes)

@@ -386,6 +386,12 @@ static MsmShape key_shape(const MsmSlot &sl) {
 //   0  slot 3 (K) created, then destroyed and pointed at slot 1's stream (rounds 4-5)          1  slot 3 never created
 //   2  as 1, and slot 1 (B1 + K) on slot 0's stream (A): three wire chains instead of four
 static std::atomic<int> g_stream_plan{1};
+// counters the tests read to prove that an optional path really ran (names in the header)
+extern "C" int32_t mi_debug_get_counter(mi_ctx *ctx, const char *name, uint64_t *out) {
+    if (!ctx || !name || !out) return MI_EINVAL;
+    if (!std::strcmp(name, "z_count_fused_launches")) { *out = ctx->z_count_fused_launches; return MI_OK; }
+    MI_FAIL(ctx, MI_EINVAL, std::string("unknown counter: ") + name);
+}
 extern "C" int32_t mi_debug_set_stream_plan(int32_t plan) {
     if (plan < 0 || plan > 2) return MI_EINVAL;
     g_stream_plan.store(plan);

@@ -588,6 +588,9 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
  *   "hold_accum" 0 | 1       = mi_debug_set_prove_schedule
  *   "ntt_lds_floor_kb" 0..160   LDS every NTT pass workgroup requests at least (caps the workgroups per CU) */
 int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value);
+/* Counters the tests read to prove that an optional path really ran: "z_count_fused_launches" = computeH last launches of this context that
+ * carried the Z MSM's digit count (knob "z_count_fused").  MI_EINVAL for an unknown name. */
+int32_t mi_debug_get_counter(mi_ctx *ctx, const char *name, uint64_t *out);
 /* Process-wide, for contexts created afterwards: how the MSM slots of a context share streams (0: K's stream created, destroyed and
  * pointed at B1's, as rounds 4-5 did; 1, the default: never created; 2: A, B1 and K on one stream).  Same results; an experiment on which
  * chains end up on one hardware queue. */

@@ -148,11 +148,48 @@ def test_z_digit_count_from_compute_h_equals_the_count_pass(ctx, log_n):
             pkh = ctx.pk_load(pk)
             for fused in (1, 0, 1):
                 ctx.set_knob("z_count_fused", fused)
+                before = ctx.counter("z_count_fused_launches")
                 got, _ = ctx.prove(pkh, W, a, b, c, r, s)
                 assert B.proof_write(got["raw"]) == want, (cz, fused, "c given")
                 got, _ = ctx.prove(pkh, W, a, b, None, r, s)
                 assert B.proof_write(got["raw"]) == want, (cz, fused, "c formed on the device")
+                assert ctx.counter("z_count_fused_launches") == before + 2 * fused, (cz, fused)   # not vacuous: the fused launch ran, or did not
             ctx.pk_free(pkh)
     finally:
         _reset(ctx)
         assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
+
+
+def test_z_digit_count_from_compute_h_with_two_slices_per_tile(ctx):
+    """N = 2^24: the last launch's tile holds 2^10 elements = TWO slices of the Z sort.  Device-generated key and witness (as bench.py's); the
+    proof with the fused count must equal the proof with the sort's own count pass (the path the oracle is compared with at every size)."""
+    B = load_binding()
+    log_n = 24
+    N = 1 << log_n
+    nw, npub, nc = N - 1000, 4097, N - 100
+    rng = np.random.default_rng(77)
+    inf_a = (rng.integers(0, 100, nw) < 10).astype(np.uint8); inf_b = (rng.integers(0, 100, nw) < 50).astype(np.uint8)
+    na, nb, nk = int((inf_a == 0).sum()), int((inf_b == 0).sum()), nw - npub
+    g1a, g1b, g1k, g1z, g2b = ctx.gen_g1(na, 1), ctx.gen_g1(nb, 2), ctx.gen_g1(nk, 3), ctx.gen_g1(N, 4), ctx.gen_g2(nb, 5)
+    small = ctx.gen_g1(3, 6).download((3, 8)); small2 = ctx.gen_g2(2, 7).download((2, 16))
+    pk = {"log_n": log_n, "nb_public": npub, "nb_wires": nw, "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk), "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb),
+          "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b}
+    pkh = ctx.pk_load(pk, device_points=True)
+    W = ctx.gen_scalars(nw, 8, 1); a = ctx.gen_scalars(nc, 9, 1); b = ctx.gen_scalars(nc, 10, 0)
+    c = ctx.alloc(32 * nc); ctx.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, nc)
+    rs = ctx.gen_scalars(2, 11, 0).download((2, 4)); ctx.sync()
+    try:
+        got = {}
+        before = ctx.counter("z_count_fused_launches")
+        for fused in (0, 1, 0):
+            ctx.set_knob("z_count_fused", fused)
+            pr, _ = ctx.prove(pkh, W.ptr, a.ptr, b.ptr, c.ptr, rs[0], rs[1], device=True, n_wires=nw, n_constraints=nc)
+            got.setdefault(fused, []).append(B.proof_write(pr["raw"]))
+        assert got[0][0] == got[0][1] == got[1][0]
+        assert ctx.counter("z_count_fused_launches") == before + 1   # the one proof with the knob on took its count from computeH
+    finally:
+        _reset(ctx)
+        ctx.pk_free(pkh)
+        for d in (g1a, g1b, g1k, g1z, g2b, W, a, b, c):
+            d.free()
+        assert ctx.lib.mi_ctx_trim(ctx.h) == 0
