@@ -150,9 +150,20 @@ def live_pmc(script, script_args, counters, timeout_s=240):
         for counter in counters:
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", script)] + [str(x) for x in script_args]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
-            if r.returncode != 0:
-                return {"error": f"{counter} pass over {script}: rc {r.returncode}: {r.stdout.decode(errors='replace')[-200:]}"}
+            # (a session of its own: on a timeout the whole group goes -- the profiler AND the program under it -- not just the direct child)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+            try:
+                out_b, _ = pr.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.wait()
+                return {"error": f"{counter} pass over {script}: no answer within {timeout_s} s"}
+            if pr.returncode != 0:
+                return {"error": f"{counter} pass over {script}: rc {pr.returncode}: {out_b.decode(errors='replace')[-200:]}"}
             dbs = glob.glob(d + "/**/*_results.db", recursive=True)
             if not dbs:
                 return {"error": f"{counter} pass over {script} wrote no rocpd database"}
