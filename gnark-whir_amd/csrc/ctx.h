@@ -31,7 +31,7 @@ struct MsmSlot {            // one in-flight MSM (msm.hip): own stream, events, 
     bool active = false, timed = false;
     bool deferred = false;      // accumulate stage done up to the bucket sums, reduce not yet enqueued (MI_MSM_DEFER_REDUCE)
     uint32_t tail_seg = 0;      // buckets per bucket-reduce thread
-    const uint32_t *entries_src = nullptr;   // device word holding the number of sorted entries (stats)
+    const uint32_t *entries_src = nullptr;   // HOST word holding the number of sorted entries (stats): in the pinned memory of the slot that owns the sort
     // Set by the caller before mi_msm_enqueue, consumed by it: called on the enqueueing thread right before the bucket accumulation is
     // enqueued (after the sort); blocks until the event it returns HAS BEEN RECORDED and the slot's stream then waits for that event
     // (null result = no wait).  prove.hip holds the wire MSMs' accumulations back until computeH is done this way.

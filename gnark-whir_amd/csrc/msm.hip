@@ -277,7 +277,11 @@ __global__ void __launch_bounds__(64) k_scan_of_sums(u32 *block_sums, u32 nblock
 // mode 0: block_sums holds the exclusive scan of the block sums (+ the total at [gridDim.x]) -- after k_scan_of_sums
 // mode 1: a single block: no block sums at all
 // mode 2: block_sums holds the raw sums of <= SCAN_MAX_INLINE_BLOCKS blocks: every workgroup scans them itself (saves the k_scan_of_sums launch)
-__global__ void __launch_bounds__(64) k_scan_final(const u32 *in, size_t m, const u32 *block_sums, u32 *out, int mode) {
+// The block that writes out[m] can also leave words in PINNED HOST memory (device-visible: hipHostMalloc) for the enqueueing thread: the
+// total (total_host) and one more word (copy_src -> copy_host: the sort's fullest bucket).  A hipMemcpyAsync of four bytes is a blit KERNEL
+// (__amd_rocclr_copyBuffer: 22 per proof, ~60 us each inside the job, every one on an MSM's chain); a store from a kernel that runs anyway is not.
+__global__ void __launch_bounds__(64) k_scan_final(const u32 *in, size_t m, const u32 *block_sums, u32 *out, int mode,
+                                                   u32 *total_host = nullptr, const u32 *copy_src = nullptr, u32 *copy_host = nullptr) {
     u32 offset = 0, grand = 0;
     if (mode == 0) { offset = block_sums[blockIdx.x]; grand = block_sums[gridDim.x]; }
     if (mode == 2) {   // lane t holds the sums of blocks 8 t .. 8 t + 7; this block's offset = sums of the blocks before it
@@ -302,7 +306,11 @@ __global__ void __launch_bounds__(64) k_scan_final(const u32 *in, size_t m, cons
         ex += v[k];
     }
     if (mode == 1) grand = total;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[m] = grand;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        out[m] = grand;
+        if (total_host) *total_host = grand;
+        if (copy_host) *copy_host = *copy_src;
+    }
 }
 // prep of the next level fused with the first half of its scan: thread = SCAN_PER_THREAD consecutive keys, as in k_scan_block_sums
 __global__ void __launch_bounds__(64) k_msm_prep_next_sums(u32 nkeys, const u32 *prev_items, const u32 *prev_item_start, u32 L, u32 *start, u32 *cnt,
@@ -337,20 +345,22 @@ __global__ void __launch_bounds__(64) k_msm_finish_list(u32 nkeys, const u32 *it
     if (small) list_small[base_s + (u32)__popcll(ms & below)] = key;
     if (big) list_big[base_b + (u32)__popcll(mb & below)] = key;
 }
-static int32_t exclusive_scan(mi_ctx *ctx, hipStream_t st, const u32 *in, size_t m, u32 *out, DevBuf &tmp) {
+// total_host / copy_src -> copy_host: words the last kernel also leaves in pinned host memory (k_scan_final), or null
+static int32_t exclusive_scan(mi_ctx *ctx, hipStream_t st, const u32 *in, size_t m, u32 *out, DevBuf &tmp,
+                              u32 *total_host = nullptr, const u32 *copy_src = nullptr, u32 *copy_host = nullptr) {
     u32 nblocks = (u32)((m + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (nblocks == 0) nblocks = 1;
     MI_TRY(mi_reserve(ctx, tmp, (size_t)(nblocks + 1) * 4));
     u32 *bs = (u32 *)tmp.p;
     if (nblocks == 1) {
-        hipLaunchKernelGGL(k_scan_final, dim3(1), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 1);
+        hipLaunchKernelGGL(k_scan_final, dim3(1), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 1, total_host, copy_src, copy_host);
     } else if (nblocks <= SCAN_MAX_INLINE_BLOCKS) {
         hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs);
-        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 2);
+        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 2, total_host, copy_src, copy_host);
     } else {
         hipLaunchKernelGGL(k_scan_block_sums, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs);
         hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(SCAN_THREADS), 0, st, bs, nblocks);
-        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 0);
+        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(SCAN_THREADS), 0, st, in, m, bs, out, 0, total_host, copy_src, copy_host);
     }
     MI_CHECK_HIP(ctx, hipGetLastError());
     return MI_OK;
@@ -472,18 +482,21 @@ __global__ void __launch_bounds__(256) k_max_u32(const u32 *v, u32 n, u32 *out) 
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 // totals == nullptr: the word at sl.buf[B_MAX] has been computed already (k_msm2_colsum); only the copy and the event are enqueued
-static int32_t fetch_max_enqueue(mi_ctx *ctx, MsmSlot &sl, const u32 *totals, u32 nkeys) {
+// Then the scan of the per-key totals -> keystart, whose last kernel ALSO leaves that word (host_wsum + 128*256 + 32) and the number of
+// sorted entries (host_wsum + 128*256) in the slot's pinned host memory: no copy launches (k_scan_final); ev[6] follows the scan.
+static int32_t fetch_max_and_scan_keys(mi_ctx *ctx, MsmSlot &sl, const u32 *totals, u32 nkeys, u32 *keystart, bool compute_max) {
     MI_TRY(mi_reserve(ctx, sl.buf[B_MAX], 64));
     u32 *dmax = (u32 *)sl.buf[B_MAX].p;
     hipStream_t st = sl.stream;
-    if (totals) {
+    if (compute_max) {
         MI_CHECK_HIP(ctx, hipMemsetAsync(dmax, 0, 4, st));
         unsigned grid = (nkeys + 255) / 256;
         if (grid > 1024) grid = 1024;
         hipLaunchKernelGGL(k_max_u32, dim3(grid), dim3(256), 0, st, totals, nkeys, dmax);
         MI_CHECK_HIP(ctx, hipGetLastError());
     }
-    MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)sl.host_wsum + 128 * 256 + 32, dmax, 4, hipMemcpyDeviceToHost, st));
+    char *host = (char *)sl.host_wsum + 128 * 256;
+    MI_TRY(exclusive_scan(ctx, st, totals, nkeys, keystart, sl.buf[B_SCAN], (u32 *)host, dmax, (u32 *)(host + 32)));
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[6], st));
     sl.max_pending = true;
     return MI_OK;
@@ -579,7 +592,7 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
             u32 *bs = (u32 *)sl.buf[B_SCAN].p;
             hipLaunchKernelGGL(k_msm_prep_next_sums, dim3(scan_blocks), dim3(SCAN_THREADS), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt,
                                nxt.items, bs);
-            hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_THREADS), 0, st, nxt.items, (size_t)nkeys, bs, nxt.item_start, 2);
+            hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_THREADS), 0, st, nxt.items, (size_t)nkeys, bs, nxt.item_start, 2, nullptr, nullptr, nullptr);
             MI_CHECK_HIP(ctx, hipGetLastError());
         } else {
             hipLaunchKernelGGL(k_msm_prep_next, dim3((nkeys + 63) / 64), dim3(64), 0, st, nkeys, cur.items, cur.item_start, L_next, nxt.start, nxt.cnt, nxt.items);
@@ -626,8 +639,7 @@ static int32_t msm_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u32
     MI_CHECK_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_msm_colsum, dim3((s.nkeys + 255) / 256), dim3(256), 0, st, s, H, total);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(fetch_max_enqueue(ctx, sl, total, s.nkeys));
-    MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
+    MI_TRY(fetch_max_and_scan_keys(ctx, sl, total, s.nkeys, keystart, true));
     hipLaunchKernelGGL(k_msm_scatter, dim3(s.nslices, s.nwin), dim3(1024), lds_bytes, st, s, digits, keystart, H, sorted);
     MI_CHECK_HIP(ctx, hipGetLastError());
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[0], st));
@@ -689,7 +701,8 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
 #undef MI_LAUNCH_COUNT
     }
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(exclusive_scan(ctx, st, C1, (size_t)s.ngroups * G, S1, sl.buf[B_SCAN]));
+    u32 *host_total = (u32 *)((char *)sl.host_wsum + 128 * 256 + 16);
+    MI_TRY(exclusive_scan(ctx, st, C1, (size_t)s.ngroups * G, S1, sl.buf[B_SCAN], exact ? host_total : nullptr));
     // Entry-indexed workspaces (two partition arrays, chunk histograms, sorted entries; later the per-item partial sums) take
     // ~19 B per entry.  The bound nwin * n is tight for uniform scalars (the h coefficients of the Z MSM) but 3x too large
     // for wire values (45 % of them in {0, 1}, 25 % bytes: 4..5 non-zero digits of 14).  `exact`: the count pass
@@ -697,9 +710,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     // enqueued keeps the GPU busy meanwhile) and size by it.  N = 2^26: 80 -> 35 GB of workspaces per context.
     u64 T = T_bound;
     if (exact) {
-        u32 *host_total = (u32 *)((char *)sl.host_wsum + 128 * 256 + 16);
-        MI_CHECK_HIP(ctx, hipMemcpyAsync(host_total, S1 + (size_t)s.ngroups * G, 4, hipMemcpyDeviceToHost, st));
-        MI_CHECK_HIP(ctx, hipStreamSynchronize(st));
+        MI_CHECK_HIP(ctx, hipStreamSynchronize(st));   // (the scan's last kernel stored the total in pinned host memory)
         T = *host_total;
         if (T > T_bound) MI_FAIL(ctx, MI_EHIP, "msm: counted more entries than windows * n");
     }
@@ -725,8 +736,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     hipLaunchKernelGGL(k_msm2_hist2, dim3(chunks_bound), dim3(1024), s.gsize * 4, st, s, gstart, cstart, part_lo, H2);
     hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 63) / 64), dim3(64), 0, st, s, cstart, H2, total, (u32 *)sl.buf[B_MAX].p);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(fetch_max_enqueue(ctx, sl, nullptr, s.nkeys));
-    MI_TRY(exclusive_scan(ctx, st, total, s.nkeys, keystart, sl.buf[B_SCAN]));
+    MI_TRY(fetch_max_and_scan_keys(ctx, sl, total, s.nkeys, keystart, false));   // (the fullest bucket: k_msm2_colsum left it in B_MAX)
     // staged (destination-order) scatter where a chunk fits eight entries per thread and two workgroups still share a CU's LDS
     const bool plain_scatter = kn->plain_scatter != 0;   // (tests and A/Bs: mi_debug_set_knob "plain_scatter")
     const size_t staged_lds = ((size_t)2 * s.gsize + 16 + chunk) * 4 + (size_t)chunk * 2;
@@ -783,7 +793,7 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     // everything below reads the bucket sums only: a point-sharded MSM (group.hip, SURVEY 8e option ii) stops here, exchanges
     // bucket slices between the devices and calls mi_msm_reduce_enqueue afterwards
     acc.tail_seg = seg;
-    acc.entries_src = (const u32 *)srt.buf[B_S].p + s.nkeys;
+    acc.entries_src = (const u32 *)((const char *)srt.host_wsum + 128 * 256);   // HOST word: the sort's key scan left the number of sorted entries there (fetch_max_and_scan_keys)
     acc.timed = timed;
     acc.deferred = defer_reduce;
     if (defer_reduce) {
@@ -806,17 +816,17 @@ static int32_t msm_tail_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &ac
     ops.bucket_reduce(st, (tb + 63) / 64, s.nwin, bucket, s.nbuckets, seg, tb, P);
     MI_CHECK_HIP(ctx, hipGetLastError());
     // window sums: LDS tree sums of sum_T partials per workgroup until one point per window is left ([w][0] layout = wsum[w])
+    // (the LAST tree -- one point per window left -- stores straight into the slot's pinned host memory: no copy launch behind it)
     char *cur = P, *next = P + (size_t)s.nwin * tb * ops.xyzz_bytes;
+    bool on_host = false;
     for (u32 k = tb; k > 1;) {
         const u32 nout = (k + ops.sum_T - 1) / ops.sum_T;
-        ops.sum_tree(st, nout, s.nwin, cur, k, next);
+        ops.sum_tree(st, nout, s.nwin, cur, k, nout == 1 ? (char *)acc.host_wsum : next);
+        on_host = nout == 1;
         cur = next; next += (size_t)s.nwin * nout * ops.xyzz_bytes; k = nout;
     }
     MI_CHECK_HIP(ctx, hipGetLastError());
-    char *wsum = cur;
-    MI_CHECK_HIP(ctx, hipMemcpyAsync(acc.host_wsum, wsum, ops.xyzz_bytes * s.nwin, hipMemcpyDeviceToHost, st));
-    // number of sorted entries (= mixed additions of level 1) for the stats: keystart[nkeys]
-    MI_CHECK_HIP(ctx, hipMemcpyAsync((char *)acc.host_wsum + 128 * 256, acc.entries_src, 4, hipMemcpyDeviceToHost, st));
+    if (!on_host) MI_CHECK_HIP(ctx, hipMemcpyAsync(acc.host_wsum, P, ops.xyzz_bytes * s.nwin, hipMemcpyDeviceToHost, st));   // tb == 1: no tree ran
     MI_CHECK_HIP(ctx, hipEventRecord(acc.ev[4], st));
     acc.deferred = false;
     acc.active = true;
@@ -835,9 +845,9 @@ static int32_t msm_finish(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, void
         ctx->stats.g1_accum_kernel_ms += ms;
         ctx->stats.g1_accum_pairs += sl.stat_pairs;
         ctx->stats.g1_accum_launches += 1;
-        ctx->stats.g1_accum_entries += *(const u32 *)((const char *)sl.host_wsum + 128 * 256);
+        ctx->stats.g1_accum_entries += *sl.entries_src;
     }
-    if (ops.xyzz_bytes == 128) ctx->stats.g1_level1_additions += *(const u32 *)((const char *)sl.host_wsum + 128 * 256);   // every G1 MSM, timed or not
+    if (ops.xyzz_bytes == 128) ctx->stats.g1_level1_additions += *sl.entries_src;   // every G1 MSM, timed or not (a host word: the owning sort's key scan stored it)
     sl.active = false;
     return MI_OK;
 }
@@ -897,7 +907,8 @@ int32_t mi_msm_enqueue(mi_ctx *ctx, int slot, int sort_slot, int curve, const vo
         MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[3], sl.stream));
         MI_CHECK_HIP(ctx, hipMemsetAsync(sl.buf[B_BUCKET].p, 0, (size_t)s.nkeys * ops.xyzz_bytes + 64, sl.stream));
         sl.tail_seg = knobs_of(ctx)->seg ? knobs_of(ctx)->seg : msm_auto_seg(s.nbuckets);
-        sl.entries_src = (const u32 *)((const char *)sl.buf[B_BUCKET].p + (size_t)s.nkeys * ops.xyzz_bytes);   // a zeroed word: no entries
+        static const u32 no_entries = 0;
+        sl.entries_src = &no_entries;   // (a host word, like every slot's)
         sl.timed = false;
         sl.deferred = true;
         MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[5], sl.stream));
