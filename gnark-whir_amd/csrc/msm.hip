@@ -79,9 +79,19 @@ __global__ void __launch_bounds__(1024) k_msm_scatter(MsmShape s, const int16_t 
     __syncthreads();
     msm_scatter_move(s, digits, g, w, lds_u32, sorted, threadIdx.x, blockDim.x);
 }
-__global__ void k_msm_prep1(MsmShape s, const u32 *S, u32 L, u32 *start, u32 *cnt, u32 *items) {
+// Also does what a hipMemsetAsync of the whole bucket array did (a launch of its own at the head of every accumulate stage, 67 MB for the Z
+// MSM's 2^19 buckets): a key WITHOUT entries gets its bucket = infinity (all zero) here -- every other bucket is written by the item that
+// ends it -- and the words behind the array (the finisher's list counters) are zeroed.  bucket_words = u32 words per bucket (32 / 64).
+__global__ void k_msm_prep1(MsmShape s, const u32 *S, u32 L, u32 *start, u32 *cnt, u32 *items, u32 *bucket, u32 bucket_words) {
     u32 key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key < s.nkeys) msm_prep_level1(s, S, L, start, cnt, items, key);
+    if (key < s.nkeys) {
+        msm_prep_level1(s, S, L, start, cnt, items, key);
+        if (bucket && cnt[key] == 0) {
+            uint4 *b = reinterpret_cast<uint4 *>(bucket + (size_t)key * bucket_words);
+            for (u32 k = 0; k < bucket_words / 4; k++) b[k] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    if (bucket && key < 16) bucket[(size_t)s.nkeys * bucket_words + key] = 0;
 }
 __global__ void k_msm_prep_next(u32 nkeys, const u32 *prev_items, const u32 *prev_item_start, u32 L, u32 *start, u32 *cnt, u32 *items) {
     u32 key = blockIdx.x * blockDim.x + threadIdx.x;
@@ -161,11 +171,6 @@ __global__ void __launch_bounds__(MSM2_PART_THREADS) k_msm2_partition(Msm2Shape 
     __syncthreads();
     msm2_stage_copy_body(s, gbase, loff, stage_lo, stage_val, stage_grp, part_lo, part_val, threadIdx.x, blockDim.x);
 }
-__global__ void k_msm2_chunk_count(Msm2Shape s, const u32 *S1, u32 *gstart, u32 *nchunks, u32 *max_word) {
-    u32 hi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (hi == 0) *max_word = 0;   // k_msm2_colsum's atomicMax target, two launches further down the stream
-    if (hi < s.ngroups) msm2_chunk_count_body(s, S1, gstart, nchunks, hi);
-}
 __global__ void __launch_bounds__(1024) k_msm2_hist2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const uint16_t *part_lo, u32 *H2) {
     extern __shared__ u32 lds_u32[];
     u32 hi, b, e;
@@ -177,11 +182,15 @@ __global__ void __launch_bounds__(1024) k_msm2_hist2(Msm2Shape s, const u32 *gst
     msm2_hist2_write(s, H2, blockIdx.x, lds_u32, threadIdx.x, blockDim.x);
 }
 // also leaves the fullest bucket's size in *max_out (zeroed on the stream before the launch): what fetch_max_enqueue's own kernel computes
-__global__ void __launch_bounds__(256) k_msm2_colsum(Msm2Shape s, const u32 *cstart, u32 *H2, u32 *total, u32 *max_out) {
+// key_block_sums != null: the wave's sum of totals is added to the key scan's block sum it belongs to (SCAN_BLOCK consecutive keys per block;
+// zeroed by k_msm2_chunk_count_scan) -- the first kernel of that scan (k_scan_block_sums) is then not launched
+__global__ void __launch_bounds__(256) k_msm2_colsum(Msm2Shape s, const u32 *cstart, u32 *H2, u32 *total, u32 *max_out, u32 *key_block_sums) {
     u32 key = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 m = key < s.nkeys ? msm2_colsum_body(s, cstart, H2, total, key) : 0u;
-    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; }
+    const u32 t = key < s.nkeys ? msm2_colsum_body(s, cstart, H2, total, key) : 0u;
+    u32 m = t, sum = t;
+    for (int off = 32; off > 0; off >>= 1) { const u32 o = (u32)__shfl_xor((int)m, off); m = o > m ? o : m; sum += (u32)__shfl_xor((int)sum, off); }
     if ((threadIdx.x & 63) == 0 && m) atomicMax(max_out, m);
+    if (key_block_sums && (threadIdx.x & 63) == 0 && sum) atomicAdd(&key_block_sums[key / (16 * 64)], sum);   // (a wave's 64 keys lie in one block of 1024)
 }
 __global__ void __launch_bounds__(1024) k_msm2_scatter2(Msm2Shape s, const u32 *gstart, const u32 *cstart, const u32 *keystart, const u32 *H2x,
                                                         const uint16_t *part_lo, const u32 *part_val, u32 *sorted) {
@@ -311,6 +320,20 @@ __global__ void __launch_bounds__(64) k_scan_final(const u32 *in, size_t m, cons
         if (total_host) *total_host = grand;
         if (copy_host) *copy_host = *copy_src;
     }
+}
+// The chunk counts of the groups (msm2_chunk_count_body) and the scan of them as ONE single-wave launch (ngroups <= 4096: lane t takes the groups [t*per, (t+1)*per)):
+// gstart, nchunks, cstart = exclusive scan of nchunks (+ the total at [ngroups]).  Also zeroes the two things kernels further down this
+// stream add into: the fullest-bucket word (k_msm2_colsum's atomicMax) and the `nzero` block sums of the key scan (k_msm2_colsum's atomicAdd).
+__global__ void __launch_bounds__(64) k_msm2_chunk_count_scan(Msm2Shape s, const u32 *S1, u32 *gstart, u32 *nchunks, u32 *cstart, u32 *max_word, u32 *key_block_sums, u32 nzero) {
+    const u32 per = (s.ngroups + 63) / 64, g0 = threadIdx.x * per;
+    if (threadIdx.x == 0) *max_word = 0;
+    for (u32 k = threadIdx.x; k < nzero; k += 64) key_block_sums[k] = 0;
+    u32 mine = 0;
+    for (u32 k = 0; k < per; k++) if (g0 + k < s.ngroups) { msm2_chunk_count_body(s, S1, gstart, nchunks, g0 + k); mine += nchunks[g0 + k]; }
+    u32 total;
+    u32 ex = wave_exclusive_scan(mine, &total);
+    for (u32 k = 0; k < per; k++) if (g0 + k < s.ngroups) { cstart[g0 + k] = ex; ex += nchunks[g0 + k]; }
+    if (threadIdx.x == 0) cstart[s.ngroups] = total;
 }
 // prep of the next level fused with the first half of its scan: thread = SCAN_PER_THREAD consecutive keys, as in k_scan_block_sums
 __global__ void __launch_bounds__(64) k_msm_prep_next_sums(u32 nkeys, const u32 *prev_items, const u32 *prev_item_start, u32 L, u32 *start, u32 *cnt,
@@ -484,7 +507,8 @@ __global__ void __launch_bounds__(256) k_max_u32(const u32 *v, u32 n, u32 *out) 
 // totals == nullptr: the word at sl.buf[B_MAX] has been computed already (k_msm2_colsum); only the copy and the event are enqueued
 // Then the scan of the per-key totals -> keystart, whose last kernel ALSO leaves that word (host_wsum + 128*256 + 32) and the number of
 // sorted entries (host_wsum + 128*256) in the slot's pinned host memory: no copy launches (k_scan_final); ev[6] follows the scan.
-static int32_t fetch_max_and_scan_keys(mi_ctx *ctx, MsmSlot &sl, const u32 *totals, u32 nkeys, u32 *keystart, bool compute_max) {
+// sums_ready: the scan's block sums are in sl.buf[B_SCAN] already (k_msm2_colsum added them up): only the scan's last kernel is launched.
+static int32_t fetch_max_and_scan_keys(mi_ctx *ctx, MsmSlot &sl, const u32 *totals, u32 nkeys, u32 *keystart, bool compute_max, bool sums_ready = false) {
     MI_TRY(mi_reserve(ctx, sl.buf[B_MAX], 64));
     u32 *dmax = (u32 *)sl.buf[B_MAX].p;
     hipStream_t st = sl.stream;
@@ -496,7 +520,14 @@ static int32_t fetch_max_and_scan_keys(mi_ctx *ctx, MsmSlot &sl, const u32 *tota
         MI_CHECK_HIP(ctx, hipGetLastError());
     }
     char *host = (char *)sl.host_wsum + 128 * 256;
-    MI_TRY(exclusive_scan(ctx, st, totals, nkeys, keystart, sl.buf[B_SCAN], (u32 *)host, dmax, (u32 *)(host + 32)));
+    if (sums_ready) {
+        const u32 nblocks = (nkeys + SCAN_BLOCK - 1) / SCAN_BLOCK;
+        hipLaunchKernelGGL(k_scan_final, dim3(nblocks), dim3(SCAN_THREADS), 0, st, totals, (size_t)nkeys, (const u32 *)sl.buf[B_SCAN].p, keystart, 2, (u32 *)host, (const u32 *)dmax,
+                           (u32 *)(host + 32));
+        MI_CHECK_HIP(ctx, hipGetLastError());
+    } else {
+        MI_TRY(exclusive_scan(ctx, st, totals, nkeys, keystart, sl.buf[B_SCAN], (u32 *)host, dmax, (u32 *)(host + 32)));
+    }
     MI_CHECK_HIP(ctx, hipEventRecord(sl.ev[6], st));
     sl.max_pending = true;
     return MI_OK;
@@ -730,13 +761,18 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     MSM2_FOR_C(s.c, MI_LAUNCH_PART)
 #undef MI_LAUNCH_PART
     MI_TRY(mi_reserve(ctx, sl.buf[B_MAX], 64));
-    hipLaunchKernelGGL(k_msm2_chunk_count, dim3((s.ngroups + 63) / 64), dim3(64), 0, st, s, S1, gstart, nchunks, (u32 *)sl.buf[B_MAX].p);
+    // three launches less on this chain than rounds 1-4 had: the chunk counts and their scan are one single-wave kernel, and the key scan's
+    // block sums are added up by k_msm2_colsum (up to 2^19 keys: 512 block sums, what k_scan_final's inline mode takes)
+    const u32 key_blocks = (s.nkeys + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const bool fuse_keys = key_blocks > 1 && key_blocks <= SCAN_MAX_INLINE_BLOCKS;
+    MI_TRY(mi_reserve(ctx, sl.buf[B_SCAN], (size_t)(key_blocks + 1) * 4));
+    u32 *key_bs = (u32 *)sl.buf[B_SCAN].p;
+    hipLaunchKernelGGL(k_msm2_chunk_count_scan, dim3(1), dim3(64), 0, st, s, S1, gstart, nchunks, cstart, (u32 *)sl.buf[B_MAX].p, key_bs, fuse_keys ? key_blocks : 0u);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(exclusive_scan(ctx, st, nchunks, s.ngroups, cstart, sl.buf[B_SCAN]));
     hipLaunchKernelGGL(k_msm2_hist2, dim3(chunks_bound), dim3(1024), s.gsize * 4, st, s, gstart, cstart, part_lo, H2);
-    hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 63) / 64), dim3(64), 0, st, s, cstart, H2, total, (u32 *)sl.buf[B_MAX].p);
+    hipLaunchKernelGGL(k_msm2_colsum, dim3((s.nkeys + 63) / 64), dim3(64), 0, st, s, cstart, H2, total, (u32 *)sl.buf[B_MAX].p, fuse_keys ? key_bs : nullptr);
     MI_CHECK_HIP(ctx, hipGetLastError());
-    MI_TRY(fetch_max_and_scan_keys(ctx, sl, total, s.nkeys, keystart, false));   // (the fullest bucket: k_msm2_colsum left it in B_MAX)
+    MI_TRY(fetch_max_and_scan_keys(ctx, sl, total, s.nkeys, keystart, false, fuse_keys));   // (the fullest bucket: k_msm2_colsum left it in B_MAX)
     // staged (destination-order) scatter where a chunk fits eight entries per thread and two workgroups still share a CU's LDS
     const bool plain_scatter = kn->plain_scatter != 0;   // (tests and A/Bs: mi_debug_set_knob "plain_scatter")
     const size_t staged_lds = ((size_t)2 * s.gsize + 16 + chunk) * 4 + (size_t)chunk * 2;
@@ -771,9 +807,8 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     const size_t stride = (size_t)s.nkeys + 1;
     LevelArrays A{la, la + stride, la + 2 * stride, la + 3 * stride}, B{la + 4 * stride, la + 5 * stride, la + 6 * stride, la + 7 * stride};
     void *bucket = acc.buf[B_BUCKET].p;
-    MI_CHECK_HIP(ctx, hipMemsetAsync(bucket, 0, (size_t)s.nkeys * ops.xyzz_bytes + 64, st));
     hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 63) / 64), dim3(64), 0, st,   // single-wave workgroups, like the scans
-                       s, S, L1, A.start, A.cnt, A.items);
+                       s, S, L1, A.start, A.cnt, A.items, (u32 *)bucket, (u32)(ops.xyzz_bytes / 4));   // (also: empty keys' buckets = infinity, finisher counters = 0)
     MI_CHECK_HIP(ctx, hipGetLastError());
     if (acc.accum_gate) {   // the caller's condition for the heavy part (prove.hip: computeH first)
         const hipEvent_t g = (*acc.accum_gate)();
