@@ -21,7 +21,7 @@ def ctx():
 
 def _reset(ctx):
     for k, v in (("l1_wg", 4), ("g2_wg", 1), ("l1_waves", 3), ("z_waves", 0), ("finisher", 1), ("finisher_max", 0), ("plain_scatter", 0), ("count_per", 0),
-                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2), ("z_count_fused", 0)):
+                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2), ("z_count_fused", 1)):
         ctx.set_knob(k, v)
     assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
 
@@ -119,7 +119,7 @@ def test_prove_with_round5_knobs_gives_the_oracle_bytes(ctx):
             assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0
             pkh = ctx.pk_load(pk)
             for cfg in ({}, {"l1_wg": 4}, {"l1_wg": 4, "l1_waves": 2, "g2_wg": 2}, {"finisher": 0}, {"finisher_max": 20, "l1_wg": 2, "z_waves": 2},
-                        {"plain_scatter": 1, "count_per": 8}, {"l1_wg": 1}, {"finisher_min_level": 0, "finisher_max": 1 << 20}, {"z_count_fused": 1}):
+                        {"plain_scatter": 1, "count_per": 8}, {"l1_wg": 1}, {"finisher_min_level": 0, "finisher_max": 1 << 20}, {"z_count_fused": 0}):
                 _reset(ctx)
                 for k, v in cfg.items():
                     ctx.set_knob(k, v)
