@@ -351,6 +351,27 @@ __global__ void __launch_bounds__(64) k_msm_prep_next_sums(u32 nkeys, const u32 
     wave_exclusive_scan(s, &total);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
 }
+// the same for LEVEL 1 (k_msm_prep1's work -- decomposition of every key, infinity into the buckets of keys without entries, the finisher's
+// counters zeroed -- with the block sums of the item scan): the first kernel of that scan is not launched
+__global__ void __launch_bounds__(64) k_msm_prep1_sums(MsmShape s, const u32 *S, u32 L, u32 *start, u32 *cnt, u32 *items, u32 *bucket, u32 bucket_words, u32 *block_sums) {
+    size_t base = (size_t)blockIdx.x * SCAN_BLOCK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    u32 sum = 0;
+    for (u32 k = 0; k < SCAN_PER_THREAD; k++) {
+        const u32 key = (u32)(base + k);
+        if (base + k < s.nkeys) {
+            msm_prep_level1(s, S, L, start, cnt, items, key);
+            sum += items[key];
+            if (cnt[key] == 0) {
+                uint4 *b = reinterpret_cast<uint4 *>(bucket + (size_t)key * bucket_words);
+                for (u32 q = 0; q < bucket_words / 4; q++) b[q] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 16) bucket[(size_t)s.nkeys * bucket_words + threadIdx.x] = 0;
+    u32 total;
+    wave_exclusive_scan(sum, &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
 // The finisher's two lists (msm_curve_kernels.cuh k_msm_finish_keys): keys that still hold 2 .. small_max partial sums / more than
 // small_max.  One atomic per wave and list; the order inside a list is whatever the atomics give (the sums do not depend on it).
 // counters[0..1] are zeroed with the bucket array at the start of the accumulate stage.
@@ -537,7 +558,7 @@ static int32_t fetch_max_and_scan_keys(mi_ctx *ctx, MsmSlot &sl, const u32 *tota
 // already in cur.  Level 0 reads (pts, sorted) when pts != null, else partial_first.
 static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 nkeys, LevelArrays cur, LevelArrays nxt, u64 first_items_bound,
                           u64 max_count, u32 L_first, u32 L_next, const void *pts, const u32 *sorted, const void *partial_first,
-                          void *final_out, bool time_first, bool rprime = false) {
+                          void *final_out, bool time_first, bool rprime = false, bool first_sums_ready = false) {
     hipStream_t st = sl.stream;
     const void *pin = partial_first;
     u64 items_bound = first_items_bound;
@@ -547,7 +568,12 @@ static int32_t run_levels(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &sl, u32 
     // partial sums between the levels in the packed R' form (curve29.cuh) when level 1 runs in 29-bit limbs and the curve has the
     // matching upper-level kernel
     const bool rp_partials = pts && rprime && ops.accum_affine_rp && ops.accum_xyzz_rp && !knobs_of(ctx)->std_partials;
-    MI_TRY(exclusive_scan(ctx, st, cur.items, nkeys, cur.item_start, sl.buf[B_SCAN]));
+    if (first_sums_ready) {   // (k_msm_prep1_sums left the block sums of cur.items in B_SCAN)
+        hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(SCAN_THREADS), 0, st, cur.items, (size_t)nkeys, (const u32 *)sl.buf[B_SCAN].p, cur.item_start, 2, nullptr, nullptr, nullptr);
+        MI_CHECK_HIP(ctx, hipGetLastError());
+    } else {
+        MI_TRY(exclusive_scan(ctx, st, cur.items, nkeys, cur.item_start, sl.buf[B_SCAN]));
+    }
     for (u32 level = 0;; level++) {
         DevBuf &pout_buf = sl.buf[(level & 1) ? B_PART1 : B_PART0];
         MI_TRY(mi_reserve(ctx, pout_buf, (items_bound + 1) * ops.xyzz_bytes));
@@ -807,8 +833,18 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     const size_t stride = (size_t)s.nkeys + 1;
     LevelArrays A{la, la + stride, la + 2 * stride, la + 3 * stride}, B{la + 4 * stride, la + 5 * stride, la + 6 * stride, la + 7 * stride};
     void *bucket = acc.buf[B_BUCKET].p;
-    hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 63) / 64), dim3(64), 0, st,   // single-wave workgroups, like the scans
-                       s, S, L1, A.start, A.cnt, A.items, (u32 *)bucket, (u32)(ops.xyzz_bytes / 4));   // (also: empty keys' buckets = infinity, finisher counters = 0)
+    // level-1 decomposition of every key (also: empty keys' buckets = infinity, finisher counters = 0) -- with the block sums of the item
+    // scan whenever that scan's inline mode takes them (up to 2^19 keys): one launch less in front of every level-1 accumulation
+    const u32 prep_blocks = (s.nkeys + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    const bool prep_sums = prep_blocks <= SCAN_MAX_INLINE_BLOCKS;
+    if (prep_sums) {
+        MI_TRY(mi_reserve(ctx, acc.buf[B_SCAN], (size_t)(prep_blocks + 1) * 4));
+        hipLaunchKernelGGL(k_msm_prep1_sums, dim3(prep_blocks), dim3(SCAN_THREADS), 0, st, s, S, L1, A.start, A.cnt, A.items, (u32 *)bucket, (u32)(ops.xyzz_bytes / 4),
+                           (u32 *)acc.buf[B_SCAN].p);
+    } else {
+        hipLaunchKernelGGL(k_msm_prep1, dim3((s.nkeys + 63) / 64), dim3(64), 0, st,   // single-wave workgroups, like the scans
+                           s, S, L1, A.start, A.cnt, A.items, (u32 *)bucket, (u32)(ops.xyzz_bytes / 4));
+    }
     MI_CHECK_HIP(ctx, hipGetLastError());
     if (acc.accum_gate) {   // the caller's condition for the heavy part (prove.hip: computeH first)
         const hipEvent_t g = (*acc.accum_gate)();
@@ -824,7 +860,7 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
         srt.max_pending = false;
     }
     if (!kn->bound_levels && srt.max_key_count && srt.max_key_count < max_count) max_count = srt.max_key_count;
-    MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed, rprime));
+    MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed, rprime, prep_sums));
     // everything below reads the bucket sums only: a point-sharded MSM (group.hip, SURVEY 8e option ii) stops here, exchanges
     // bucket slices between the devices and calls mi_msm_reduce_enqueue afterwards
     acc.tail_seg = seg;
