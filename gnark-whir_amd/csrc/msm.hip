@@ -39,6 +39,8 @@ struct MsmKnobs {
     u32 g1_grid_per_cu = 0, g2_grid_per_cu = 0; // resident-grid cap per CU of the level-1 launches (0 = 128)
     u32 count_per = 0;                          // fixed-base sort: slices per counting workgroup (0 = 32)
     u32 plain_scatter = 0;                      // fixed-base sort: 1 = pass 2 by the plain scatter instead of the staged one
+    u32 flat_L1 = 0;                            // level-1 item size of a FLAT sort (fullest bucket <= 2 x the average: uniform scalars, prove's Z MSM): 0 = automatic
+                                                // (msm_accum_enqueue: the average / L2^k that falls into 17..32, so that the levels above are full L2-ary trees), 1 = off (L1), 4..64 = forced
     u32 z_count_fused = 1;                      // 1: prove's Z MSM takes its digit count from computeH's last launch (ctx->zhook) instead of a count pass of its own
                                                 // (built for VERDICT r4; throughput equal -- 33.96 against 33.97 proofs/s over 8 same-process rounds --, one proof alone 0.2 ms shorter)
     u32 finisher = 1;                           // 1: item levels whose fullest key holds <= finisher_max partial sums end in ONE launch (k_msm_finish_keys)
@@ -818,7 +820,8 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     acc.n = srt.n; acc.c = srt.c; acc.G = srt.G; acc.nwin_keys = srt.nwin_keys; acc.nwin_digits = srt.nwin_digits;
     const MsmShape s = key_shape(srt);
     const u32 n = s.n;
-    const u32 L1 = kn->L1 ? kn->L1 : 16, L2 = kn->L2 ? kn->L2 : 8;   // tools/tune.py sweep, N = 2^23
+    u32 L1 = kn->L1 ? kn->L1 : 16;
+    const u32 L2 = kn->L2 ? kn->L2 : 8;   // tools/tune.py sweep, N = 2^23
     // buckets per bucket-reduce thread: a thread spends 2 seg additions on its segment and ~19 addition-equivalents on the multiple of its
     // running sum by the segment's base, so the one big bucket set of a fixed-base MSM (2^16 .. 2^21 buckets) wants the longer segment
     // (same-box A/B at N = 2^23: 16 against 8 +0.6 % proofs/s in 7 of 9 pairs; 32 equal, 64 and 4 slower)
@@ -833,6 +836,31 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     const size_t stride = (size_t)s.nkeys + 1;
     LevelArrays A{la, la + stride, la + 2 * stride, la + 3 * stride}, B{la + 4 * stride, la + 5 * stride, la + 6 * stride, la + 7 * stride};
     void *bucket = acc.buf[B_BUCKET].p;
+    // largest possible bucket: one entry per scalar and window of the key space it collects -- or, fetched from this very sort, the
+    // fullest bucket there is (k_max_u32 above: the wait is on the enqueueing thread and ends before the sort does)
+    u64 max_count = (u64)(srt.nwin_digits / srt.nwin_keys) * n;
+    if (srt.max_pending) {
+        MI_CHECK_HIP(ctx, hipEventSynchronize(srt.ev[6]));
+        srt.max_key_count = *(const u32 *)((const char *)srt.host_wsum + 128 * 256 + 32);
+        srt.max_pending = false;
+    }
+    if (!kn->bound_levels && srt.max_key_count && srt.max_key_count < max_count) max_count = srt.max_key_count;
+    // A FLAT sort (uniform scalars: the h coefficients of prove's Z MSM, ~208 entries in every one of 2^19 buckets at N = 2^23): with 16
+    // entries per item a bucket leaves level 1 as 13 partial sums -- two items of level 2, then a third level.  An item size of average /
+    // L2^k (26 there) makes the levels above full L2-ary trees: 8 partial sums, ONE item, no third level (same-process A/B: +0.4..0.6 % /
+    // +0.7 %, 11 and 12 of 12 rounds).  The fullest bucket and the entry count are in host memory by now (the key scan stored them).
+    if (kn->flat_L1 != 1 && !kn->L1 && pts && srt.max_key_count) {
+        const u64 entries = *(const u32 *)((const char *)srt.host_wsum + 128 * 256);
+        const u64 avg = entries / (s.nkeys ? s.nkeys : 1);
+        if (avg >= 64 && (u64)srt.max_key_count <= 2 * avg) {
+            if (kn->flat_L1 >= 4) L1 = kn->flat_L1;
+            else {
+                u64 t = avg;
+                while (t > 32) t = (t + L2 - 1) / L2;
+                if (t >= 17) L1 = (u32)t;
+            }
+        }
+    }
     // level-1 decomposition of every key (also: empty keys' buckets = infinity, finisher counters = 0) -- with the block sums of the item
     // scan whenever that scan's inline mode takes them (up to 2^19 keys): one launch less in front of every level-1 accumulation
     const u32 prep_blocks = (s.nkeys + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -851,15 +879,6 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
         acc.accum_gate = nullptr;
         if (g) MI_CHECK_HIP(ctx, hipStreamWaitEvent(st, g, 0));
     }
-    // largest possible bucket: one entry per scalar and window of the key space it collects -- or, fetched from this very sort, the
-    // fullest bucket there is (k_max_u32 above: the wait is on the enqueueing thread and ends before the sort does)
-    u64 max_count = (u64)(srt.nwin_digits / srt.nwin_keys) * n;
-    if (srt.max_pending) {
-        MI_CHECK_HIP(ctx, hipEventSynchronize(srt.ev[6]));
-        srt.max_key_count = *(const u32 *)((const char *)srt.host_wsum + 128 * 256 + 32);
-        srt.max_pending = false;
-    }
-    if (!kn->bound_levels && srt.max_key_count && srt.max_key_count < max_count) max_count = srt.max_key_count;
     MI_TRY(run_levels(ctx, ops, acc, s.nkeys, A, B, T_bound / L1 + s.nkeys + 1, max_count, L1, L2, pts, sorted, nullptr, bucket, timed, rprime, prep_sums));
     // everything below reads the bucket sums only: a point-sharded MSM (group.hip, SURVEY 8e option ii) stops here, exchanges
     // bucket slices between the devices and calls mi_msm_reduce_enqueue afterwards
@@ -1143,6 +1162,7 @@ int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value) {
     else if (is("count_per") && value >= 0 && value <= 64) k->count_per = (u32)value;
     else if (is("plain_scatter") && (value == 0 || value == 1)) k->plain_scatter = (u32)value;
     else if (is("z_count_fused") && (value == 0 || value == 1)) k->z_count_fused = (u32)value;
+    else if (is("flat_item_l1") && (value == 0 || value == 1 || (value >= 4 && value <= 64))) k->flat_L1 = (u32)value;
     else if (is("finisher") && (value == 0 || value == 1)) k->finisher = (u32)value;
     else if (is("finisher_max") && value >= 0 && value <= (1 << 20)) k->finisher_max = (u32)value;
     else if (is("item_l1") && (value == 0 || (value >= 2 && value <= 64))) k->L1 = (u32)value;     // entries per level-1 item (0 = 16)

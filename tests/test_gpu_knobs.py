@@ -21,7 +21,7 @@ def ctx():
 
 def _reset(ctx):
     for k, v in (("l1_wg", 4), ("g2_wg", 1), ("l1_waves", 3), ("z_waves", 0), ("finisher", 1), ("finisher_max", 0), ("plain_scatter", 0), ("count_per", 0),
-                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2), ("z_count_fused", 1)):
+                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2), ("z_count_fused", 1), ("flat_item_l1", 0)):
         ctx.set_knob(k, v)
     assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
 
@@ -193,3 +193,31 @@ def test_z_digit_count_from_compute_h_with_two_slices_per_tile(ctx):
         for d in (g1a, g1b, g1k, g1z, g2b, W, a, b, c):
             d.free()
         assert ctx.lib.mi_ctx_trim(ctx.h) == 0
+
+
+def test_flat_sort_item_size_agrees_with_oracle(ctx):
+    """a proof whose FIVE MSMs all run over uniform scalars (flat sorts: ~200 entries in every bucket): the automatic level-1 item size of a
+    flat sort (average / L2^k), the plan's own, and forced ones -- the same 164 bytes as the oracle's, and an MSM with a skewed mix beside it"""
+    B = load_binding()
+    log_n = 20
+    N = 1 << log_n
+    nw, nc = N - 37, N - 5
+    pk = synthetic_pk(log_n, nw, 40, 7700)
+    W = cref.gen_scalars(nw, 1, 0); a = cref.gen_scalars(nc, 2, 0); b = cref.gen_scalars(nc, 3, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    n = (1 << 18) + 5
+    pts, sc = _skewed(n, 9400)
+    want_msm = cref.msm_g1(pts, sc)
+    try:
+        assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 17, 17, 17) == 0
+        pkh = ctx.pk_load(pk)
+        for flat in (0, 1, 20, 33, 0):
+            ctx.set_knob("flat_item_l1", flat)
+            got, _ = ctx.prove(pkh, W, a, b, c, r, s)
+            assert B.proof_write(got["raw"]) == want, flat
+            assert np.array_equal(ctx.msm_g1(pts, sc), want_msm), flat
+        ctx.pk_free(pkh)
+    finally:
+        _reset(ctx)
+        assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
