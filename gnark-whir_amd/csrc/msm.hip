@@ -849,7 +849,7 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     // entries per item a bucket leaves level 1 as 13 partial sums -- two items of level 2, then a third level.  An item size of average /
     // L2^k (26 there) makes the levels above full L2-ary trees: 8 partial sums, ONE item, no third level (same-process A/B: +0.4..0.6 % /
     // +0.7 %, 11 and 12 of 12 rounds).  The fullest bucket and the entry count are in host memory by now (the key scan stored them).
-    if (kn->flat_L1 != 1 && !kn->L1 && pts && srt.max_key_count) {
+    if (kn->flat_L1 != 1 && pts && srt.max_key_count) {   // (a flat sort's own size wins over the plan's L1)
         const u64 entries = *(const u32 *)((const char *)srt.host_wsum + 128 * 256);
         const u64 avg = entries / (s.nkeys ? s.nkeys : 1);
         if (avg >= 64 && (u64)srt.max_key_count <= 2 * avg) {

@@ -587,7 +587,7 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
  *   "finisher_max" 0..2^20   0 = automatic (G1 4096, G2 1024)
  *   "finisher_min_level" 0..16   the finisher follows accumulate pass number this + 1 at the earliest (default 2: the first two passes
  *                            are where every ordinary bucket ends; a finisher over 2^19 buckets of 13 partial sums each measured -5 %)
- *   "item_l1", "item_l2", "reduce_seg"   = the L1, L2, seg of mi_debug_set_msm_plan, one at a time
+ *   "item_l1", "item_l2", "reduce_seg"   = the L1, L2, seg of mi_debug_set_msm_plan, one at a time (a flat sort keeps its own item size: "flat_item_l1")
  *   "hold_accum" 0 | 1       = mi_debug_set_prove_schedule
  *   "ntt_lds_floor_kb" 0..160   LDS every NTT pass workgroup requests at least (caps the workgroups per CU) */
 int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value);
