@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(1024) k_msm2_hist2(Msm2Shape s, const u32 *gst
     __syncthreads();
     msm2_hist2_write(s, H2, blockIdx.x, lds_u32, threadIdx.x, blockDim.x);
 }
-// also leaves the fullest bucket's size in *max_out (zeroed on the stream before the launch): what fetch_max_enqueue's own kernel computes
+// also leaves the fullest bucket's size in *max_out (zeroed by k_msm2_chunk_count_scan earlier on the stream): what k_max_u32 computes for the one-pass sort
 // key_block_sums != null: the wave's sum of totals is added to the key scan's block sum it belongs to (SCAN_BLOCK consecutive keys per block;
 // zeroed by k_msm2_chunk_count_scan) -- the first kernel of that scan (k_scan_block_sums) is then not launched
 __global__ void __launch_bounds__(256) k_msm2_colsum(Msm2Shape s, const u32 *cstart, u32 *H2, u32 *total, u32 *max_out, u32 *key_block_sums) {
