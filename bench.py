@@ -20,7 +20,6 @@ GPU-side rate: the same key, inputs already in HBM, no commitment), the single-p
 N = 1 only: the whole step of the benchmarked workload itself -- Commit, ProveKnowledge, fold, prove -- 196 bytes compared).
 """
 import argparse
-import importlib.util
 import json
 import os
 import sys
@@ -29,20 +28,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
-def _binding():
-    spec = importlib.util.spec_from_file_location("gnark_whir_amd_binding", os.path.join(ROOT, "gnark-whir_amd", "binding.py"))
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules["gnark_whir_amd_binding"] = mod
-    spec.loader.exec_module(mod)
-    return mod
-
-
-def _sha16(path):
-    import hashlib
-    try:
-        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
-    except OSError:
-        return None
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from benchlib.common import _binding, _sha16, dist_id_of   # noqa: E402  (the tests and tools reach these through this module)
+from benchlib.pmc import _kernel_short, live_pmc   # noqa: E402,F401
+from benchlib.clocks import ClockSampler   # noqa: E402
+from benchlib.sharded import sharded_helper_main, run_sharded_legs   # noqa: E402
+from benchlib.launch import self_launch, bind_to_gpu_numa_node   # noqa: E402
 
 
 def cpu_baseline(pk_host, W, a, b, c, r, s, ped, log_n, gpu_proof_bytes):
@@ -79,439 +70,15 @@ def cpu_baseline(pk_host, W, a, b, c, r, s, ped, log_n, gpu_proof_bytes):
             "proof_bytes_match": True, "proof_bytes_compared": len(cpu_bytes)}
 
 
-def _kernel_short(name):
-    """'void k_msm_accum_affine29<4, 3>(Affine<...> const*, ...)' -> 'k_msm_accum_affine29' (signature dropped; template arguments of the level-1 kernels too)"""
-    k = name.split("(")[0].replace("void ", "")
-    return k.split("<")[0] if k.startswith(("k_msm_accum_affine29", "k_msm_accum_affine_g2_29")) else k
-
-
-class ClockSampler:
-    """Reads the GPU's shader clock and package power (rocm-smi, read-only; a child process every ~0.2 s from a thread of rank 0) while the
-    timed regions run: the roofline figures assume 2.4 GHz, the chip decides what it sustains under this instruction mix."""
-
-    def __init__(self, device):
-        import threading
-        self.device, self.samples, self._stop = device, [], threading.Event()
-        self._th = threading.Thread(target=self._run, daemon=True)
-
-    def _once(self):
-        import re
-        import subprocess
-        try:
-            out = subprocess.run(["rocm-smi", "-d", str(self.device), "--showclocks", "--showpower", "--csv"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=5).stdout
-            rows = [r for r in out.splitlines() if r.strip()]
-            d = dict(zip(rows[0].split(","), rows[1].split(",")))
-            sclk = int(re.sub(r"[^0-9]", "", d.get("sclk clock speed:", "")) or 0)
-            pw = float(d.get("Current Socket Graphics Package Power (W)", "0") or 0)
-            if sclk > 0:
-                self.samples.append((sclk, pw))
-        except Exception:
-            pass
-
-    def _run(self):
-        while not self._stop.is_set():
-            self._once()
-            self._stop.wait(0.2)
-
-    def start(self):
-        self._th.start()
-        return self
-
-    def stop(self):
-        self._stop.set()
-        self._th.join(timeout=10)
-        if not self.samples:
-            return None
-        sc = [x[0] for x in self.samples]; pw = [x[1] for x in self.samples]
-        return {"sclk_mhz_mean": sum(sc) / len(sc), "sclk_mhz_min": min(sc), "sclk_mhz_max": max(sc), "package_power_w_mean": sum(pw) / len(pw), "samples": len(sc),
-                "how": "rocm-smi --showclocks --showpower every ~0.2 s over the HBM-resident timed region (rank 0's GPU; the host is idle there)",
-                "note": "every roofline / issue-floor figure of this line assumes 2.4 GHz; the chip sustains what its power management allows for the instruction mix"}
-
-
-def live_pmc(script, script_args, counters, timeout_s=240):
-    """Hardware counters MEASURED BY THIS RUN: one child `rocprofv3 --pmc <counter>` per counter (separate passes, as
-    /opt/skills/guides/MI355X_MICROARCH.md prescribes; the program itself right after `--`) over tools/<script>.  Returns
-    {counter: {kernel: {"launches", "total", "per_launch"}}, "seconds": s} (values as rocprofv3 reports them, summed over the counter's dimensions:
-    KB for FETCH_SIZE / WRITE_SIZE) or {"error": ...}.  Children of a process that holds the GPU are started, never exec'ed into; the parent
-    is idle meanwhile (called after the timed regions)."""
-    import glob
-    import shutil
-    import sqlite3
-    import subprocess
-    import tempfile
-    from collections import defaultdict
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return {"error": "rocprofv3 not found"}
-    t0 = time.time()
-    out = {}
-    tmp = tempfile.mkdtemp(prefix="live_pmc_", dir="/tmp")
-    try:
-        for counter in counters:
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "-d", d, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", script)] + [str(x) for x in script_args]
-            # (a session of its own: on a timeout the whole group goes -- the profiler AND the program under it -- not just the direct child)
-            pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
-            try:
-                out_b, _ = pr.communicate(timeout=timeout_s)
-            except subprocess.TimeoutExpired:
-                import signal
-                try:
-                    os.killpg(pr.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-                pr.wait()
-                return {"error": f"{counter} pass over {script}: no answer within {timeout_s} s"}
-            if pr.returncode != 0:
-                return {"error": f"{counter} pass over {script}: rc {pr.returncode}: {out_b.decode(errors='replace')[-200:]}"}
-            dbs = glob.glob(d + "/**/*_results.db", recursive=True)
-            if not dbs:
-                return {"error": f"{counter} pass over {script} wrote no rocpd database"}
-            agg = defaultdict(lambda: [set(), 0.0])
-            for k, did, v in sqlite3.connect(dbs[0]).execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=?", (counter,)):
-                k = _kernel_short(k); agg[k][0].add(did); agg[k][1] += v
-            out[counter] = {k: {"launches": len(v[0]), "total": v[1], "per_launch": v[1] / len(v[0])} for k, v in agg.items()}
-        out["seconds"] = time.time() - t0
-        return out
-    except Exception as e:   # a timeout, a refused profiler, an unreadable database: the line falls back to the committed passes and says so
-        return {"error": f"{type(e).__name__}: {e}"[:300]}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-
-
-def sharded_msm_section(B, g, rank, world, log_n_msm, steps):
-    """BASELINE configs[4]: ONE G1 MSM of 2^log_n_msm pairs, bases point-sharded over the ranks (one per GPU), through the C-ABI's
-    device group g (mi_group_create_rank + mi_msm_g1_sharded_dev, csrc/group.hip): mode 0 = all-gather of per-rank partial sums,
-    mode 1 = reduce-scatter of bucket sums (grouped ncclSend / ncclRecv) before the bucket reduce.  Strong scaling: total work
-    fixed.  Runs in the HELPER PROCESS (see main): no torch, no torch.distributed -- the ranks meet in the group's own collectives;
-    returns this rank's seconds per mode, the caller takes the maximum over the ranks."""
-    import numpy as np
-    n = 1 << log_n_msm
-    lo, hi = B.shard_range(n, world, rank)
-    c = g.ctx(0)
-    pts = c.gen_g1(hi - lo, 4242 + 17 * rank); sc = c.gen_scalars(hi - lo, 2424 + 17 * rank, 0)
-    c.sync()
-    out = {}
-    for mode in (0, 1):
-        ref = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)   # warm-up: sizes the workspaces, and lines the ranks up
-        c.sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            got = g.msm_dev([pts.ptr], [sc.ptr], [hi - lo], n, mode=mode)
-        c.sync()
-        dt = time.perf_counter() - t0
-        assert np.array_equal(got, ref)
-        out[mode] = (got, dt)
-    res = {"steps": steps, "dt0": out[0][1], "dt1": out[1][1], "modes_agree": bool(np.array_equal(out[0][0], out[1][0]))}
-    pts.free(); sc.free()
-    return res
-
-
-def sharded_prove_section(B, g, rank, world, log_n, steps):
-    """BASELINE configs[4] as north_star states it: ONE groth16.Prove of an N = 2^log_n circuit over the ranks of the group
-    (mi_pk_load_sharded_dev + mi_groth16_prove_sharded_dev, csrc/group.hip): every rank keeps its slice of pk.G1.{A,B,K,Z} / pk.G2.B
-    (generated on its own device), rank 0 runs computeH and hands out h slices over the group's transport, the MSMs run point-sharded,
-    mode 0 combines per-rank partial sums, mode 1 reduce-scatters bucket sums first.  Inputs resident in HBM.  Strong scaling.
-    Validity: (1) a small key (N = 2^16, the SAME on every rank) proved sharded in both modes must give the bytes of the unsharded
-    mi_groth16_prove on this rank's own device; (2) at N = 2^log_n both modes must give the same bytes, and with one rank those of the
-    unsharded prove of the same key."""
-    import numpy as np
-    c = g.ctx(0)
-    out = {}
-
-    def masks(nb_wires, seed):
-        rng = np.random.default_rng(seed)
-        return (rng.integers(0, 100, nb_wires) < 10).astype(np.uint8), (rng.integers(0, 100, nb_wires) < 50).astype(np.uint8)
-
-    # ---- (1) small parity: whole key on every rank (device generators, same seeds), host arrays -> mi_pk_load_sharded
-    ls = 16
-    Ns = 1 << ls
-    nw, npub, ncs = Ns - 50, 300, Ns - 10
-    ia, ib = masks(nw, 99)
-    na, nb, nk = int((ia == 0).sum()), int((ib == 0).sum()), nw - npub
-
-    def pull(d, shape):
-        o = d.download(shape); d.free(); return o
-    small = pull(c.gen_g1(3, 206), (3, 8)); small2 = pull(c.gen_g2(2, 207), (2, 16))
-    pk = {"log_n": ls, "nb_public": npub, "nb_wires": nw, "g1_a": pull(c.gen_g1(na, 201), (na, 8)), "g1_b": pull(c.gen_g1(nb, 202), (nb, 8)),
-          "g1_k": pull(c.gen_g1(nk, 203), (nk, 8)), "g1_z": pull(c.gen_g1(Ns, 204), (Ns, 8)), "g2_b": pull(c.gen_g2(nb, 205), (nb, 16)),
-          "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": ia, "infinity_b": ib}
-    W = pull(c.gen_scalars(nw, 208, 1), (nw, 4)); a = pull(c.gen_scalars(ncs, 209, 1), (ncs, 4)); b = pull(c.gen_scalars(ncs, 210, 0), (ncs, 4))
-    cc = c.field_op(0, 2, a, b)
-    rs = pull(c.gen_scalars(2, 211, 0), (2, 4))
-    pkh = c.pk_load(pk)
-    want = B.proof_write(c.prove(pkh, W, a, b, cc, rs[0], rs[1])[0]["raw"])
-    c.pk_free(pkh)
-    spk = g.pk_load(pk)
-    small_ok = all(B.proof_write(g.prove(spk, W, a if rank == 0 else None, b if rank == 0 else None, cc if rank == 0 else None, rs[0], rs[1], mode=m)[0]["raw"]) == want
-                   for m in (0, 1))
-    g.pk_free(spk)
-    out["small_parity"] = {"log_n": ls, "sharded_equals_unsharded_both_modes": bool(small_ok)}
-    if not small_ok:
-        raise RuntimeError("sharded proof of the small key differs from the unsharded proof")
-
-    # ---- (2) the big proof: every rank generates ITS slices on its device
-    N = 1 << log_n
-    nb_wires, nb_public, n_constraints = N - 1000, 4097, N - 100
-    seed = 0x57484952 + 4
-    ia, ib = masks(nb_wires, seed)
-    lo, hi = g.wire_range(nb_wires, rank); zlo, zhi = B.shard_range(N - 1, world, rank)   # wires by the group's lead share (automatic), the Z pairs evenly
-    na, nb = int((ia[lo:hi] == 0).sum()), int((ib[lo:hi] == 0).sum())
-    nk = max(hi, nb_public) - max(lo, nb_public)
-    rseed = seed + 1000 * rank
-    arrs = {"g1_a": (c.gen_g1(na, rseed + 1), na), "g1_b": (c.gen_g1(nb, rseed + 2), nb), "g1_k": (c.gen_g1(nk, rseed + 3), nk),
-            "g1_z": (c.gen_g1(zhi - zlo, rseed + 4), zhi - zlo), "g2_b": (c.gen_g2(nb, rseed + 5), nb)}
-    hdr = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "alpha1": small[0], "beta1": small[1], "delta1": small[2],
-           "beta2": small2[0], "delta2": small2[1], "infinity_a": ia, "infinity_b": ib}
-    Wd = c.gen_scalars(hi - lo, rseed + 8, 1)
-    da = db = dc = None
-    over_ranks = world in (2, 4, 8, 16)   # computeH over the ranks (mi_groth16_prove_sharded_slices_dev): every rank then needs ITS rows of a and b
-    if rank == 0 or over_ranks:           # (every rank generates the whole vectors -- same seeds -- and points into them: simple, and 2 x 2 GB at N = 2^26)
-        da = c.gen_scalars(n_constraints, seed + 9, 1); db = c.gen_scalars(n_constraints, seed + 10, 0)
-    if rank == 0:
-        dc = c.alloc(32 * n_constraints)
-        c.field_op_dev(0, 2, dc.ptr, da.ptr, db.ptr, n_constraints)
-    c.sync()
-    ptr = lambda d: None if d is None else d.ptr
-    unsharded = None
-    if world == 1:   # the same key through the unsharded entry points first (both keys at once would not fit at N = 2^26)
-        full = dict(hdr); full.update({k: (v[0].ptr, v[1]) for k, v in arrs.items()})
-        pkh = c.pk_load(full, device_points=True)
-        unsharded = B.proof_write(c.prove(pkh, Wd.ptr, da.ptr, db.ptr, dc.ptr, rs[0], rs[1], device=True, n_wires=nb_wires, n_constraints=n_constraints)[0]["raw"])
-        c.pk_free(pkh)
-    t0 = time.perf_counter()
-    spk = g.pk_load_dev(hdr, [{k: (v[0].ptr, v[1]) for k, v in arrs.items()}])
-    out["pk_load_sharded_s"] = time.perf_counter() - t0
-    got = {}
-    lead_abc = (ptr(da), ptr(db), ptr(dc)) if rank == 0 else (None, None, None)
-    for mode in (0, 1):
-        pr, _ = g.prove_dev(spk, [Wd.ptr], nb_wires, *lead_abc, n_constraints, rs[0], rs[1], mode=mode)   # warm-up: sizes the workspaces, lines the ranks up
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            pr, st = g.prove_dev(spk, [Wd.ptr], nb_wires, *lead_abc, n_constraints, rs[0], rs[1], mode=mode)
-        got[mode] = (B.proof_write(pr["raw"]), time.perf_counter() - t0, st)
-    if over_ranks:   # the same proof with computeH over the ranks: this rank's rows of a and b, c formed on the devices
-        M = N // world
-        row0 = min(rank * M, n_constraints)
-        for mode in (0, 1):
-            args = (spk, [Wd.ptr], nb_wires, [da.ptr + 32 * row0], [db.ptr + 32 * row0], None, n_constraints, rs[0], rs[1])
-            pr, _ = g.prove_slices_dev(*args, mode=mode)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                pr, st = g.prove_slices_dev(*args, mode=mode)
-            got[2 + mode] = (B.proof_write(pr["raw"]), time.perf_counter() - t0, st)
-        out.update({"compute_h_over_ranks": True, "dt2": got[2][1], "dt3": got[3][1], "over_ranks_agree": got[2][0] == got[0][0] and got[3][0] == got[0][0]})
-        if not out["over_ranks_agree"]:
-            raise RuntimeError("the proof with computeH over the ranks differs from the proof with computeH on the lead")
-    g.pk_free(spk)
-    for d in [v[0] for v in arrs.values()] + [Wd, da, db, dc]:
-        if d is not None:
-            d.free()
-    out.update({"log_n": log_n, "steps": steps, "dt0": got[0][1], "dt1": got[1][1], "modes_agree": got[0][0] == got[1][0],
-                "equals_unsharded": None if unsharded is None else bool(got[0][0] == unsharded),
-                "compute_h_ms_on_rank0": got[0][2]["compute_h_ms"] if rank == 0 else None})
-    if not out["modes_agree"] or out["equals_unsharded"] is False:
-        raise RuntimeError("sharded proofs disagree (mode 0 vs mode 1, or sharded vs unsharded)")
-    return out
-
-
-def sharded_helper_main():
-    """`bench.py --sharded-helper`: started by main() BEFORE the parent touches the GPU (a process that has initialised the GPU must not
-    exec), idle until the parent writes one JSON line of parameters, then runs the multi-GPU legs on its own GPU context -- the
-    transport self-test first (a broken communicator is diagnosed, not timed out), the point-sharded MSM, the point-sharded PROVE --
-    and answers with one JSON line.  A fault or a stuck collective in these paths then costs the parent nothing but the `sharded_*`
-    blocks of its line."""
-    req = sys.stdin.readline()
-    if not req.strip():
-        return
-    q = json.loads(req)
-    if os.environ.get("MI_BENCH_HELPER_FAULT") == "abort":   # rehearsal of the failure this process exists for
-        os.abort()
-    if os.environ.get("MI_BENCH_HELPER_FAULT") == "hang":
-        time.sleep(10000)
-    res = {"ok": False, "selftest": "not run"}
-    g = None
-    try:
-        B = _binding()
-        g = B.Group.rank(q["local_rank"], q["rank"], q["world"], bytes.fromhex(q["uid"]), transport=q.get("transport", 1))
-        try:
-            g.exchange_selftest(1 << 20)
-            res["selftest"] = "ok"
-        except BaseException as e:
-            res["selftest"] = f"FAILED: {e}"
-            raise
-        res["transport"] = g.transport()
-        if q["log_n"]:
-            res["msm"] = sharded_msm_section(B, g, q["rank"], q["world"], q["log_n"], q["steps"])
-        res["ok"] = True   # the MSM block is valid from here on, whatever the prove leg does
-        if q.get("prove_log_n"):
-            try:
-                res["prove"] = sharded_prove_section(B, g, q["rank"], q["world"], q["prove_log_n"], q["prove_steps"])
-                res["prove"]["ok"] = True
-            except BaseException as e:
-                res["prove"] = {"ok": False, "error": f"{type(e).__name__}: {e}"}
-    except BaseException as e:
-        res["error"] = f"{type(e).__name__}: {e}"
-    finally:
-        if g is not None:
-            g.close()
-    print(json.dumps(res), flush=True)
-
-
-def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
-    """configs[4] through the C-ABI's device group, in the helper process started at the top of main(): the transport self-test, one G1
-    MSM point-sharded over the ranks, and ONE PROOF point-sharded over the ranks.  Transport: RCCL with one rank per GPU; the
-    host-staged one (shared memory) with --rehearse-on-one-gpu, where every rank sits on device 0 and RCCL would refuse.  Bounded by a
-    watchdog: a stuck collective or a fault there must not cost the run its proofs/s line.  Called after this process has released its
-    own pool, key and buffers (an N = 2^26 proof wants most of a GPU)."""
-    import threading
-    sharded, sharded_prove = {"done": False}, {"done": False}
-    transport = 3 if args.rehearse_on_one_gpu else 1
-    dev = "cpu" if args.rehearse_on_one_gpu else torch.device("cuda", local_rank)
-    uid = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        uid = torch.tensor(list(os.urandom(128) if transport == 3 else B.Group.unique_id()), dtype=torch.uint8)
-    if dist is not None:
-        t = uid.to(dev); dist.broadcast(t, src=0); uid = t.cpu()
-        dist.barrier()
-    steps_msm, steps_prove = 3, 3
-    answer = {}
-
-    def ask():
-        try:
-            helper.stdin.write(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "uid": bytes(uid.tolist()).hex(), "transport": transport,
-                                           "log_n": args.sharded_msm_log_n, "steps": steps_msm,
-                                           "prove_log_n": args.sharded_prove_log_n, "prove_steps": steps_prove}) + "\n")
-            helper.stdin.flush()
-            while True:   # the answer is the first line that is a JSON object (anything a library prints before it is skipped)
-                ln = helper.stdout.readline()
-                if not ln or ln.lstrip().startswith("{"):
-                    break
-            answer["line"] = ln
-        except BaseException as e:
-            answer["line"] = json.dumps({"ok": False, "error": f"{type(e).__name__}: {e}"})
-    th = threading.Thread(target=ask, daemon=True)
-    th.start()
-    watchdog_s = 360
-    th.join(timeout=watchdog_s)
-    res = {"ok": False, "error": f"timeout after {watchdog_s} s (collective stuck?)"}
-    if th.is_alive():
-        helper.kill()
-    else:
-        try:
-            res = json.loads(answer.get("line") or "") if (answer.get("line") or "").strip() else {"ok": False, "error": "helper ended without an answer"}
-        except ValueError:
-            res = {"ok": False, "error": "helper answered garbage"}
-    m, pv = res.get("msm") or {}, res.get("prove") or {}
-    ok = 1.0 if res.get("ok") and m else 0.0
-    okp = 1.0 if pv.get("ok") else 0.0
-    v = [ok, float(m.get("dt0", 0.0)), float(m.get("dt1", 0.0)), 1.0 if m.get("modes_agree") else 0.0]
-    w = [okp, float(pv.get("dt0", 0.0)), float(pv.get("dt1", 0.0)), float(pv.get("dt2", 0.0)), float(pv.get("dt3", 0.0))]
-    if dist is not None:   # every rank takes part, whatever its helper did: all ok?  slowest rank's times; all agree?
-        tmin = torch.tensor([v[0], v[3], w[0]], device=dev, dtype=torch.float64); dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        tmax = torch.tensor([v[1], v[2], w[1], w[2], w[3], w[4]], device=dev, dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        v = [float(tmin[0]), float(tmax[0]), float(tmax[1]), float(tmin[1])]
-        w = [float(tmin[2]), float(tmax[2]), float(tmax[3]), float(tmax[4]), float(tmax[5])]
-    n_msm = 1 << args.sharded_msm_log_n
-    sharded["selftest"] = sharded_prove["selftest"] = res.get("selftest", "not run")
-    devices = "ONE device shared by all ranks (rehearsal: the multi-process code path, not a scaling measurement)" if args.rehearse_on_one_gpu else f"{world} device(s)"
-    if v[0] == 1.0 and v[1] > 0 and v[2] > 0:
-        sharded.update({"workload": f"one G1 MSM, 2^{args.sharded_msm_log_n} uniform pairs, bases point-sharded over {world} rank(s) (BASELINE configs[4])",
-                        "scaling": "strong", "transport": res.get("transport"), "devices": devices, "steps": steps_msm, "process": "helper process per rank (own GPU context)",
-                        "mode0_partial_sums_pts_per_s": n_msm * steps_msm / v[1], "mode0_ms": v[1] / steps_msm * 1e3,
-                        "mode1_bucket_exchange_pts_per_s": n_msm * steps_msm / v[2], "mode1_ms": v[2] / steps_msm * 1e3,
-                        "modes_agree": v[3] == 1.0, "done": True})
-    elif not args.sharded_msm_log_n:
-        sharded["skipped"] = "--sharded-msm-log-n 0"
-    else:
-        sharded["error"] = res.get("error", "a rank's helper failed")
-    if w[0] == 1.0 and w[1] > 0 and w[2] > 0:
-        sharded_prove.update({"workload": f"ONE Groth16 proof, FFT domain N=2^{args.sharded_prove_log_n}, WHIR-verifier-shaped synthetic key point-sharded over {world} rank(s): "
-                                          "slice r of pk.G1.{A,B,K,Z} / pk.G2.B resident on rank r, computeH on rank 0, h slices over the group's transport (BASELINE configs[4])",
-                              "scaling": "strong", "transport": res.get("transport"), "devices": devices, "steps": steps_prove, "inputs": "resident in HBM (mi_groth16_prove_sharded_dev)",
-                              "mode0_partial_sums_ms_per_proof": w[1] / steps_prove * 1e3, "mode0_proofs_per_s": steps_prove / w[1],
-                              "mode1_bucket_exchange_ms_per_proof": w[2] / steps_prove * 1e3, "mode1_proofs_per_s": steps_prove / w[2],
-                              "compute_h_over_ranks": None if not (w[3] > 0 and w[4] > 0) else {
-                                  "what": "the same proof through mi_groth16_prove_sharded_slices_dev: computeH as local size-N/ranks transforms + cross-rank steps between all-to-alls, every rank's h slice born where its Z pairs live (DESIGN.md 6)",
-                                  "mode0_ms_per_proof": w[3] / steps_prove * 1e3, "mode1_ms_per_proof": w[4] / steps_prove * 1e3, "bytes_equal_the_lead_computeH_proof": pv.get("over_ranks_agree")},
-                              "modes_agree": pv.get("modes_agree"), "equals_unsharded_prove": pv.get("equals_unsharded"),
-                              "small_parity": pv.get("small_parity"), "compute_h_ms_on_rank0": pv.get("compute_h_ms_on_rank0"),
-                              "pk_load_sharded_s": pv.get("pk_load_sharded_s"),
-                              "note": "NO SCALING CURVE EXISTS until this runs with n_gpus > 1 on distinct devices: with n_gpus = 1 this is the same code path over a world-1 RCCL "
-                                      "communicator; the one-rank-per-process flow with world 2 and 3 is parity-tested on one GPU over the host-staged transport (tests/test_gpu_group_multiprocess.py)",
-                              "done": True})
-    elif not args.sharded_prove_log_n:
-        sharded_prove["skipped"] = "--sharded-prove-log-n 0"
-    else:
-        sharded_prove["error"] = pv.get("error") or res.get("error", "a rank's helper failed")
-    try:
-        helper.stdin.close(); helper.wait(timeout=10)
-    except BaseException:
-        helper.kill()
-    return sharded, sharded_prove
-
-
-def bind_to_gpu_numa_node(torch, local_rank):
-    """One rank per GPU on a multi-socket node: keep this rank's threads -- and, by first touch, the host buffers it is about to allocate,
-    which the uploader reads at ~25 GB/s per rank -- on the NUMA node the GPU hangs off.  Best effort (sysfs may say -1 or be unreadable;
-    the box may confine the process to other cores): returns a short description for the line, or None when nothing was changed."""
-    try:
-        pr = torch.cuda.get_device_properties(local_rank)
-        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
-        if node < 0:
-            return None
-        cpus = set()
-        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
-            lo, _, hi = part.partition("-")
-            cpus.update(range(int(lo), int(hi or lo) + 1))
-        allowed = os.sched_getaffinity(0)
-        pick = cpus & allowed
-        if len(pick) < 8:   # too few of that node's cores are ours: leave the affinity alone
-            return None
-        os.sched_setaffinity(0, pick)
-        return f"GPU {bdf} on NUMA node {node}: {len(pick)} cores"
-    except Exception:
-        return None
-
-
-def self_launch(n, argv):
-    """`python bench.py --gpus N` without a launcher: start the N rank processes as CHILDREN of this process -- which has not touched
-    the GPU and never will -- with the environment torch.distributed.run would give them, relay rank 0's JSON line, and exit with the
-    worst child status.  (A re-exec of this process would do as well here, but the rule is: children, before any GPU call.)"""
-    import socket
-    import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    line = None
-    for ln in procs[0].stdout:   # rank 0 prints the line; anything else it writes to stdout goes to stderr here
-        if ln.lstrip().startswith("{"):
-            line = ln.rstrip("\n")
-        else:
-            sys.stderr.write(ln)
-    rcs = [p.wait() for p in procs]
-    if line is not None:
-        print(line, flush=True)
-    bad = [rc for rc in rcs if rc != 0]
-    if bad or line is None:
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
-        sys.exit(bad[0] if bad else 1)
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)   # ~1 s of proofs: one rare runtime hiccup then moves the result by < 2 %
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=23, help="FFT domain (2^23 = BASELINE configs[1])")
-    ap.add_argument("--dist", choices=["whir", "half", "uniform"], default="whir",
-                    help="witness (W, a) distribution: the WHIR mix of SURVEY 8d (a documented guess), uniform Fr, or half of each (row by row)")
+    ap.add_argument("--dist", choices=["whir", "half", "uniform", "census"], default="whir",
+                    help="witness (W, a) distribution: the WHIR mix of SURVEY 8d / BASELINE.md 3 (a documented guess), uniform Fr, half of each (row by row), or "
+                         "`census`: the midpoint mix tools/wire_census.py derives from the reference's circuit (profiles/r06_wire_census.txt)")
     ap.add_argument("--no-solo-legs", action="store_true", help="skip the solo MSM / computeH / probe legs after the proofs (PMC passes: their launches would mix into the per-kernel averages); the roofline line then falls back to the in-job launch")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the `sensitivity` legs (the same key proved with a half-uniform and a uniform witness)")
     ap.add_argument("--stream-plan", type=int, default=-1, help="tuning: mi_debug_set_stream_plan before the pool is created (0, 1, 2; -1 = the library's default)")
@@ -628,7 +195,6 @@ def main():
         committed_wires = np.concatenate([committed_private, np.array([nb_wires - 1], dtype=np.uint32)])   # the last wire plays CommitmentIndex
     na, nb = int((inf_a == 0).sum()), int((inf_b == 0).sum())
     nk = nb_wires - nb_public - (n_committed + 1 if n_committed else 0)
-    dist_id = 0 if args.dist == "uniform" else 1
     g1a, g1b, g1k, g1z = ctx.gen_g1(na, seed + 1), ctx.gen_g1(nb, seed + 2), ctx.gen_g1(nk, seed + 3), ctx.gen_g1(N, seed + 4)
     g2b = ctx.gen_g2(nb, seed + 5)
     small = ctx.gen_g1(3, seed + 6).download((3, 8)); small2 = ctx.gen_g2(2, seed + 7).download((2, 16))
@@ -654,7 +220,7 @@ def main():
             d.free()
     def gen_witness(dist):
         """W, a (the distribution under test), b (uniform), c = a o b on the device; 'half': every other row of W and a by a seeded coin uniform"""
-        did = 0 if dist == "uniform" else 1
+        did = dist_id_of(B, "whir" if dist == "half" else dist)
         W_ = ctx.gen_scalars(nb_wires, seed + 8, did); a_ = ctx.gen_scalars(n_constraints, seed + 9, did)
         if dist == "half":
             for arr, cnt, sd in ((W_, nb_wires, 8), (a_, n_constraints, 9)):
@@ -844,8 +410,13 @@ def main():
     sensitivity = None
     if rank == 0 and world == 1 and not args.no_sensitivity and args.dist == "whir":
         sensitivity = {"what": "the same key and step with other witness distributions (rows of W and a): `whir` = the headline's 45 % {0,1} / 25 % bytes / 5 % 64-bit / 25 % "
-                               "uniform mix, `half_uniform` = every row uniform with probability 1/2, `uniform` = every row uniform (the floor)",
-                       "half_uniform": sensitivity_leg("half"), "uniform": sensitivity_leg("uniform")}
+                               "uniform mix, `half_uniform` = every row uniform with probability 1/2, `uniform` = every row uniform (the floor), `census` = the mix the reference's circuit implies",
+                       "half_uniform": sensitivity_leg("half"), "uniform": sensitivity_leg("uniform"), "census": sensitivity_leg("census")}
+        import wire_census   # (tools/ is on the path: pure Python, restated counting rules, no reference file is read)
+        pm = wire_census.census_mix_permille()
+        sensitivity["census"]["mix"] = (f"{pm[0] / 10:.1f} % {{0,1}} / {pm[1] / 10:.1f} % bytes / {pm[2] / 10:.1f} % 64-bit / {(1000 - sum(pm)) / 10:.1f} % full-width: the midpoint of the range "
+                                        "tools/wire_census.py derives from the reference's circuit for configs[1] (profiles/r06_wire_census.txt: eq tables and matrix MLE, "
+                                        "mtUtilities.go:494-532, are all full-width; Merkle / STIR terms are bytes and full-width in comparable numbers; bits 1-3 %)")
     ex.shutdown()
 
     # HBM ledger of the PROVE path, taken right after the timed regions: key + tables, every context's workspaces, the pool's input sets,
@@ -1118,6 +689,8 @@ def main():
             "g1_msm_solo": solo, "g1_msm_z_shaped_solo": zsolo,
             # the headline's sensitivity to the witness distribution, and the floor next to the headline
             "sensitivity": sensitivity, "value_uniform_witness": None if not sensitivity else sensitivity["uniform"]["value"],
+            # the same step on the witness mix the reference's circuit implies (tools/wire_census.py): the number to hold beside `value`
+            "value_census_mix": None if not sensitivity else sensitivity["census"]["value"],
             # the level-1 accumulate gathers one 64-B point per mixed addition from tables of 7..16 GB: measured ceiling of the memory
             # system for that access pattern, the kernel's own gather rate alone on the GPU, and the job's aggregate rate
             "random_gather": {"ceiling_gathers_per_s": 256 * 4 * 64 * 4 * 128 / (gather_ms * 1e-3), "ceiling_GBps_useful": 256 * 4 * 64 * 4 * 128 * 64 / (gather_ms * 1e-3) / 1e9,

@@ -25,7 +25,7 @@ EXPORTS = [
     "mi_batch_scalar_mul_g1", "mi_batch_scalar_mul_g1_dev", "mi_batch_scalar_mul_g2", "mi_batch_scalar_mul_g2_dev",
     "mi_pedersen_pk_load", "mi_pedersen_pk_free", "mi_pedersen_commit", "mi_pedersen_prove_knowledge", "mi_pedersen_fold",
     "mi_debug_set_prove_fixed_base", "mi_debug_set_prove_schedule", "mi_debug_set_msm_batch_affine", "mi_debug_set_msm_group_bits", "mi_debug_inject_hip_failure", "mi_debug_set_ntt_plan", "mi_debug_set_ntt_threads", "mi_debug_set_ntt_wave_stages",
-    "mi_debug_set_msm_plan", "mi_debug_set_msm_chunk", "mi_debug_set_msm_one_pass_sort", "mi_debug_set_msm_bound_levels", "mi_debug_set_msm_limb29", "mi_debug_set_msm_l1_waves", "mi_debug_set_msm_precompute_batched", "mi_debug_set_ntt_fuse_pair", "mi_debug_set_knob", "mi_debug_get_counter", "mi_debug_set_stream_plan", "mi_debug_set_trace_ranges",
+    "mi_debug_set_msm_plan", "mi_debug_set_msm_chunk", "mi_debug_set_msm_one_pass_sort", "mi_debug_set_msm_bound_levels", "mi_debug_set_msm_limb29", "mi_debug_set_msm_l1_waves", "mi_debug_set_msm_precompute_batched", "mi_debug_set_ntt_fuse_pair", "mi_debug_set_knob", "mi_debug_get_counter", "mi_debug_set_stream_plan", "mi_debug_set_trace_ranges", "mi_set_trace_ranges",
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
     "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22", "mi_prover_trim", "mi_ctx_trim",
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_create_rank_ex", "mi_group_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
@@ -103,6 +103,15 @@ def load():
         _LIB.mi_group_ctx.restype = C.c_void_p
         _LIB.mi_group_last_error.restype = C.c_char_p
     return _LIB
+
+
+DIST_UNIFORM, DIST_WHIR = 0, 1
+
+
+def dist_mix(bit_pm, byte_pm, u64_pm=0):
+    """MI_DIST_MIX(bit, byte, u64) of include/mi355x_groth16_debug.h: per-mille shares of {0,1} / bytes / 64-bit scalars, the rest uniform Fr"""
+    assert 0 <= bit_pm and 0 <= byte_pm and 0 <= u64_pm and bit_pm + byte_pm + u64_pm <= 1000
+    return 0x40000000 | (bit_pm << 20) | (byte_pm << 10) | u64_pm
 
 
 def _p(a):

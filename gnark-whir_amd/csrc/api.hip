@@ -38,11 +38,12 @@ int32_t mi_copy_stream(mi_ctx *ctx, hipStream_t *out) {
 
 extern "C" {
 
-int32_t mi_debug_set_trace_ranges(int32_t on) {
+int32_t mi_set_trace_ranges(int32_t on) {
     if (on && !ranges_load()) return MI_ENODEV;   // no roctx library on this machine
     mi_ranges_on.store(on ? 1 : 0);
     return MI_OK;
 }
+int32_t mi_debug_set_trace_ranges(int32_t on) { return mi_set_trace_ranges(on); }
 int32_t mi_debug_inject_hip_failure(int32_t nth) { mi_fault_countdown.store(nth > 0 ? nth : 0); return MI_OK; }
 int32_t mi_init(int device_id, mi_ctx **out) { return mi_init_prio(device_id, MI_PRIO_SOLO, out); }
 int32_t mi_init_prio(int device_id, int prio_scheme, mi_ctx **out) {

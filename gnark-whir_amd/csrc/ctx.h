@@ -7,6 +7,9 @@
 #include <vector>
 #include <cstdio>
 #include "../../include/mi355x_groth16.h"
+#include "../../include/mi355x_groth16_group.h"
+#include "../../include/mi355x_whir_ingest.h"
+#include "../../include/mi355x_groth16_debug.h"
 
 struct DevBuf {             // growable device scratch owned by the ctx (no hipMalloc in the hot path
     void *p = nullptr;      // after warm-up: buffers only ever grow)

@@ -37,12 +37,15 @@ __global__ void k_gen_scalars(Fr *out, size_t n, u64 seed, int dist) {
     Fr z;
     if (dist == MI_DIST_UNIFORM) z = rnd_fe<FrParams>(seed, i);
     else {
-        u64 u = rnd(seed, i, 4) % 100;
+        // MI_DIST_WHIR: per cent 45 / 25 / 5; MI_DIST_MIX(bit, byte, u64): the caller's per-mille thresholds; the rest uniform
+        const bool mix = (dist & MI_DIST_MIX_FLAG) != 0;
+        const u64 t0 = mix ? (u64)((dist >> 20) & 1023) : 45, t1 = t0 + (mix ? (u64)((dist >> 10) & 1023) : 25), t2 = t1 + (mix ? (u64)(dist & 1023) : 5);
+        u64 u = rnd(seed, i, 4) % (mix ? 1000 : 100);
         z = Fr::zero();
         u64 v = rnd(seed, i, 5);
-        if (u < 45) z.l[0] = (u32)(v & 1);
-        else if (u < 70) z.l[0] = (u32)(v & 255);
-        else if (u < 75) { z.l[0] = (u32)v; z.l[1] = (u32)(v >> 32); }
+        if (u < t0) z.l[0] = (u32)(v & 1);
+        else if (u < t1) z.l[0] = (u32)(v & 255);
+        else if (u < t2) { z.l[0] = (u32)v; z.l[1] = (u32)(v >> 32); }
         else z = rnd_fe<FrParams>(seed, i);
     }
     out[i] = fe_to_mont(z);

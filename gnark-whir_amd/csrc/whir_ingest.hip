@@ -15,7 +15,7 @@
 // ark-serialize rules (u64 / usize = 8 bytes little-endian; Vec<T> = u64 length + elements; [u8; 32] = 32 raw bytes; Fp256 = 4 x u64
 // limbs, limb 0 first, canonical value; structs = fields in declaration order).  oracle/whir_ingest.py is the Python restatement the
 // tests compare with; nothing reference-held pins either (no ProveKit artefact in the container): parity unpinned.
-#include "../../include/mi355x_groth16.h"
+#include "../../include/mi355x_whir_ingest.h"
 #include <cstdlib>
 #include <cstring>
 #include <new>

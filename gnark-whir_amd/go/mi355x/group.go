@@ -9,6 +9,7 @@ package mi355x
 
 /*
 #include "mi355x_groth16.h"
+#include "mi355x_groth16_group.h"
 */
 import "C"
 

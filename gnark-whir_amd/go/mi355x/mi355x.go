@@ -363,14 +363,14 @@ func (pk *ProvingKey) batchProve(values [][]fr.Element, challenge fr.Element) (b
 	return out, nil
 }
 
-// TraceRanges switches the library's roctx ranges on or off (mi_debug_set_trace_ranges): the host-side phases of every call show up in
+// TraceRanges switches the library's roctx ranges on or off (mi_set_trace_ranges): the host-side phases of every call show up in
 // `rocprofv3 --marker-trace --kernel-trace` beside the kernels.  Process-wide; an error when no roctx library can be loaded.
 func TraceRanges(on bool) error {
 	v := C.int32_t(0)
 	if on {
 		v = 1
 	}
-	if rc := C.mi_debug_set_trace_ranges(v); rc != C.MI_OK {
+	if rc := C.mi_set_trace_ranges(v); rc != C.MI_OK {
 		return fmt.Errorf("mi355x: trace ranges: rc=%d (no roctx library?)", int(rc))
 	}
 	return nil

@@ -18,6 +18,8 @@
 #include <string>
 #include <vector>
 #include "../../include/mi355x_groth16.h"
+#include "../../include/mi355x_groth16_group.h"
+#include "../../include/mi355x_groth16_debug.h"   // (this mirror is the TEST side: generators and knobs)
 
 namespace groth16 {
 

@@ -24,6 +24,12 @@
  *     (cgo rule).  mi_ctx / mi_pk are opaque library-owned handles.
  *   - one mi_ctx drives one GPU.  Calls on one ctx must not overlap (no internal locking); inside a call the library
  *     fans work out over its own HIP streams and joins them before returning.
+ *
+ * Companion headers (same library, same conventions; each includes this one):
+ *   mi355x_groth16_group.h   one proof / one MSM point-sharded over several GPUs
+ *   mi355x_whir_ingest.h     host-only decoding of ProveKit's artefacts
+ *   mi355x_groth16_debug.h   generators, probes, plan knobs, fault injection: tests, bench and tuning ONLY -- a service that binds
+ *                            the prove path never includes it
  */
 #ifndef MI355X_GROTH16_H
 #define MI355X_GROTH16_H
@@ -277,125 +283,6 @@ int32_t mi_prover_submit_bsb22(mi_prover *p, mi_pk *pk, const mi_fr *W, size_t n
                                const mi_fr *r, const mi_fr *s, const mi_bsb22_input *commitments, uint32_t n_commitments,
                                const mi_fr *challenge, mi_proof_out *out, mi_g1_affine *pok_out, mi_stats *stats, uint64_t *ticket);
 
-/* ---- device groups: one proof / one MSM point-sharded over several GPUs (BASELINE configs[4]).
- * The reference's single call groth16.Prove (mt.go:496) knows no devices; a Go caller that wants one proof spread over the
- * 8 MI355X of a node binds these.  pk points are static, so mi_pk_load_sharded cuts the wires
- * (and the N - 1 pairs of the Z MSM) into `world` contiguous ranges and keeps slice r of pk.G1.{A,B,K,Z} / pk.G2.B resident
- * on rank r; per proof only scalars move (W slices from the host, h slices device to device from the lead rank, which runs
- * computeH: NTT = replicas only).  EC addition is not an RCCL reduce op, so the exchange is byte-typed:
- *   mode 0  every rank finishes Pippenger locally; one partial sum per MSM is combined (host additions in one process,
- *           ncclAllGather(ncclUint8) with one rank per process);
- *   mode 1  "all-reduce of partial bucket sums": every rank stops at its bucket sums, rank r receives the keys it owns from
- *           every other rank (reduce-scatter as grouped ncclSend / ncclRecv, one hop on the xGMI mesh), adds them, reduces
- *           its slice; the per-rank results are combined as in mode 0.
- * Results are bit-identical to the unsharded entry points.  A group serves ONE call at a time: an entry point called while another
- * call on the same group is still running returns MI_EINVAL at once and touches nothing (the exchange streams and receive
- * buffers belong to the running call).  A process holds either ALL ranks of a group (mi_group_create) or exactly ONE
- * (mi_group_create_rank); with one rank per process every process makes the same calls in the same order (they are
- * collectives), each with its own rank's data.
- * Failures are collective too: before every exchange the ranks agree on their status (one small all-gather), so a call either succeeds
- * on every rank or returns an error on every rank -- the failing rank its own, the others "rank r failed" -- with every MSM slot
- * drained; nobody is left waiting in an exchange.  Only a failure INSIDE an exchange (a dead peer, an RCCL error) breaks the group:
- * later calls on it return MI_EHIP until it is destroyed and created anew. ---- */
-typedef struct mi_group mi_group;
-typedef struct mi_pk_sharded mi_pk_sharded;
-/* all ranks in this process, one context per entry of dev_ids (SURVEY 8b proposed mi_init(dev_ids, n_dev, ...)).  Distinct
- * devices: RCCL communicator (ncclCommInitAll).  A device named twice (1-GPU rehearsal): same-process peer copies. */
-int32_t mi_group_create(const int *dev_ids, int n_dev, mi_group **out);
-/* one rank per process: id = mi_group_unique_id() from rank 0, handed to the others by the caller's own channel */
-int32_t mi_group_unique_id(uint8_t id[128]);
-int32_t mi_group_create_rank(int device_id, int rank, int world, const uint8_t id[128], mi_group **out);   /* = _ex(..., MI_GROUP_TRANSPORT_RCCL, ...) */
-/* the same with the transport named.  MI_GROUP_TRANSPORT_HOST: the processes meet in a POSIX shared-memory segment named after the 128
- * id bytes (any 128 bytes all ranks share; mi_group_unique_id is not needed) and slices travel device -> segment -> device.  For ranks
- * RCCL cannot connect: two processes on ONE device (RCCL refuses two ranks per device; how a 1-GPU box rehearses this flow) or a box
- * without a working RCCL fabric.
- * THE DEAD-PEER CONTRACT, both transports: with one rank per process no call of this library waits for another rank without a deadline.
- * MI_GROUP_TIMEOUT_MS (environment, read when the group is created; default 60000) bounds the time a rank waits for its peers while
- * NOTHING completes -- joining the group, an exchange, an all-gather.  When it passes (a peer's process ended, a link went down), or
- * when RCCL reports an asynchronous error, the call returns MI_EHIP with a message that says "timeout", the group is broken (every
- * later call on it returns MI_EHIP at once) and must be destroyed; mi_group_destroy itself does not wait for anybody.
- *   RCCL transport: the per-rank communicator is non-blocking (ncclCommInitRankConfig, blocking = 0); joining, every group of sends /
- *     receives and every all-gather is polled with ncclCommGetAsyncError / hipStreamQuery against the deadline, and ncclCommAbort takes
- *     the communicator's kernels off the stream when it passes.  An exchange has completed on every rank that returns from it.
- *   host-staged transport: every wait on the shared segment has the deadline, and a rank that gives up poisons the segment so that the
- *     others stop waiting at once.  MI_GROUP_SHM_CHUNK_KB (default 1024, 4..65536): bytes per ring slot of the segment.
- * (Single-process groups, mi_group_create, have no peers in other processes: their communicators stay blocking.) */
-#define MI_GROUP_TRANSPORT_RCCL 1
-#define MI_GROUP_TRANSPORT_HOST 3
-int32_t mi_group_create_rank_ex(int device_id, int rank, int world, const uint8_t id[128], int transport, mi_group **out);
-int32_t mi_group_destroy(mi_group *g);
-/* The lead's share of the WIRES of a sharded key.  Rank 0 also runs computeH (the NTT does not shard: SURVEY 8e) and no rank can start
- * its Z MSM before h exists, so a lead that carries an equal share of the wire MSMs lengthens the critical path of the proof.
- * permille = the fraction of an even share (nb_wires / world) that rank 0 takes, 0..1000; the other ranks split the rest evenly; the
- * N - 1 pairs of the Z MSM are always cut evenly.  1000 = the even cut.  MI_LEAD_SHARE_AUTO (the default): 1000 for one rank, 500 for
- * two, 0 from three ranks on -- from the measured ratio computeH : wire MSMs = 1 : 2 at N = 2^26.  Set it -- to the same
- * value in every process -- BEFORE mi_pk_load_sharded*: the key's parts are cut by it (a disagreement fails that load on every rank),
- * and a caller that passes device slices (mi_pk_load_sharded_dev, mi_groth16_prove_sharded_dev) cuts its arrays by
- * mi_group_wire_range.  Same proofs whatever the share. */
-#define MI_LEAD_SHARE_AUTO 0xffffffffu
-int32_t mi_group_set_lead_share(mi_group *g, uint32_t permille);
-/* wires [*lo, *hi) of global rank `rank` under the group's current lead share */
-int32_t mi_group_wire_range(const mi_group *g, uint64_t nb_wires, int rank, uint64_t *lo, uint64_t *hi);
-/* computeH OVER the ranks (2, 4, 8 or 16 of them, N >= ranks^2): every transform becomes a local size-N/ranks transform and one
- * cross-rank step between two all-to-alls over the group's transport (9 batches per computeH, each moving (ranks - 1) / ranks of a
- * slice per rank), and the h slices are born on the ranks whose Z pairs they multiply -- instead of rank 0 transforming alone while the
- * others wait for h (the cap of a proof sharded over 8 GPUs moves from ~3x to the MSMs' own 1 / ranks).  Same h, same
- * proof bytes.  on = 1: mi_groth16_prove_sharded (host arrays) then needs a and b (and c, or NULL) in EVERY process, not on rank 0's
- * alone, and takes its rank's rows from them; mi_groth16_prove_sharded_dev is unchanged (its a, b, c live on rank 0's device).
- * The same value in every process.  Default 0. */
-int32_t mi_group_set_sharded_compute_h(mi_group *g, uint32_t on);
-/* computeH alone, as a collective: local rank i passes device pointers to ITS rows of a, b (and c; c_sl == NULL: c = a o b on the
- * device) -- rows [r M, min((r + 1) M, n_constraints)) of global rank r, M = N / ranks -- and receives its M coefficients of h in
- * gnark's bit-reversed order (rank r: positions [r M, (r + 1) M) of what mi_compute_h_dev returns). */
-int32_t mi_compute_h_sharded_dev(mi_group *g, uint32_t log_n, const mi_fr *const *a_sl, const mi_fr *const *b_sl, const mi_fr *const *c_sl,
-                                 size_t n_constraints, mi_fr *const *h_sl);
-int32_t mi_group_world(const mi_group *g);
-int32_t mi_group_local(const mi_group *g);                 /* ranks held by this process */
-mi_ctx *mi_group_ctx(mi_group *g, int local_rank);         /* for mi_dev_* / generators on that rank's device */
-const char *mi_group_last_error(mi_group *g);
-int32_t mi_group_rank(const mi_group *g);                  /* global rank of this process's first local rank */
-int32_t mi_group_transport(const mi_group *g);             /* 1 = RCCL, 2 = copies inside one process, 3 = host-staged (shared memory) */
-/* transport check: every rank sends `bytes` patterned bytes to every rank (itself included) and verifies what it received */
-int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes);
-/* desc: the same whole-key descriptor as mi_pk_load (host arrays); with one rank per process every process passes the whole
- * descriptor and keeps its own rank's slice.  The fixed-base table plan is agreed over the whole group (tightest device). */
-int32_t mi_pk_load_sharded(mi_group *g, const mi_pk_desc *desc, mi_pk_sharded **out);
-/* slice_descs[i], i < mi_group_local(): header (log_n, nb_public, nb_wires) and masks of the WHOLE key in host memory; the five
- * point arrays are DEVICE pointers on local rank i's device to that rank's slices (the points of wires [nb_wires r / world,
- * nb_wires (r+1) / world) and the Z pairs [(N-1) r / world, (N-1)(r+1) / world), r = global rank), counts = points of the slice.
- * Adopted by reference like mi_pk_load_dev (the caller keeps them alive). */
-int32_t mi_pk_load_sharded_dev(mi_group *g, const mi_pk_desc *slice_descs, mi_pk_sharded **out);
-int32_t mi_pk_sharded_free(mi_group *g, mi_pk_sharded *pk);
-/* groth16.Prove after the solve (mt.go:496) over the ranks of the group; arguments as mi_groth16_prove.  W is the WHOLE wire
- * vector: a process reads only the wire ranges of its local ranks.  a, b, c are read by the process that holds rank 0 (which runs
- * computeH and hands every rank its slice of h over the group's transport); other processes may pass NULL.  Every process
- * receives the proof. */
-int32_t mi_groth16_prove_sharded(mi_group *g, mi_pk_sharded *pk, const mi_fr *W, size_t n_wires,
-                                 const mi_fr *a, const mi_fr *b, const mi_fr *c, size_t n_constraints,
-                                 const mi_fr *r, const mi_fr *s, uint32_t mode, mi_proof_out *out, mi_stats *stats_or_null);
-/* the same with the inputs already in HBM: W_dev[i] = the wire range of local rank i on its device (n_wires = the WHOLE count);
- * a_dev, b_dev, c_dev on rank 0's device (NULL in the other processes) */
-int32_t mi_groth16_prove_sharded_dev(mi_group *g, mi_pk_sharded *pk, const mi_fr *const *W_dev, size_t n_wires,
-                                     const mi_fr *a_dev, const mi_fr *b_dev, const mi_fr *c_dev, size_t n_constraints,
-                                     const mi_fr *r, const mi_fr *s, uint32_t mode, mi_proof_out *out, mi_stats *stats_or_null);
-/* the same with a, b, c as ROW SLICES per local rank (rows [r M, min((r + 1) M, n_constraints)) of global rank r on that rank's device,
- * M = N / ranks; c_sl == NULL: c = a o b): computeH runs over the ranks (mi_group_set_sharded_compute_h says what that means; here it
- * is the only way, whatever the group's setting).  2, 4, 8 or 16 ranks, N >= ranks^2. */
-int32_t mi_groth16_prove_sharded_slices_dev(mi_group *g, mi_pk_sharded *pk, const mi_fr *const *W_dev, size_t n_wires,
-                                            const mi_fr *const *a_sl, const mi_fr *const *b_sl, const mi_fr *const *c_sl, size_t n_constraints,
-                                            const mi_fr *r, const mi_fr *s, uint32_t mode, mi_proof_out *out, mi_stats *stats);
-/* one MSM over host arrays cut into contiguous slices (single-process groups) */
-int32_t mi_msm_g1_sharded(mi_group *g, const mi_g1_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags,
-                          uint32_t mode, mi_g1_jac *out);
-int32_t mi_msm_g2_sharded(mi_group *g, const mi_g2_affine *pts, const mi_fr *scalars, size_t n, uint32_t flags,
-                          uint32_t mode, mi_g2_jac *out);
-/* one MSM whose pairs already sit on the ranks' devices: arrays of mi_group_local() device pointers / counts; n_total = pairs
- * over ALL ranks (every rank passes the same value: it fixes the common window width).  Every rank receives the result. */
-int32_t mi_msm_g1_sharded_dev(mi_group *g, const mi_g1_affine *const *pts_dev, const mi_fr *const *scalars_dev,
-                              const size_t *n_local, size_t n_total, uint32_t flags, uint32_t mode, mi_g1_jac *out);
-int32_t mi_msm_g2_sharded_dev(mi_group *g, const mi_g2_affine *const *pts_dev, const mi_fr *const *scalars_dev,
-                              const size_t *n_local, size_t n_total, uint32_t flags, uint32_t mode, mi_g2_jac *out);
-
 /* ---- Proof.WriteTo / point encoding (row a12), pure host code ---- */
 void mi_g1_compress(const mi_g1_affine *p, uint8_t out[32]);
 void mi_g2_compress(const mi_g2_affine *p, uint8_t out[64]);
@@ -427,185 +314,12 @@ int32_t mi_batch_scalar_mul_g1_dev(mi_ctx *ctx, const mi_g1_affine *base, const 
 int32_t mi_batch_scalar_mul_g2(mi_ctx *ctx, const mi_g2_affine *base, const mi_fr *scalars, size_t n, mi_g2_affine *out);
 int32_t mi_batch_scalar_mul_g2_dev(mi_ctx *ctx, const mi_g2_affine *base, const mi_fr *scalars_dev, size_t n, mi_g2_affine *out_dev);
 
-/* ---- ProveKit artefact ingestion: what /root/reference/main.go:92-152 and the top of verify_circuit (mt.go:306-401) do
- * with the files the Rust prover wrote, BEFORE frontend.Compile -- pure host code, no device needed.  Their consumers are gnark's
- * frontend and solver (Go), so a Go caller binds these only to replace go-ark-serialize + the decoding loops; nothing of the prove path
- * depends on them.  The arkworks wire format is restated from the published ark-serialize rules (go-ark-serialize, go.mod:10, is absent
- * from the reference tree): parity unpinned until a real ProveKit `proof` file is decoded.
- *   mi_whir_proof_decode        go_ark_serialize.CanonicalDeserializeWithMode(proofFile, &proof, false, false), main.go:101, into
- *                               ProofObject (main.go:35-39: round0_merkle_paths, merkle_paths, statement_values_at_random_point)
- *   mi_whir_element_shape       leaves proved, tree height (= len(AuthPathsSuffixes[0]), mt.go:243), leaf values of one ProofElement
- *   mi_whir_parse_paths         ParsePathsObject, mt.go:229-304, for one ProofElement: auth_paths[j][z] = node z (leaf end first) of
- *                               leaf j's authentication path after PrefixDecodePath + Reverse; leaves reduced mod r (LimbsToBigIntMod)
- *   mi_whir_reverse             utilities.Reverse, utilities/utilities.go:58-65 (out must not alias in)
- *   mi_whir_prefix_decode_path  utilities.PrefixDecodePath, utilities/utilities.go:67-78 (MI_EINVAL where Go would panic: prefix_len > n_prev)
- *   mi_whir_limbs_to_fr         typeConverters.LimbsToBigIntMod, typeConverters/typeConverters.go:26-44: 4 x u64 little-endian limbs
- *                               -> the canonical value mod r, same limb order (NOT Montgomery: multiply by R for an mi_fr)
- *   mi_whir_interner_decode     Interner{Values []Fp256}, main.go:74-76,146
- *   mi_whir_matrix_cells        the CSR -> MatrixCell loops of mt.go:358-401 (row i owns entries [row_indices[i], row_indices[i+1] - 1],
- *                               the last row runs to the end; value = LimbsToBigIntMod(interner[values[j]]))
- *   mi_whir_config_parse        json.Unmarshal into Config, main.go:41-58,115: unknown keys ignored, missing keys zero, null leaves a field as
- *                               it is (a top-level null too), keys match ASCII-case-insensitively, the last duplicate wins; strict literals,
- *                               numbers (no leading zeros; an int refuses fractions, exponents, values outside int64) and string escapes
- *                               (an unpaired \uD800-\uDFFF escape becomes U+FFFD); nothing but white space may follow the object; nesting
- *                               deeper than 10000 is refused.  `transcript` as a JSON array of numbers or a padded base64 string (\r, \n
- *                               skipped); decimal strings -> 4 x u64 limbs.  Refused although Go would accept: more than
- *                               MI_WHIR_MAX_ROUNDS list entries, a decimal string that is empty / not a number / >= 2^256 (Go keeps the string
- *                               and fails later, mt.go:310,352).  Copied as they are although Go substitutes U+FFFD: invalid UTF-8 bytes
- *                               inside a string.
- * These readers take bytes an outside party wrote: they run under AddressSanitizer / UBSan with a mutation driver on every CPU test run
- * (gnark-whir_amd/Makefile `sanitize`, tests/test_parsers_sanitized.py), together with mi_pk_raw_inspect. ---- */
-typedef struct mi_whir_proof mi_whir_proof;
-typedef struct mi_whir_shape { uint64_t n_leaves, tree_height, total_leaf_values; } mi_whir_shape;
-int32_t mi_whir_proof_decode(const uint8_t *buf, size_t len, mi_whir_proof **out, size_t *consumed_or_null);
-void mi_whir_proof_free(mi_whir_proof *p);
-uint64_t mi_whir_proof_elements(const mi_whir_proof *p, int which /* 0 = round0_merkle_paths, 1 = merkle_paths */);
-uint64_t mi_whir_proof_statement_values(const mi_whir_proof *p, uint64_t *limbs_out /* count x 4 raw limbs, may be NULL */);
-int32_t mi_whir_element_shape(const mi_whir_proof *p, int which, uint64_t i, mi_whir_shape *out);
-int32_t mi_whir_parse_paths(const mi_whir_proof *p, int which, uint64_t i, uint8_t *auth_paths /* n_leaves x tree_height x 32 */,
-                            uint8_t *leaf_sibling_hashes /* n_leaves x 32 */, uint64_t *leaf_indexes /* n_leaves */,
-                            uint64_t *leaf_lengths /* n_leaves */, uint64_t *leaves /* total_leaf_values x 4 */);   /* any output may be NULL */
-int32_t mi_whir_reverse(const void *in, size_t n, size_t elem_bytes, void *out);
-int32_t mi_whir_prefix_decode_path(const void *prev, size_t n_prev, uint64_t prefix_len, const void *suffix, size_t n_suffix,
-                                   size_t elem_bytes, void *out /* (prefix_len + n_suffix) elements */, size_t *n_out);
-void mi_whir_limbs_to_fr(const uint64_t limbs[4], uint64_t out[4]);
-int32_t mi_whir_interner_decode(const uint8_t *buf, size_t len, uint64_t *limbs_out /* count x 4, may be NULL */, uint64_t *n_out, size_t *consumed_or_null);
-int32_t mi_whir_matrix_cells(const uint64_t *row_indices, size_t n_rows, const uint64_t *col_indices, const uint64_t *values, size_t nnz,
-                             const uint64_t *interner_limbs, size_t n_interner, uint64_t *rows_out, uint64_t *cols_out, uint64_t *values_out /* nnz x 4 */);
-#define MI_WHIR_MAX_ROUNDS 64
-typedef struct mi_whir_config {   /* Config, main.go:41-58; pointers are owned by the config (mi_whir_config_free) */
-    int64_t log_num_constraints, n_rounds, n_vars, final_queries, final_pow_bits, final_folding_pow_bits, rate, transcript_len;
-    int64_t folding_factor[MI_WHIR_MAX_ROUNDS], ood_samples[MI_WHIR_MAX_ROUNDS], num_queries[MI_WHIR_MAX_ROUNDS], pow_bits[MI_WHIR_MAX_ROUNDS];
-    uint32_t n_folding_factor, n_ood_samples, n_num_queries, n_pow_bits;
-    uint64_t domain_generator[4];              /* the decimal string as an integer (mt.go:310), little-endian limbs */
-    const char *io_pattern; size_t io_pattern_len;
-    const uint8_t *transcript; size_t n_transcript;
-    const uint64_t *statement_evaluations; size_t n_statement_evaluations;   /* decimal strings (mt.go:352) -> 4 limbs each */
-    void *store;
-} mi_whir_config;
-int32_t mi_whir_config_parse(const char *json, size_t len, mi_whir_config **out);
-void mi_whir_config_free(mi_whir_config *c);
-
-/* ---- partial-sum combine for the point-sharded MSM (SURVEY section 8e option i): adds n
- * Jacobian partial results (e.g. all-gathered from the ranks), host side ---- */
-int32_t mi_g1_sum(const mi_g1_jac *parts, size_t n, mi_g1_jac *out);
-int32_t mi_g2_sum(const mi_g2_jac *parts, size_t n, mi_g2_jac *out);
-
-/* ---- device-side test / bench utilities (not part of the reference surface) ---- */
-#define MI_DIST_UNIFORM 0
-#define MI_DIST_WHIR 1      /* 45% {0,1}, 25% bytes, 5% 64-bit, 25% uniform */
-int32_t mi_gen_scalars_dev(mi_ctx *ctx, mi_fr *out_dev, size_t n, uint64_t seed, int dist);
-int32_t mi_gen_g1_dev(mi_ctx *ctx, mi_g1_affine *out_dev, size_t n, uint64_t seed);
-int32_t mi_gen_g2_dev(mi_ctx *ctx, mi_g2_affine *out_dev, size_t n, uint64_t seed);
-/* elementwise field ops for parity tests of the device field layer:
- * field: 0 = Fr, 1 = Fp; op: 0 add, 1 sub, 2 mul, 3 inv(x), 4 to_mont(x), 5 from_mont(x),
- * 6 (xy + yx)/R and 7 (xy - yy)/R through the dual-product multiplier, 8 x^2 */
-int32_t mi_field_op_dev(mi_ctx *ctx, int field, int op, void *z_dev, const void *x_dev,
-                        const void *y_dev, size_t n);
-/* out[i] = a[i] + b[i] on G1 (affine in, affine out; exercises add/double/inf cases) */
-int32_t mi_g1_add_dev(mi_ctx *ctx, mi_g1_affine *out_dev, const mi_g1_affine *a_dev,
-                      const mi_g1_affine *b_dev, size_t n);
-int32_t mi_g2_add_dev(mi_ctx *ctx, mi_g2_affine *out_dev, const mi_g2_affine *a_dev,
-                      const mi_g2_affine *b_dev, size_t n);
-/* random-gather throughput probe: n_threads lanes each chain `iters` dependent 64-byte gathers from a table of n_entries
- * (a power of two) 64-byte entries; scratch: 1 KiB.  The ceiling the level-1 bucket accumulation's point gathers run against. */
-int32_t mi_bench_gather_dev(mi_ctx *ctx, const void *table_dev, size_t n_entries, size_t n_threads, uint32_t iters,
-                            void *scratch_dev, float *ms_out);
-/* modular-multiply throughput probe: chains `iters` dependent Fp products per thread */
-int32_t mi_bench_modmul_dev(mi_ctx *ctx, int field, size_t n_threads, uint32_t iters,
-                            void *scratch_dev, float *ms_out);
-/* raw VALU issue-rate probe (the integer-MAC ceiling SURVEY 8d asks to report beside the MSM):
- * kind 0 = 32x32+64 mad, 1 = mul_lo+mul_hi u32, 2 = fma f64, 3 = 24-bit mul+add, 4 = 64-bit add;
- * each thread runs 8 independent chains x iters steps */
-int32_t mi_bench_valu_dev(mi_ctx *ctx, int kind, size_t n_threads, uint32_t iters,
-                          void *scratch_dev, float *ms_out);
-/* tuning / test knobs (0 = automatic).  NTT: tile = 2^log_e elements, radix caps of the contiguous and the
- * strided passes, threads per workgroup.  MSM: window bits c (2..16), item sizes of level 1 / later levels,
- * bucket-reduce segment, slices per window.  Tests use them to force multi-pass / multi-level paths at small n. */
-int32_t mi_debug_set_ntt_plan(mi_ctx *ctx, uint32_t log_e, uint32_t max_contig, uint32_t max_strided);
-int32_t mi_debug_set_ntt_threads(mi_ctx *ctx, uint32_t threads);
-/* on = 1 (default): passes of radix >= 2^7 run seven of their stages in registers (wavefront butterflies); 0: every stage through
- * LDS.  direct_min_log_n: computeH builds its data-layout twiddle / coset tables from this size on (default 12; 29 = never). */
-int32_t mi_debug_set_ntt_wave_stages(mi_ctx *ctx, uint32_t on, uint32_t direct_min_log_n);
-/* Fused launches of computeH, a bit mask (default 7 = all).  Bit 0: the contiguous last pass of FFTInverse(a | b) and the contiguous
- * first pass of the coset FFT that follows run as one launch on the same tiles (csrc/ntt.hip k_ntt_contig_pair).  Bit 1: the strided
- * last pass of the coset FFT of a and of b, the product a b and the strided first pass of the last transform run as one launch
- * (k_ntt_strided_triple; plans whose first radix is 2^7 or 2^8).  Bit 2: the last pass of den FFTInverse(c) and the last pass of the last
- * transform, which subtracts it, run as one launch (k_ntt_contig_last_sub).  Same h whatever the mask; parity tests run the combinations. */
-int32_t mi_debug_set_ntt_fuse_pair(mi_ctx *ctx, uint32_t on);
-int32_t mi_debug_set_msm_plan(mi_ctx *ctx, uint32_t c, uint32_t L1, uint32_t L2, uint32_t seg, uint32_t G);
-int32_t mi_debug_set_msm_chunk(mi_ctx *ctx, uint32_t chunk);   /* fixed-base sort: entries per pass-2 chunk */
-int32_t mi_debug_set_msm_group_bits(mi_ctx *ctx, uint32_t gbits);   /* fixed-base sort: log2 buckets per pass-1 group, 6..15 */
-/* window widths of the fixed-base tables the NEXT mi_pk_load[_dev] on ctx builds for the MSM groups A+K, B1+B2, Z:
- * 0 = automatic (tables when the MSM has >= 2^20 points and they fit in a third of the free device memory),
- * 1 = never, 17..22 = that width whatever the size */
-int32_t mi_debug_set_prove_fixed_base(mi_ctx *ctx, uint32_t c_ak, uint32_t c_b, uint32_t c_z);
-/* hold_accum = 1: inside a prove whose inputs are in HBM the wire MSMs (A, B1, B2, K) sort at once but start their bucket
- * accumulations only when computeH is done; 0 (default): everything as soon as its inputs exist.  Same proofs.  Measured neutral on
- * throughput and 0.4 ms worse on the single-proof latency (a proof alone is work-bound, not schedule-bound: DESIGN.md 7b). */
-int32_t mi_debug_set_prove_schedule(mi_ctx *ctx, uint32_t hold_accum);
-/* on = 0 (default): an MSM runs as many item levels as the fullest bucket of its sort needs (one 4-byte read-back per sort, waited for on the
- * thread that enqueues the accumulation); 1: as many as the worst case would (every entry in one bucket).  Same sums; parity tests run both. */
-int32_t mi_debug_set_msm_bound_levels(mi_ctx *ctx, uint32_t on);
-/* 1: generic MSMs of >= 2^18 pairs keep the one-pass counting sort instead of the LDS-staged two-pass one (parity tests run both) */
-int32_t mi_debug_set_msm_one_pass_sort(mi_ctx *ctx, uint32_t on);
-/* on = 1 (default): the G1 level-1 bucket accumulation runs in nine 29-bit limbs (keys loaded afterwards keep their G1 points in
- * the matching packed form) and the G1 partial sums between the levels stay in that form; 2: the same level 1 with standard-form
- * partial sums; 0: the 8 x 32-bit kernels everywhere.  Set before mi_pk_load; parity tests run all three. */
-int32_t mi_debug_set_msm_limb29(mi_ctx *ctx, uint32_t on);
-/* 3 (default) or 2: which build of the G1 level-1 29-bit kernel runs -- three waves per SIMD (fastest alone, shortest launches) or two
- * (leaves registers for other kernels' waves on the same SIMD: +1.7 % proofs/s with three proofs in flight at N = 2^23, slower when
- * one proof fills the GPU).  Same results. */
-int32_t mi_debug_set_msm_l1_waves(mi_ctx *ctx, uint32_t waves);
-/* EXPERIMENT, default 0 (off).  rounds = 1..4: the G1 level-1 accumulation by batch-affine rounds (affine additions, one shared inversion
- * per 64 * K additions; csrc/msm_ba_g1.cuh) wherever the buckets hold >= 32 entries on average and the scratch (768 B per item) fits.
- * 32 % fewer multiplications per addition, the same results -- and half the speed on MI355X: every pass is bound by its random 64-byte
- * reads at ~3 TB/s.  Kept for the measurement and the parity test. */
-int32_t mi_debug_set_msm_batch_affine(mi_ctx *ctx, uint32_t rounds);
-/* on = 1 (default): the fixed-base window tables of mi_pk_load / mi_msm_precompute_* convert to affine with one inversion per 16 points
- * (needs n XYZZ + n coordinates of scratch while building; falls back by itself without room); 0: one inversion per point.  Same tables. */
-int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
-/* Named measurement / test knobs of one context (the switches that are not worth an entry point each; none changes a result).
- * MI_EINVAL for an unknown name or a value out of range.  The library reads NO environment variable for any of this: the only
- * variables it looks at are MI_GROUP_TIMEOUT_MS and MI_GROUP_SHM_CHUNK_KB of the device groups (documented at mi_group_create_rank_ex).
- *   "l1_wg" 1 | 2 | 4        waves per workgroup of the G1 level-1 bucket-accumulate kernel, default 4 (a workgroup takes one slot on each
- *                            SIMD of a CU and returns them together, so the other streams' multi-wave workgroups find room)
- *   "g2_wg" 1 | 2 | 4        the same for the G2 level-1 kernel (each wave has its own 18 KiB LDS accumulator image)
- *   "l1_waves" 2 | 3         = mi_debug_set_msm_l1_waves
- *   "z_waves" 0 | 2          2: the Z MSM's level-1 launch alone on the two-waves-per-SIMD build
- *   "g1_grid_per_cu", "g2_grid_per_cu"   resident-grid cap per CU of the level-1 launches, in waves (0 = 128)
- *   "count_per" 0..64        fixed-base sort: slices per counting workgroup (0 = 32)
- *   "plain_scatter" 0 | 1    fixed-base sort: pass 2 by the plain scatter instead of the LDS-staged one
- *   "finisher" 0 | 1         1 (default): once no bucket holds more than "finisher_max" partial sums the item levels end in ONE launch
- *                            (k_msm_finish_keys) instead of log_8 more levels of three launches each
- *   "z_count_fused" 0 | 1     1 (default): inside a proof the Z MSM's sort takes its digit count from computeH's last launch (the kernel that
- *                            stores h counts the digits of what it stores: h is read once less) instead of a count pass of its own.  Same
- *                            proofs; throughput equal (the count's instructions move, they do not go away), one proof alone 0.1-0.2 ms shorter
- *   "flat_item_l1" 0 | 1 | 4..64   entries per level-1 item of a FLAT sort (fullest bucket <= 2 x the average: uniform scalars, e.g. the h
- *                            coefficients of a proof's Z MSM).  0 (default) = automatic: average / L2^k where that falls into 17..32 (26 at
- *                            N = 2^23), so that the levels above are full L2-ary trees; 1 = off (the plan's L1); 4..64 = forced
- *   "finisher_max" 0..2^20   0 = automatic (G1 4096, G2 1024)
- *   "finisher_min_level" 0..16   the finisher follows accumulate pass number this + 1 at the earliest (default 2: the first two passes
- *                            are where every ordinary bucket ends; a finisher over 2^19 buckets of 13 partial sums each measured -5 %)
- *   "item_l1", "item_l2", "reduce_seg"   = the L1, L2, seg of mi_debug_set_msm_plan, one at a time (a flat sort keeps its own item size: "flat_item_l1")
- *   "hold_accum" 0 | 1       = mi_debug_set_prove_schedule
- *   "ntt_lds_floor_kb" 0..160   LDS every NTT pass workgroup requests at least (caps the workgroups per CU) */
-int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value);
-/* Counters the tests read to prove that an optional path really ran: "z_count_fused_launches" = computeH last launches of this context that
- * carried the Z MSM's digit count (knob "z_count_fused").  MI_EINVAL for an unknown name. */
-int32_t mi_debug_get_counter(mi_ctx *ctx, const char *name, uint64_t *out);
-/* Process-wide, for contexts created afterwards: how the MSM slots of a context share streams (0: K's stream created, destroyed and
- * pointed at B1's, as rounds 4-5 did; 1, the default: never created; 2: A, B1 and K on one stream).  Same results; an experiment on which
- * chains end up on one hardware queue. */
-int32_t mi_debug_set_stream_plan(int32_t plan);
-/* Tracing: on != 0 wraps the host-side phases of every call -- uploads, computeH's enqueue, each MSM's enqueue and
+/* ---- tracing: on != 0 wraps the host-side phases of every call -- uploads, computeH's enqueue, each MSM's enqueue and
  * collection, the pool's stages, the device groups' exchanges -- in roctx ranges ("mi.prove", "mi.computeH.enqueue", "mi.msm.Z.enqueue", ...),
  * which `rocprofv3 --marker-trace --kernel-trace` shows beside the kernels.  Process-wide; off by default (one relaxed load per site).
- * MI_ENODEV when no roctx library can be loaded (librocprofiler-sdk-roctx / libroctx64, looked up at the first call; nothing links it). */
-int32_t mi_debug_set_trace_ranges(int32_t on);
-/* error-path tests: the nth MI-checked HIP call from now (library-wide, any thread) fails with hipErrorUnknown instead of
- * running; 0 disarms.  Used to prove that init / load / prove unwind without leaks or crashes. */
-int32_t mi_debug_inject_hip_failure(int32_t nth);
+ * MI_ENODEV when no roctx library can be loaded (looked up at the first call; nothing links it). */
+int32_t mi_set_trace_ranges(int32_t on);
+
 /* raw device memory helpers so hosts without a HIP binding (ctypes, cgo) can stage data */
 int32_t mi_dev_alloc(mi_ctx *ctx, size_t bytes, void **out_dev);
 int32_t mi_dev_free(mi_ctx *ctx, void *dev);

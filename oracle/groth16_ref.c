@@ -20,6 +20,7 @@
 #include <string.h>
 #include <omp.h>
 #include "../include/mi355x_groth16.h"
+#include "../include/mi355x_groth16_debug.h"   /* MI_DIST_*: the synthetic-input generators are shared with the tests */
 #include "ref_field.h"
 
 /* ---------------------------------------------------------------- Fp2 = Fp[u]/(u^2+1) */
@@ -133,11 +134,14 @@ static inline void rnd_fe(fe *z, uint64_t seed, uint64_t idx, const fctx *F) {
 /* canonical scalar of the synthetic workload */
 static void gen_scalar_canonical(fe *z, uint64_t seed, uint64_t i, int dist) {
     if (dist == MI_DIST_UNIFORM) { rnd_fe(z, seed, i, &FR); return; }
-    uint64_t u = rnd(seed, i, 4) % 100;
+    /* MI_DIST_WHIR: 45 / 25 / 5 per cent; MI_DIST_MIX(bit, byte, u64): per-mille shares packed into dist (include/mi355x_groth16_debug.h) */
+    int mix = (dist & MI_DIST_MIX_FLAG) != 0;
+    uint64_t t0 = mix ? (uint64_t)((dist >> 20) & 1023) : 45, t1 = t0 + (mix ? (uint64_t)((dist >> 10) & 1023) : 25), t2 = t1 + (mix ? (uint64_t)(dist & 1023) : 5);
+    uint64_t u = rnd(seed, i, 4) % (mix ? 1000 : 100);
     memset(z, 0, sizeof(*z));
-    if (u < 45) z->l[0] = rnd(seed, i, 5) & 1;
-    else if (u < 70) z->l[0] = rnd(seed, i, 5) & 255;
-    else if (u < 75) z->l[0] = rnd(seed, i, 5);
+    if (u < t0) z->l[0] = rnd(seed, i, 5) & 1;
+    else if (u < t1) z->l[0] = rnd(seed, i, 5) & 255;
+    else if (u < t2) z->l[0] = rnd(seed, i, 5);
     else rnd_fe(z, seed, i, &FR);
 }
 void ref_gen_scalars(mi_fr *out, size_t n, uint64_t seed, int dist) { /* Montgomery out */

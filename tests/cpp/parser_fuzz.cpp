@@ -12,6 +12,7 @@
 // buffers sized from the shapes the library reports, so an out-of-bounds write on the library's side is the sanitizer's to find.
 // Exit status 0 = no sanitizer report and no contract violation (a mutant may be accepted or refused; it may not crash).
 #include "../../include/mi355x_groth16.h"
+#include "../../include/mi355x_whir_ingest.h"
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>

@@ -12,9 +12,33 @@ from helpers import *
 from gpu_common import load_binding, ROOT
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "mi355x_groth16.h")).read()
-    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+HEADERS = ("mi355x_groth16.h", "mi355x_groth16_group.h", "mi355x_whir_ingest.h", "mi355x_groth16_debug.h")
+
+
+def _declared(headers=HEADERS):
+    out = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)   # (comments mention entry points of the other headers)
+        out |= set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src))
+    return sorted(out)
+
+
+def test_product_header_carries_no_lab_bench():
+    """what a maintainer binds (include/mi355x_groth16.h, + _group.h / whir_ingest.h by need) declares no generator, probe,
+    plan knob or fault injection -- those live in mi355x_groth16_debug.h, which the Go shim never includes -- and stays short"""
+    for h in HEADERS[:3]:
+        names = _declared((h,))
+        bad = [n for n in names if n.startswith(("mi_debug_", "mi_bench_", "mi_gen_")) or n in ("mi_field_op_dev", "mi_g1_add_dev", "mi_g2_add_dev")]
+        assert not bad, f"{h} declares lab-bench symbols: {bad}"
+    assert len(open(os.path.join(ROOT, "include", HEADERS[0])).read().splitlines()) < 350
+    dbg = _declared((HEADERS[3],))
+    assert "mi_debug_inject_hip_failure" in dbg and "mi_gen_scalars_dev" in dbg and "mi_bench_modmul_dev" in dbg
+    go = os.path.join(ROOT, "gnark-whir_amd", "go")
+    for d, _, fs in os.walk(go):
+        for f in fs:
+            if f.endswith(".go"):
+                assert "mi355x_groth16_debug.h" not in open(os.path.join(d, f)).read(), f"{f} includes the debug header"
 
 
 def test_library_exports_every_declared_symbol():
@@ -23,7 +47,7 @@ def test_library_exports_every_declared_symbol():
     names = _declared()
     assert len(names) >= 35
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/mi355x_groth16.h but not exported"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported"
     for n in B.EXPORTS:
         assert n in names
 

@@ -54,8 +54,13 @@ def test_montgomery_product_carry_edge_limbs(ctx):
 
 def test_generators_match_oracle(ctx):
     n = 3000
-    for dist in (0, 1):
+    B = load_binding()
+    for dist in (0, 1, B.dist_mix(23, 237, 0), B.dist_mix(450, 250, 50), B.dist_mix(0, 0, 1000), B.dist_mix(1000, 0, 0), B.dist_mix(0, 0, 0)):
         assert np.array_equal(ctx.gen_scalars(n, 77, dist).download((n, 4)), cref.gen_scalars(n, 77, dist))
+    # MI_DIST_MIX(bit, byte, u64): the shares are what the name says (per mille, the rest full-width)
+    v = fr_vals(cref.gen_scalars(20000, 5, B.dist_mix(23, 237, 0)))
+    share = lambda f: sum(1 for x in v if f(x)) / len(v)
+    assert abs(share(lambda x: x < 2) - (0.023 + 0.237 * 2 / 256)) < 0.006 and abs(share(lambda x: x < 256) - 0.260) < 0.012 and share(lambda x: x >= 1 << 200) > 0.70
     assert np.array_equal(ctx.gen_g1(n, 5).download((n, 8)), cref.gen_g1(n, 5))
     assert np.array_equal(ctx.gen_g2(200, 6).download((200, 16)), cref.gen_g2(200, 6))
 

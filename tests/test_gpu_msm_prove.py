@@ -186,6 +186,44 @@ def test_prove_with_fixed_base_tables_vs_oracle(ctx, knob):
     assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 16, 0, 0) != 0 and ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 23, 0) != 0
 
 
+_CENSUS_CASE = {}
+
+
+@pytest.mark.parametrize("knob", [(0, 0, 0), (19, 17, 20), (20, 18, 20)])
+def test_prove_census_mix_at_2p20_vs_oracle(ctx, knob):
+    """the witness mix tools/wire_census.py derives from the reference's circuit (mtUtilities.go:494-532 eq tables and
+    matrix MLE all full-width; Merkle / STIR terms bytes and full-width; bits 1-3 %: MI_DIST_MIX, same generator on both sides) at
+    N = 2^20, through the generic path and through fixed-base tables of the production widths: proof bytes == oracle proof bytes"""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wire_census
+    B = load_binding()
+    pm = wire_census.census_mix_permille()
+    assert sum(pm) < 500 and pm[2] == 0, "the census says: mostly full-width values, no 64-bit class"
+    dist = B.dist_mix(*pm)
+    log_n = 20
+    n = 1 << log_n
+    nb_wires, nb_public, n_constraints = n - 1000, 4097, n - 100
+    if "case" not in _CENSUS_CASE:   # one key, one witness and one oracle proof for the three table plans
+        pk = synthetic_pk(log_n, nb_wires, nb_public, 4400, n_committed=n >> 5)
+        W = ctx.gen_scalars(nb_wires, 1, dist).download((nb_wires, 4)); a = ctx.gen_scalars(n_constraints, 2, dist).download((n_constraints, 4))
+        assert np.array_equal(W[:4000], cref.gen_scalars(4000, 1, dist))
+        b = cref.gen_scalars(n_constraints, 3, 0); c = cref.field_op(0, 2, a, b)
+        r, s = cref.gen_scalars(2, 4, 0)
+        _CENSUS_CASE["case"] = (pk, W, a, b, r, s, cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"]))
+    pk, W, a, b, r, s, want = _CENSUS_CASE["case"]
+    assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, *knob) == 0
+    try:
+        pkh = ctx.pk_load(pk)
+    finally:
+        assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
+    got, st = ctx.prove(pkh, W, a, b, None, r, s)      # c formed on the device, as on the benchmarked path
+    assert B.proof_write(got["raw"]) == want
+    if knob[0]:   # ~3/4 of the wire scalars are full-width: about 0.76 x 14 digits each against the WHIR mix's ~4
+        assert st["g1_level1_additions"] > 8 * nb_wires
+    ctx.pk_free(pkh)
+
+
 def test_prove_rejects_mismatched_inputs(ctx):
     z, pk = _load_toy()
     bad = dict(pk); bad["g1_a"] = pk["g1_a"][:-1]

@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--in-flight", type=int, default=3)
-    ap.add_argument("--dist", choices=["whir", "uniform"], default="whir")
+    ap.add_argument("--dist", choices=["whir", "uniform", "census"], default="whir")
     ap.add_argument("--defaults", default="", help="knobs applied under every configuration (the baseline the others are compared with)")
     ap.add_argument("configs", nargs="*")
     args = ap.parse_args()
@@ -62,7 +62,7 @@ def main():
     pkh = ctx.pk_load(pk, device_points=True)
     for d in (g1a, g1b, g1k, g2b):
         d.free()
-    dist_id = 1 if args.dist == "whir" else 0
+    dist_id = bench.dist_id_of(B, args.dist)
     W = ctx.gen_scalars(nb_wires, seed + 8, dist_id); a = ctx.gen_scalars(n_constraints, seed + 9, dist_id); b = ctx.gen_scalars(n_constraints, seed + 10, 0)
     c = ctx.alloc(32 * n_constraints); ctx.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)
     rs = ctx.gen_scalars(3, seed + 11, 0).download((3, 4)); ctx.sync()

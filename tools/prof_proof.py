@@ -51,7 +51,8 @@ def main():
     pk = {"log_n": log_n, "nb_public": nb_public, "nb_wires": nb_wires, "g1_a": (g1a.ptr, na), "g1_b": (g1b.ptr, nb), "g1_k": (g1k.ptr, nk), "g1_z": (g1z.ptr, N), "g2_b": (g2b.ptr, nb),
           "alpha1": small[0], "beta1": small[1], "delta1": small[2], "beta2": small2[0], "delta2": small2[1], "infinity_a": inf_a, "infinity_b": inf_b, "committed_wires": cw}
     pkh = ctx.pk_load(pk, device_points=True)
-    W = ctx.gen_scalars(nb_wires, seed + 8, 1); a = ctx.gen_scalars(n_constraints, seed + 9, 1); b = ctx.gen_scalars(n_constraints, seed + 10, 0)
+    did = bench.dist_id_of(B, sys.argv[4] if len(sys.argv) > 4 else "whir")   # 4th argument: whir (default) | uniform | census
+    W = ctx.gen_scalars(nb_wires, seed + 8, did); a = ctx.gen_scalars(n_constraints, seed + 9, did); b = ctx.gen_scalars(n_constraints, seed + 10, 0)
     c = ctx.alloc(32 * n_constraints); ctx.field_op_dev(0, 2, c.ptr, a.ptr, b.ptr, n_constraints)
     rs = ctx.gen_scalars(2, seed + 11, 0).download((2, 4)); ctx.sync()
     ts = []
