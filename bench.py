@@ -33,7 +33,7 @@ from benchlib.common import _binding, _sha16, dist_id_of   # noqa: E402  (the te
 from benchlib.pmc import _kernel_short, live_pmc   # noqa: E402,F401
 from benchlib.clocks import ClockSampler   # noqa: E402
 from benchlib.sharded import sharded_helper_main, run_sharded_legs   # noqa: E402
-from benchlib.launch import self_launch, bind_to_gpu_numa_node   # noqa: E402
+from benchlib.launch import self_launch, bind_to_gpu_numa_node, require_gpus, observe_devices   # noqa: E402
 
 
 def cpu_baseline(pk_host, W, a, b, c, r, s, ped, log_n, gpu_proof_bytes):
@@ -112,6 +112,8 @@ def main():
     args = ap.parse_args()
     if args.sharded_helper:
         return sharded_helper_main()
+    if not args.launch_check:
+        require_gpus(args.gpus, args.rehearse_on_one_gpu)   # N ranks on N distinct GPUs, or the declared rehearsal: said before any rank starts
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args.gpus, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,6 +149,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     red_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"
+    devices_observed = observe_devices(torch, dist, local_rank, world, args.rehearse_on_one_gpu)
     numa = bind_to_gpu_numa_node(torch, local_rank) if world > 1 and not args.rehearse_on_one_gpu else None   # (N = 1 keeps every core: the CPU baseline wants them)
 
     B = _binding()
@@ -465,8 +468,16 @@ def main():
                     st = ctx.stats()
                     if best is None or st["g1_accum_kernel_ms"] < best["g1_accum_kernel_ms"]:
                         best = st
+                # the shader clock this launch sustains (the floors below are cycles): ~0.5 s of the same MSM back to back under the sampler
+                zclk = None
+                if not args.no_clock_samples:
+                    smp = ClockSampler(local_rank).start()
+                    t_end = time.perf_counter() + 0.7
+                    while time.perf_counter() < t_end:
+                        ctx.msm_fixed_dev(tab.ptr, hsc.ptr, n_z, cz, flags=2)
+                    zclk = smp.stop()
                 tab.free(); hsc.free()
-                zsolo = {"pairs": n_z, "scalars": "uniform", "window_bits": cz, "windows": nwin_z, "msm_total_ms": best["total_ms"], "accum_launch_ms": best["g1_accum_kernel_ms"],
+                zsolo = {"sclk_mhz_under_this_msm": None if not zclk else zclk["sclk_mhz_mean"], "pairs": n_z, "scalars": "uniform", "window_bits": cz, "windows": nwin_z, "msm_total_ms": best["total_ms"], "accum_launch_ms": best["g1_accum_kernel_ms"],
                          "accum_GBps_algorithmic": 96.0 * n_z / (best["g1_accum_kernel_ms"] * 1e-3) / 1e9, "mixed_adds": int(best["g1_accum_entries"]),
                          "mixed_adds_per_s": best["g1_accum_entries"] / (best["g1_accum_kernel_ms"] * 1e-3), "msm_pts_per_s": n_z / (best["total_ms"] * 1e-3)}
         except B.MiError as e:
@@ -592,14 +603,23 @@ def main():
         in_job = {"launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes, "achieved": achieved, "frac": achieved / 8000.0,
                   "note": "average over the proofs' four G1 level-1 launches while three proofs share the GPU (HIP events on the launch's stream): what rounds 1-4 reported as "
                           "`achieved`; it falls when the launch shares the CUs more evenly with the other streams, i.e. when the job gets FASTER"}
+        bound_note = ("the kernel is bound by vector-ALU instruction issue (exact 254-bit modular products: no MFMA form exists), not by HBM: `achieved` / `peak` / `frac` are the "
+                      "HBM roofline BASELINE.json's north_star asks to report; `valu_frac` is the roofline that binds")
         if zsolo and "accum_launch_ms" in zsolo:
-            roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm",
+            zmhz = zsolo.get("sclk_mhz_under_this_msm") or (clocks or {}).get("sclk_mhz_mean")
+            floor_meas = None if not (issue_floor and zmhz) else issue_floor * (zmhz * 1e6 / 2.4e9)
+            roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "valu-issue", "bound_note": bound_note,
+                        "valu_frac": None if not floor_meas else zsolo["mixed_adds_per_s"] / floor_meas,
+                        "valu_frac_at_2400_mhz": None if not issue_floor else zsolo["mixed_adds_per_s"] / issue_floor,
+                        "valu_frac_basis": None if not floor_meas else f"{zsolo['mixed_adds_per_s'] / 1e9:.2f} G mixed additions/s / ({zmhz:.0f} MHz measured under this MSM x 65536 lanes / cycles per wave-addition of the ISA census)",
+                        "traffic_ratio": None if not traffic_solo else traffic_solo / (96.0 * zsolo["pairs"]),
                         "basis": f"solo launch: the proof's largest level-1 launch (Z MSM: {zsolo['pairs']} uniform scalars, {zsolo['windows']} windows of {zsolo['window_bits']} bits, fixed-base tables) alone on the GPU",
                         "achieved": zsolo["accum_GBps_algorithmic"], "peak": 8000.0, "unit": "GB/s", "frac": zsolo["accum_GBps_algorithmic"] / 8000.0,
                         "traffic": traffic_solo, "traffic_source": pmc_src_solo, "launch_ms": zsolo["accum_launch_ms"], "algorithmic_bytes_per_launch": 96.0 * zsolo["pairs"],
                         "in_job": dict(in_job, traffic=traffic, traffic_source=pmc_src)}
         else:
-            roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "hbm", "basis": "in-job average launch (the solo Z-shaped launch did not run)",
+            roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "valu-issue", "bound_note": bound_note, "valu_frac": None,
+                        "traffic_ratio": None if not (traffic and per_launch_bytes) else traffic / per_launch_bytes, "basis": "in-job average launch (the solo Z-shaped launch did not run)",
                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": pmc_src,
                         "launch_ms": per_launch_ms, "algorithmic_bytes_per_launch": per_launch_bytes, "in_job": in_job}
         # vector-ALU utilisation of the job: wave-instructions per proof (SQ_INSTS_VALU over four proofs alone on one context,
@@ -651,6 +671,9 @@ def main():
                        "g1_msm_sizes": [na, nb, nk, N - 1], "g2_msm_size": nb, "pedersen_msm_sizes": [n_committed, n_committed], "proofs_in_flight_per_gpu": in_flight,
                        "caller_threads": callers, "inputs": "host memory (PCIe inside the step)"},
             "proof_bytes": len(serial_bytes), "rank0_numa_binding": numa,
+            # observed, not derived from the arguments: the ranks' PCI bus ids and how many are distinct (a run with fewer distinct devices than
+            # ranks is refused unless it is the declared one-GPU rehearsal); the device group's own view is in sharded_prove.observed
+            "devices_observed": dict(devices_observed, rehearsal_on_one_gpu=bool(args.rehearse_on_one_gpu)),
             # the GPU-side rate: the same key and witness with W, a, b, c already in HBM and no commitment (164-byte body) -- what rounds 1-3
             # reported as `value`; no caller of the reference can reach it (gnark's solver is CPU code)
             "value_hbm_resident_inputs": dev_rate, "ms_per_step_hbm_resident_inputs": dev_ms,
@@ -679,7 +702,12 @@ def main():
             "roofline": roofline,
             # second kernel: k_ntt_pass.  Algorithmic bytes 64 * N per size-N transform whatever the number of passes;
             # time = computeH alone on the GPU / its 6 transforms (gnark's 7th, the coset FFT of c, is never needed: DESIGN.md 4)
-            "roofline_ntt": {"kernel": "k_ntt_pass_wave + k_ntt_contig_pair + k_ntt_strided_triple + k_ntt_contig_last_sub (all passes of one size-N transform)", "bound": "hbm",
+            "roofline_ntt": {"kernel": "k_ntt_pass_wave + k_ntt_contig_pair + k_ntt_strided_triple + k_ntt_contig_last_sub (all passes of one size-N transform)", "bound": "valu-issue",
+                             "bound_note": "77 modular products per element per computeH on the vector ALU; the HBM figures are what north_star asks for.  `achieved` counts the SIX transforms this "
+                                           "library runs (64 N bytes each); `achieved_survey_8d_accounting` prices the same computeH at SURVEY 8d's 7 x 64 N = 448 N bytes",
+                             "achieved_survey_8d_accounting": 448.0 * N / (ntt_solo["compute_h_ms"] * 1e-3) / 1e9,
+                             "frac_survey_8d_accounting": 448.0 * N / (ntt_solo["compute_h_ms"] * 1e-3) / 1e9 / 8000.0,
+                             "traffic_ratio": None if not traffic_ntt else traffic_ntt / (64.0 * N),
                              "achieved": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                              "frac": 64.0 * N / (ntt_solo["ms_per_transform"] * 1e-3) / 1e9 / 8000.0, "traffic": traffic_ntt,
                              "traffic_source": pmc_src + ": (2 x FETCH_SIZE + WRITE_SIZE) per pass launch x pass launches per transform",

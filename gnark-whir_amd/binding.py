@@ -29,7 +29,7 @@ EXPORTS = [
     "mi_prover_create", "mi_prover_destroy", "mi_prover_in_flight", "mi_prover_ctx", "mi_prover_last_error",
     "mi_prover_submit", "mi_prover_submit_dev", "mi_prover_wait", "mi_prover_commit", "mi_prover_submit_bsb22", "mi_prover_trim", "mi_ctx_trim",
     "mi_group_create", "mi_group_unique_id", "mi_group_create_rank", "mi_group_create_rank_ex", "mi_group_rank", "mi_group_destroy", "mi_group_world", "mi_group_local", "mi_group_ctx",
-    "mi_group_last_error", "mi_group_transport", "mi_group_set_lead_share", "mi_group_wire_range", "mi_group_set_sharded_compute_h", "mi_compute_h_sharded_dev", "mi_groth16_prove_sharded_slices_dev", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
+    "mi_group_last_error", "mi_group_transport", "mi_group_comm_ranks", "mi_group_device_pci", "mi_group_set_lead_share", "mi_group_wire_range", "mi_group_set_sharded_compute_h", "mi_compute_h_sharded_dev", "mi_groth16_prove_sharded_slices_dev", "mi_group_exchange_selftest", "mi_pk_load_sharded", "mi_pk_sharded_free",
     "mi_groth16_prove_sharded", "mi_groth16_prove_sharded_dev", "mi_pk_load_sharded_dev", "mi_msm_g1_sharded", "mi_msm_g2_sharded",
     "mi_msm_g1_sharded_dev", "mi_msm_g2_sharded_dev",
     "mi_pk_raw_inspect", "mi_pk_load_raw",
@@ -551,6 +551,18 @@ class Group:
 
     def rank_index(self):
         return int(self.lib.mi_group_rank(self.h))
+
+    def comm_ranks(self):
+        """ranks the RCCL communicator itself reports (ncclCommCount); 0 = the transport is not RCCL"""
+        n = int(self.lib.mi_group_comm_ranks(self.h))
+        if n < 0:
+            raise MiError(f"mi_group_comm_ranks: {n}")
+        return n
+
+    def device_pci(self, local_rank=0):
+        buf = C.create_string_buffer(32)
+        self._ck(self.lib.mi_group_device_pci(self.h, C.c_int(local_rank), buf))
+        return buf.value.decode()
 
     def set_lead_share(self, permille=0xFFFFFFFF):
         """rank 0's share of the wires, permille of an even share (0xFFFFFFFF = automatic); before pk_load*, the same on every rank"""

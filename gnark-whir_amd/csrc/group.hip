@@ -102,6 +102,7 @@ struct mi_pk_sharded {
     u32 log_n = 0;
     u64 nb_wires = 0;
     bool uniform = false;          // every local part chose the same MSM plan per group (needed by mode 1)
+    uint32_t lead_share = 1000;    // the wire cut this key was loaded with (permille, resolved): a prove under another cut is refused
 };
 
 #define G_FAIL(g, code, msg) do { (g)->err = (msg); return (code); } while (0)
@@ -130,6 +131,7 @@ static void range_of(u64 total, int world, int r, u64 &lo, u64 &hi) { lo = total
 static uint32_t lead_share_of(const mi_group *g) {
     if (g->lead_share <= 1000) return g->lead_share;
     const int w = g->world;
+    if (g->sharded_h) return 1000u;   // computeH over the ranks: every rank carries 1 / world of it, so the even cut is the balanced one
     return w <= 1 ? 1000u : w == 2 ? 500u : 0u;
 }
 static void wire_range_of(u64 nb_wires, int world, int r, uint32_t share, u64 &lo, u64 &hi) {
@@ -316,8 +318,9 @@ static int32_t nccl_wait_stream(mi_group *g, int i, hipStream_t s, const char *w
     if (!g->nonblocking) { G_HIP(g, hipStreamSynchronize(s)); return MI_OK; }
     const Deadline dl(g->timeout_ms);
     unsigned spins = 0;
+    bool injected = mi_fault_hit();   // ONE count per wait: the call number an injected failure fires at does not depend on how often this loop polls
     for (;;) {
-        const hipError_t q = mi_fault_hit() ? hipErrorUnknown : hipStreamQuery(s);
+        const hipError_t q = injected ? hipErrorUnknown : hipStreamQuery(s);
         if (q == hipSuccess) return MI_OK;
         if (q != hipErrorNotReady) { (void)hipGetLastError(); return nccl_abort_all(g, std::string("group: the exchange stream failed ") + what + ": " + hipGetErrorString(q)); }
         ncclResult_t st = ncclSuccess;
@@ -535,6 +538,7 @@ static int32_t group_finish_init(mi_group *g) {
     g->xs.assign(n, nullptr); g->ev_x.assign(n, nullptr); g->ev_in.assign(n, nullptr); g->ev_done.assign(n, nullptr); g->ev_h.assign(n, nullptr);
     g->recv.assign(n, DevBuf{}); g->stage.assign(n, DevBuf{});
     g->xt.assign(n, CrossNttTables{}); g->hy.assign(n, DevBuf{}); g->hy2.assign(n, DevBuf{}); g->hh.assign(n, DevBuf{}); g->ev_c0.assign(n, nullptr); g->ev_c1.assign(n, nullptr);
+    g->ev_r.assign((size_t)n * 7, nullptr);   // computeH over the ranks: seven "ready" events a local rank, created by compute_h_sharded_prepare
     for (auto &v : g->hx) v.assign(n, DevBuf{});
     for (int i = 0; i < n; i++) {
         (void)hipSetDevice(g->dev[i]);
@@ -668,6 +672,21 @@ mi_ctx *mi_group_ctx(mi_group *g, int local_rank) { return g && local_rank >= 0 
 const char *mi_group_last_error(mi_group *g) { return g ? g->err.c_str() : "null group"; }
 // 1 = RCCL communicator, 2 = copies inside this process (a device named twice), 3 = host-staged through shared memory
 int32_t mi_group_transport(const mi_group *g) { return !g ? 0 : g->transport; }
+// What the communicator ITSELF says about the group (observed, not derived from the arguments of mi_group_create_rank): the number of
+// ranks RCCL joined (ncclCommCount of this process's first communicator), 0 when the transport is not RCCL, negative on an RCCL error.
+int32_t mi_group_comm_ranks(const mi_group *g) {
+    if (!g) return MI_EINVAL;
+    if (g->transport != MI_GROUP_TRANSPORT_RCCL || g->comm.empty() || !g->comm[0]) return 0;
+    int n = 0;
+    return ncclCommCount(g->comm[0], &n) == ncclSuccess ? n : MI_EHIP;
+}
+// PCI bus id ("0000:c1:00.0") of the device local rank `local_rank` runs on, as the HIP runtime reports it: what tells two ranks on two
+// GPUs from two ranks on one.
+int32_t mi_group_device_pci(const mi_group *g, int local_rank, char out[32]) {
+    if (!g || !out || local_rank < 0 || local_rank >= g->n_local()) return MI_EINVAL;
+    out[0] = 0;
+    return hipDeviceGetPCIBusId(out, 32, g->dev[local_rank]) == hipSuccess ? MI_OK : MI_EHIP;
+}
 
 // Every local rank sends a distinct pattern of `bytes` bytes to every rank of the group (itself included) and checks what it
 // received: the transport (RCCL grouped send / recv, peer copies, or the shared-memory rings) in isolation, then the all-gather of
@@ -969,6 +988,34 @@ static bool sharded_h_possible(const mi_group *g, u32 log_n) {
     while ((1 << lw) < W) lw++;
     return log_n >= 2 * lw && log_n <= 28;
 }
+// Seven "ready" events per local rank: a transfer waits for the ONE kernel that produced what it moves, not for whatever else has
+// been enqueued on the context's stream since -- that is what lets the next vector's arithmetic run under this vector's transfer.
+enum { E_IN, E_DA, E_DB, E_DC, E_FA, E_FB, E_MID, E_COUNT };
+// Everything compute_h_sharded allocates -- the cross-rank tables, the two exchange vectors, the h slice, the events -- for ONE local rank.
+// Called in the LOCAL phase of the callers, before the group agrees to proceed: an allocation that fails here is an MI_ENOMEM
+// every rank returns with the group intact, not a null pointer under kernels and transfers the peers are already waiting for.
+static int32_t compute_h_sharded_prepare(mi_group *g, int i, u32 log_n) {
+    const int nl = g->n_local();
+    u32 log_w = 0;
+    while ((1 << log_w) < g->world) log_w++;
+    const size_t M = (size_t)1 << (log_n - log_w);
+    mi_ctx *c = g->ctx[i];
+    MI_TRY(mi_cross_tables_build(c, log_n, log_w, (u32)(g->rank0 + i), &g->xt[i]));
+    MI_TRY(mi_reserve(c, g->hy[i], M * sizeof(Fr)));
+    MI_TRY(mi_reserve(c, g->hy2[i], M * sizeof(Fr)));
+    MI_TRY(mi_reserve(c, g->hh[i], (M + 1) * sizeof(Fr)));
+    if (g->ev_r.size() != (size_t)nl * E_COUNT) MI_FAIL(c, MI_EINVAL, "sharded computeH: the group's event table was not sized at creation");
+    for (int k = 0; k < E_COUNT; k++) {   // (slots of local rank i only: local ranks prepare from their own threads)
+        hipEvent_t &e = g->ev_r[(size_t)i * E_COUNT + k];
+        if (!e) MI_CHECK_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return MI_OK;
+}
+static bool compute_h_sharded_prepared(const mi_group *g, int i) {
+    if (g->ev_r.size() != (size_t)g->n_local() * E_COUNT || !g->hy[i].p || !g->hy2[i].p || !g->hh[i].p || !g->xt[i].s_fwd || !g->xt[i].s_inv) return false;
+    for (int k = 0; k < E_COUNT; k++) if (!g->ev_r[(size_t)i * E_COUNT + k]) return false;
+    return true;
+}
 static int32_t compute_h_sharded(mi_group *g, u32 log_n, bool derive_c) {
     const MiRange range_fn("mi.group.computeH.enqueue");
     const int nl = g->n_local(), W = g->world;
@@ -982,23 +1029,9 @@ static int32_t compute_h_sharded(mi_group *g, u32 log_n, bool derive_c) {
     auto each = [&](const std::function<int32_t(int, mi_ctx *)> &fn) {
         for (int i = 0; i < nl; i++) { (void)hipSetDevice(g->dev[i]); const int32_t rc = fn(i, g->ctx[i]); note(rc, mi_last_error(g->ctx[i])); }
     };
-    each([&](int i, mi_ctx *c) -> int32_t {
-        MI_TRY(mi_cross_tables_build(c, log_n, log_w, (u32)(g->rank0 + i), &g->xt[i]));
-        MI_TRY(mi_reserve(c, g->hy[i], M * sizeof(Fr)));
-        MI_TRY(mi_reserve(c, g->hy2[i], M * sizeof(Fr)));
-        return mi_reserve(c, g->hh[i], (M + 1) * sizeof(Fr));
-    });
-    // Seven "ready" events per local rank: a transfer waits for the ONE kernel that produced what it moves, not for whatever else has
-    // been enqueued on the context's stream since -- that is what lets the next vector's arithmetic run under this vector's transfer.
-    enum { E_IN, E_DA, E_DB, E_DC, E_FA, E_FB, E_MID, E_COUNT };
-    if (g->ev_r.size() != (size_t)nl * E_COUNT) {
-        for (hipEvent_t e : g->ev_r) if (e) (void)hipEventDestroy(e);
-        g->ev_r.assign((size_t)nl * E_COUNT, nullptr);
-        for (int i = 0; i < nl; i++) {
-            (void)hipSetDevice(g->dev[i]);
-            for (int k = 0; k < E_COUNT; k++) if (hipEventCreateWithFlags(&g->ev_r[(size_t)i * E_COUNT + k], hipEventDisableTiming) != hipSuccess) note(MI_EHIP, "sharded computeH: hipEventCreate failed");
-        }
-    }
+    // the callers prepared every local rank and the GROUP agreed on the outcome: nothing is allocated from here on.  (A caller that skipped
+    // that would have kernels and transfers run on null buffers: refused before anything is enqueued.)
+    for (int i = 0; i < nl; i++) if (!compute_h_sharded_prepared(g, i)) { g->err = "sharded computeH: buffers were not prepared before the agreement"; return MI_EINVAL; }
     auto mark = [&](int k) {
         for (int i = 0; i < nl; i++) {
             (void)hipSetDevice(g->dev[i]);
@@ -1130,6 +1163,7 @@ int32_t mi_compute_h_sharded_dev(mi_group *g, uint32_t log_n, const mi_fr *const
         int32_t rc = load_h_slice(g, i, 0, log_m, a_sl[i], false, n_constraints, c->stream);
         if (rc == MI_OK) rc = load_h_slice(g, i, 1, log_m, b_sl[i], false, n_constraints, c->stream);
         if (rc == MI_OK) rc = c_sl ? load_h_slice(g, i, 2, log_m, c_sl[i], false, n_constraints, c->stream) : mi_reserve(c, g->hx[2][i], sizeof(Fr) << log_m);
+        if (rc == MI_OK) rc = compute_h_sharded_prepare(g, i, log_n);   // every buffer of the collective exists BEFORE the ranks agree to enter it
         if (rc != MI_OK) { lrc = rc; lerr = mi_last_error(c); }
     }
     const uint64_t check[3] = {log_n, (uint64_t)n_constraints, c_sl ? 1u : 0u};
@@ -1188,6 +1222,7 @@ static int32_t pk_load_sharded_impl(mi_group *g, const mi_pk_desc *descs, bool d
     // (a rank WITHOUT pairs of some MSM -- the lead with a wire share of 0, a tiny key -- still takes part in mode 1: an empty deferred MSM
     //  leaves a zeroed bucket array of the agreed shape, msm.hip mi_msm_enqueue)
     const uint32_t share = lead_share_of(g);
+    spk->lead_share = share;
     u64 max_w = 0, max_b = 0, max_z = 0;
     for (int r = 0; r < W; r++) {
         u64 lo, hi, zlo, zhi, nb = 0;
@@ -1300,6 +1335,8 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
     if (use_sh && n_constraints > N) note(MI_EINVAL, "prove: witness size does not match the proving key");
     if (n_wires != spk->nb_wires || (lead_here && n_constraints > N)) note(MI_EINVAL, "prove: witness size does not match the proving key");
     if (mode == 1 && !spk->uniform) note(MI_EINVAL, "group: mode 1 needs every part of the key to use the same MSM plan");
+    // (mi_group_wire_range answers with the group's CURRENT share: a caller of the _dev entry points would cut W unlike the key's parts)
+    if (lead_share_of(g) != spk->lead_share) note(MI_EINVAL, "group: the lead's wire share (mi_group_set_lead_share / mi_group_set_sharded_compute_h) changed since this key was loaded: reload the key");
     // workspaces, each on its own device: W slice (+ a, b, c on the lead) for host inputs; h (whole on the lead, a slice elsewhere)
     for (int i = 0; i < nl && lrc == MI_OK; i++) {
         (void)hipSetDevice(g->dev[i]);
@@ -1343,7 +1380,7 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
                 MI_TRY(load_h_slice(g, i, which, log_m, src, !abc_sl, n_constraints, abc_sl ? ctx->stream : cps));
             }
             if (!abc_sl) MI_CHECK_HIP(ctx, hipStreamSynchronize(cps));   // (grown buffers: hipFree inside mi_reserve has synchronised already)
-            return MI_OK;
+            return compute_h_sharded_prepare(g, i, pk->log_n);   // the collective's own buffers too: a failure is agreed on below, before any rank enters it
         }
         if (!lead) return MI_OK;
         // lead: a, b, c arrive while the wire MSMs run; computeH; its own slice of h feeds its Z MSM straight away

@@ -718,7 +718,7 @@ static Msm2Shape msm2_plan_shape(const MsmKnobs *kn, u32 n, u32 c, bool wkeys) {
 }
 int32_t mi_msm_z_count_arm(mi_ctx *ctx, int slot, size_t n, uint32_t c) {
     static_assert(sizeof(Msm2Shape) <= sizeof(ctx->zhook.shape), "Msm2Shape travels in ctx->zhook.shape");
-    ctx->zhook.armed = ctx->zhook.done = false;
+    ctx->zhook.armed = ctx->zhook.done = false; ctx->zhook.h = nullptr;
     const MsmKnobs *kn = knobs_of(ctx);
     if (!kn->z_count_fused || slot != MI_ZHOOK_SLOT || c < 17 || c > 22 || n < MSM2_SLICE || n > ((size_t)1 << 27)) return MI_OK;
     const Msm2Shape s = msm2_plan_shape(kn, (u32)n, c, false);
@@ -751,7 +751,7 @@ static int32_t msm2_sort_enqueue(mi_ctx *ctx, MsmSlot &sl, const Fr *scalars, u3
     // computeH's last launch may have counted these very scalars already (ctx->zhook, armed by prove.hip for this slot, shape and matrix)
     bool counted = false;
     if (&sl == &ctx->msm[MI_ZHOOK_SLOT]) {   // (the other slots' sorts run on helper threads and never touch the hook)
-        counted = ctx->zhook.done && ctx->zhook.slot == MI_ZHOOK_SLOT && ctx->zhook.n == n && ctx->zhook.c == c && ctx->zhook.C1 == C1 && mont && !wkeys;
+        counted = ctx->zhook.done && ctx->zhook.slot == MI_ZHOOK_SLOT && ctx->zhook.n == n && ctx->zhook.c == c && ctx->zhook.C1 == C1 && ctx->zhook.h == (const void *)scalars && mont && !wkeys;
         ctx->zhook.done = false;
     }
     if (!counted) {

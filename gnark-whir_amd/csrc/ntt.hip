@@ -702,7 +702,7 @@ int32_t mi_compute_h_part(mi_ctx *ctx, uint32_t log_n, int part, const mi_fr *sr
             switch (zs.c) { case 17: MI_LAST_COUNT(17); break; case 18: MI_LAST_COUNT(18); break; case 19: MI_LAST_COUNT(19); break; case 20: MI_LAST_COUNT(20); break;
                             case 21: MI_LAST_COUNT(21); break; default: MI_LAST_COUNT(22); break; }
 #undef MI_LAST_COUNT
-            ctx->zhook.done = true;
+            ctx->zhook.done = true; ctx->zhook.h = A;
             ctx->z_count_fused_launches++;
         } else {
             hipLaunchKernelGGL(k_ntt_contig_last_sub, dim3(1u << (log_n - pa.log_r - pa.log_c)), dim3(256), (size_t)32 * ntt_plane_slots(pa), ctx->stream, A, (const Fr *)C, pa, ta, pcl, tcl);

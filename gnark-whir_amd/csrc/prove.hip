@@ -618,6 +618,9 @@ static int32_t prove_common(mi_ctx *ctx, mi_pk *pk, const mi_fr *W, size_t n_wir
         if (!h_promised) h_recorded.set_value(nullptr);   // a failure before computeH's event: release the helpers
         if (f_b.valid()) { const int32_t r = f_b.get(); if (rc == MI_OK) rc = r; }
         if (f_ak.valid()) { const int32_t r = f_ak.get(); if (rc == MI_OK) rc = r; }
+        // a digit count computeH's last launch produced for a Z sort that never came must not meet a later sort of the same shape
+        // (the sort also compares the counted vector's address)
+        if (rc != MI_OK) ctx->zhook.armed = ctx->zhook.done = false;
         if (rc != MI_OK) {
             const std::string keep = ctx->err;   // the collection below may overwrite it
             G1X t1; G2X t2;

@@ -59,7 +59,9 @@ int32_t mi_group_destroy(mi_group *g);
  * its Z MSM before h exists, so a lead that carries an equal share of the wire MSMs lengthens the critical path of the proof.
  * permille = the fraction of an even share (nb_wires / world) that rank 0 takes, 0..1000; the other ranks split the rest evenly; the
  * N - 1 pairs of the Z MSM are always cut evenly.  1000 = the even cut.  MI_LEAD_SHARE_AUTO (the default): 1000 for one rank, 500 for
- * two, 0 from three ranks on -- from the measured ratio computeH : wire MSMs = 1 : 2 at N = 2^26.  Set it -- to the same
+ * two, 0 from three ranks on -- from the measured ratio computeH : wire MSMs = 1 : 2 at N = 2^26 -- and 1000 whatever the
+ * world while mi_group_set_sharded_compute_h is on (computeH is then every rank's, 1 / world each).  A key remembers the share it was cut
+ * with: a prove under another one returns MI_EINVAL ("reload the key").  Set it -- to the same
  * value in every process -- BEFORE mi_pk_load_sharded*: the key's parts are cut by it (a disagreement fails that load on every rank),
  * and a caller that passes device slices (mi_pk_load_sharded_dev, mi_groth16_prove_sharded_dev) cuts its arrays by
  * mi_group_wire_range.  Same proofs whatever the share. */
@@ -86,6 +88,10 @@ mi_ctx *mi_group_ctx(mi_group *g, int local_rank);         /* for mi_dev_* / gen
 const char *mi_group_last_error(mi_group *g);
 int32_t mi_group_rank(const mi_group *g);                  /* global rank of this process's first local rank */
 int32_t mi_group_transport(const mi_group *g);             /* 1 = RCCL, 2 = copies inside one process, 3 = host-staged (shared memory) */
+/* observed facts for a multi-GPU run's record: the rank count the RCCL communicator itself reports (ncclCommCount; 0 when the transport
+ * is not RCCL) and the PCI bus id of a local rank's device ("0000:c1:00.0") -- N ranks on N distinct devices, or not */
+int32_t mi_group_comm_ranks(const mi_group *g);
+int32_t mi_group_device_pci(const mi_group *g, int local_rank, char out[32]);
 /* transport check: every rank sends `bytes` patterned bytes to every rank (itself included) and verifies what it received */
 int32_t mi_group_exchange_selftest(mi_group *g, size_t bytes);
 /* desc: the same whole-key descriptor as mi_pk_load (host arrays); with one rank per process every process passes the whole

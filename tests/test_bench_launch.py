@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])
 def test_plain_launch_starts_its_ranks_and_prints_one_line(n):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
@@ -19,6 +19,24 @@ def test_plain_launch_starts_its_ranks_and_prints_one_line(n):
     assert len(lines) == 1, out.stdout
     j = json.loads(lines[0])
     assert j == {"launch_check": True, "world": n, "sum_of_ranks": float(n * (n - 1) // 2)}
+
+
+def test_more_ranks_than_distinct_gpus_is_refused_with_a_message_unless_it_is_the_declared_rehearsal():
+    """`--gpus N` means N ranks on N distinct devices.  A node with fewer GPUs (this container has none; a one-GPU box has
+    one) refuses a plain `--gpus 2` with that message and a non-zero status BEFORE any rank starts; the one-GPU rehearsal has to be asked for
+    by name (and then fails later here, for want of any GPU -- with the 'no CPU path' message, not the device-count one)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "distinct_devices != n_gpus" in r.stderr and "--rehearse-on-one-gpu" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], "no JSON line may come out of a refused run"
+    if torch.cuda.device_count() == 0:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "1", "--warmup", "0", "--sharded-msm-log-n", "0", "--sharded-prove-log-n", "0"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and "distinct_devices" not in r.stderr
 
 
 def test_launcher_given_ranks_are_used_as_they_are():

@@ -111,3 +111,46 @@ def test_sharded_prove_and_pool_report_injected_failures_and_recover():
         c0.pk_free(pkh)
     finally:
         p.close()
+
+
+def test_compute_h_over_the_ranks_fails_cleanly_when_its_buffers_cannot_be_had():
+    """ADVICE r5 (group.hip compute_h_sharded): the cross-rank tables, exchange vectors, h slice and events of computeH over the ranks are
+    reserved in the LOCAL phase, before the ranks agree to enter the collective.  On a FRESH group (nothing reserved yet) every early
+    MI-checked HIP call of the first sharded prove is made to fail in turn: the call returns an error on every rank -- no kernel or
+    transfer ever runs on a null buffer (that would be a GPU memory fault, not an error code) -- the group stays usable unless a transfer
+    itself failed, and the next proof on a usable group is the oracle's."""
+    B = load_binding()
+    pk = synthetic_pk(12, 4000, 7, 299)
+    W = cref.gen_scalars(4000, 1, 1); a = cref.gen_scalars(4090, 2, 1); b = cref.gen_scalars(4090, 3, 0); cc = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 4, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, cc, r, s)["raw"])
+    outcomes = {"failed_usable": 0, "failed_broken": 0, "beyond": 0}
+    for nth in list(range(1, 40, 2)) + [48, 64, 90]:
+        g = B.Group([0, 0])
+        try:
+            g.set_sharded_compute_h(True)
+            spk = g.pk_load(pk)
+            assert g.lib.mi_debug_inject_hip_failure(nth) == 0
+            failed = False
+            try:
+                got, _ = g.prove(spk, W, a, b, None, r, s, mode=1)
+            except B.MiError:
+                failed = True
+            finally:
+                g.lib.mi_debug_inject_hip_failure(0)
+            for i in range(g.n_local):
+                g.ctx(i).sync()
+            if not failed:
+                assert B.proof_write(got["raw"]) == want, nth
+                outcomes["beyond"] += 1
+                continue
+            try:
+                got, _ = g.prove(spk, W, a, b, None, r, s, mode=1)
+                assert B.proof_write(got["raw"]) == want, nth
+                outcomes["failed_usable"] += 1
+            except B.MiError as e:     # a failure INSIDE an exchange breaks the group by contract: every later call is refused with that message
+                assert "destroy the group" in str(e) or "failed" in str(e), str(e)
+                outcomes["failed_broken"] += 1
+        finally:
+            g.close()
+    assert outcomes["failed_usable"] >= 5, outcomes   # the local phase (reserves included) is where most early calls are

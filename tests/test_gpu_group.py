@@ -341,6 +341,33 @@ def test_lead_share_of_the_wires_gives_the_same_proof(B, grp, share, mode):
         grp.set_lead_share(0xFFFFFFFF)
 
 
+def test_a_key_remembers_the_wire_cut_it_was_loaded_with(B):
+    """the automatic lead share is the even cut while computeH runs over the ranks (every rank carries 1 / world of it), and a
+    prove under another share than the key's is refused -- mi_group_wire_range would tell a _dev caller a cut the key's parts do not have"""
+    log_n = 12
+    N = 1 << log_n
+    nb_wires, n_constraints = N - 50, N - 10
+    pk = synthetic_pk(log_n, nb_wires, 100, 8900)
+    W = cref.gen_scalars(nb_wires, 41, 1); a = cref.gen_scalars(n_constraints, 42, 1); b = cref.gen_scalars(n_constraints, 43, 0); c = cref.field_op(0, 2, a, b)
+    r, s = cref.gen_scalars(2, 44, 0)
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
+    g = B.Group([0] * 4)
+    try:
+        assert g.wire_range(nb_wires, 0) == (0, 0)                       # automatic, computeH on the lead, 4 ranks: no wires on the lead
+        g.set_sharded_compute_h(True)
+        assert g.wire_range(nb_wires, 0) == (0, nb_wires // 4)           # computeH over the ranks: the even cut
+        spk = g.pk_load(pk)
+        assert B.proof_write(g.prove(spk, W, a, b, c, r, s, mode=1)[0]["raw"]) == want
+        g.set_sharded_compute_h(False)                                    # the automatic share is 0 again: not this key's cut
+        with pytest.raises(B.MiError, match="reload the key"):
+            g.prove(spk, W, a, b, c, r, s, mode=1)
+        g.set_lead_share(1000)                                            # the key's own cut, stated explicitly: accepted (computeH on the lead)
+        assert B.proof_write(g.prove(spk, W, a, b, c, r, s, mode=0)[0]["raw"]) == want
+        g.pk_free(spk)
+    finally:
+        g.close()
+
+
 def test_sharded_msm_with_ranks_that_hold_no_pairs(B):
     """fewer pairs than ranks: some ranks' shares are EMPTY; mode 1 exchanges their (all-infinity) bucket arrays like any other"""
     g = B.Group([0, 0, 0])

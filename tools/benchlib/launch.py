@@ -56,3 +56,33 @@ def self_launch(n, argv):
     if bad or line is None:
         sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
         sys.exit(bad[0] if bad else 1)
+
+
+def require_gpus(n, rehearse):
+    """`--gpus N` means N ranks on N DISTINCT GPUs.  Before any rank touches a device: the node must show at least N (counting devices does not
+    initialise the GPU).  The one-GPU rehearsal of the multi-process code path says so explicitly (--rehearse-on-one-gpu)."""
+    if n <= 1 or rehearse:
+        return
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} needs {n} distinct GPUs and this node shows {have}: distinct_devices != n_gpus.  "
+                         "(For the multi-process code path on one GPU: --rehearse-on-one-gpu; its line says what it is.)")
+
+
+def observe_devices(torch, dist, local_rank, world, rehearse):
+    """What the run OBSERVED about its devices, for the line: every rank's PCI bus id, gathered over the ranks, and how many are distinct.
+    A multi-GPU run whose ranks do not sit on `world` distinct devices is refused here unless it is the declared rehearsal."""
+    pr = torch.cuda.get_device_properties(local_rank)
+    bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    all_bdf = [bdf]
+    if dist is not None and world > 1:
+        all_bdf = [None] * world
+        dist.all_gather_object(all_bdf, bdf)
+    distinct = len(set(all_bdf))
+    if world > 1 and distinct != world and not rehearse:
+        raise SystemExit(f"bench.py: {world} ranks sit on {distinct} distinct device(s) {sorted(set(all_bdf))}: distinct_devices != n_gpus (one rank per GPU is the contract; "
+                         "--rehearse-on-one-gpu for the declared one-GPU rehearsal)")
+    return {"distinct_devices": distinct, "device_pci_by_rank": all_bdf,
+            "torch_distributed": None if dist is None else {"backend": dist.get_backend(), "world_size": dist.get_world_size()},
+            "how": "torch.cuda.get_device_properties(local_rank) PCI ids of every rank, all-gathered; the device group's own view (hipDeviceGetPCIBusId, ncclCommCount) is in sharded_prove.observed"}

@@ -169,6 +169,8 @@ def sharded_helper_main():
             res["selftest"] = f"FAILED: {e}"
             raise
         res["transport"] = g.transport()
+        res["comm_ranks"] = g.comm_ranks()          # what ncclCommCount says (0: not RCCL)
+        res["device_pci"] = g.device_pci(0)         # the GPU this rank's group context really sits on
         if q["log_n"]:
             res["msm"] = sharded_msm_section(B, g, q["rank"], q["world"], q["log_n"], q["steps"])
         res["ok"] = True   # the MSM block is valid from here on, whatever the prove leg does
@@ -242,7 +244,23 @@ def run_sharded_legs(helper, B, torch, dist, rank, local_rank, world, args):
         w = [float(tmin[2]), float(tmax[2]), float(tmax[3]), float(tmax[4]), float(tmax[5])]
     n_msm = 1 << args.sharded_msm_log_n
     sharded["selftest"] = sharded_prove["selftest"] = res.get("selftest", "not run")
-    devices = "ONE device shared by all ranks (rehearsal: the multi-process code path, not a scaling measurement)" if args.rehearse_on_one_gpu else f"{world} device(s)"
+    # OBSERVED, not derived from `world`: every rank's PCI bus id (from its helper's group context) and the rank count its RCCL
+    # communicator reports, gathered over the ranks
+    obs = [(res.get("device_pci"), res.get("comm_ranks"))]
+    if dist is not None:
+        allobs = [None] * world
+        dist.all_gather_object(allobs, obs[0])
+        obs = allobs
+    pcis = [o[0] for o in obs if o and o[0]]
+    counts = sorted({o[1] for o in obs if o and o[1] is not None})
+    observed = {"distinct_devices": len(set(pcis)) if len(pcis) == world else None, "device_pci_by_rank": pcis,
+                "rccl_ranks_seen": None if transport != 1 else (counts[0] if len(counts) == 1 else counts),
+                "transport": res.get("transport"),
+                "how": "device_pci: hipDeviceGetPCIBusId of each rank's group context (mi_group_device_pci); rccl_ranks_seen: ncclCommCount of each rank's communicator "
+                       "(mi_group_comm_ranks; null under the host-staged rehearsal transport, which has no communicator)"}
+    sharded["observed"] = sharded_prove["observed"] = observed
+    devices = ("ONE device shared by all ranks (rehearsal: the multi-process code path, not a scaling measurement)" if args.rehearse_on_one_gpu
+               else f"{observed['distinct_devices']} distinct device(s) observed for {world} rank(s)")
     if v[0] == 1.0 and v[1] > 0 and v[2] > 0:
         sharded.update({"workload": f"one G1 MSM, 2^{args.sharded_msm_log_n} uniform pairs, bases point-sharded over {world} rank(s) (BASELINE configs[4])",
                         "scaling": "strong", "transport": res.get("transport"), "devices": devices, "steps": steps_msm, "process": "helper process per rank (own GPU context)",
