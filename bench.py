@@ -493,6 +493,23 @@ def main():
         ntt_solo = {"compute_h_ms": ms_h, "transforms": 6, "pass_launches": launches, "ms_per_transform": ms_h / 6.0}
     # VALU context for the roofline line: the chip's measured 256-bit Montgomery product rate (dependent chains, all CUs)
     modmul_ms = min(ctx.bench_modmul(1, 256 * 4096, 256) for _ in range(3)) if rank == 0 else 0.0
+    # ... and the TRUE cycles of a v_mad_u64_u32 (the instruction 71 % of the dominant kernel's cycles go to): eight waves per SIMD of
+    # independent multiply-accumulate chains for ~0.7 s under the clock sampler.  profiles/r02_probe_instr_rate.txt priced it at 5.28 cycles
+    # ASSUMING 2.4 GHz; the chip clocks lower under such a load, so every cycle figure derived from that table is scaled by this ratio
+    mad_probe = None
+    if rank == 0 and not args.no_clock_samples and not args.no_solo_legs:
+        thr, it = 256 * 4 * 8 * 64, 20000
+        ctx.bench_valu(0, thr, 256)
+        smp = ClockSampler(local_rank).start()
+        t_end, rates = time.perf_counter() + 0.7, []
+        while time.perf_counter() < t_end:
+            rates.append((thr / 64) * 8 * it / (ctx.bench_valu(0, thr, it) * 1e-3) / 1024.0)
+        ck = smp.stop()
+        if ck and rates:
+            rate = max(rates)
+            mad_probe = {"wave_instr_per_s_per_simd": rate, "sclk_mhz": ck["sclk_mhz_mean"], "cycles_per_mad": ck["sclk_mhz_mean"] * 1e6 / rate,
+                         "cycles_per_mad_if_2400_mhz": 2.4e9 / rate, "table_value_at_assumed_2400_mhz": 5.28,
+                         "how": "mi_bench_valu_dev kind 0 (eight independent v_mad_u64_u32 chains per lane, 8 waves per SIMD) back to back for 0.7 s; rocm-smi shader clock meanwhile"}
     # ... and the memory system's ceiling for what that kernel asks of it: dependent random 64-byte gathers from a table far larger
     # than the 256 MB Infinity Cache (8.6 GB of scratch: the Z MSM's window tables are 7 GB at N = 2^23, A+K's 15 GB)
     gather_ms = 0.0
@@ -538,12 +555,12 @@ def main():
         # HBM traffic per launch.  MEASURED BY THIS RUN when it can be (one GPU, no profiler around this process): child runs of
         # `rocprofv3 --pmc` (live_pmc above) over the solo Z-shaped launch and over four proofs of this workload alone on one context.
         # Otherwise -- and only for the profiled shape (N = 2^23, WHIR mix, automatic plans) with unchanged kernel sources -- the
-        # committed passes of profiles/r05_pmc_bench_traffic.json (sha256 of the sources recorded in it): a file older than the kernels
+        # committed passes of profiles/r06_pmc_bench_traffic.json (sha256 of the sources recorded in it): a file older than the kernels
         # reads as traffic: null, never as stale bytes.  The accumulate kernel gathers 64-B points, so its FETCH_SIZE is taken raw; the
         # NTT passes stream 16 B per lane, so theirs gets the guide's x2 correction.
         traffic = traffic_ntt = traffic_solo = None
         kname = "k_msm_accum_affine29"
-        pmc_file = os.path.join("profiles", "r05_pmc_bench_traffic.json")
+        pmc_file = os.path.join("profiles", "r06_pmc_bench_traffic.json")
         csrc = os.path.join(ROOT, "gnark-whir_amd", "csrc")
         pmc = None
         fresh_msm = fresh_ntt = False
@@ -589,13 +606,13 @@ def main():
             pmc_src_solo = (f"THIS RUN: child runs `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) over tools/solo_z_msm.py {log_n} 2 "
                             f"({live_solo['FETCH_SIZE'][kname]['launches']} launches each, {live_solo['seconds']:.0f} s)")
         # the level-1 kernel's own instruction-issue floor, from the committed ISA census of its code object (tools/isa_census.py ->
-        # profiles/r05_isa_census_accum_affine29.json: instructions per loop iteration by class x the measured cycles per wave64
+        # profiles/r06_isa_census_accum_affine29.json: instructions per loop iteration by class x the measured cycles per wave64
         # instruction of profiles/r02_probe_instr_rate.txt)
         issue_floor = census_src = None
         try:
-            cen = json.load(open(os.path.join(ROOT, "profiles", "r05_isa_census_accum_affine29.json")))
+            cen = json.load(open(os.path.join(ROOT, "profiles", "r06_isa_census_accum_affine29.json")))
             issue_floor = 2.4e9 / cen["cycles_per_addition"] * 64 * 1024
-            census_src = f"profiles/r05_isa_census_accum_affine29.json: {cen['valu_per_addition']} vector instructions per mixed addition ({cen['mad_u64_u32_per_addition']} v_mad_u64_u32) = {cen['cycles_per_addition']:.0f} cycles per wave-addition"
+            census_src = f"profiles/r06_isa_census_accum_affine29.json: {cen['valu_per_addition']} vector instructions per mixed addition ({cen['mad_u64_u32_per_addition']} v_mad_u64_u32) = {cen['cycles_per_addition']:.0f} cycles per wave-addition"
         except Exception:
             pass
         # roofline of the dominant kernel: achieved = the algorithmic 96 B per pair of ONE launch / that launch's duration.
@@ -607,11 +624,18 @@ def main():
                       "HBM roofline BASELINE.json's north_star asks to report; `valu_frac` is the roofline that binds")
         if zsolo and "accum_launch_ms" in zsolo:
             zmhz = zsolo.get("sclk_mhz_under_this_msm") or (clocks or {}).get("sclk_mhz_mean")
-            floor_meas = None if not (issue_floor and zmhz) else issue_floor * (zmhz * 1e6 / 2.4e9)
+            # the census's cycles per wave-addition come from a table that assumed 2.4 GHz: true cycles = table cycles x (true / table cycles of the mad)
+            # (the table's rate for this instruction: 4.542e8 wave-instructions/s/SIMD; today's probe may sustain another rate and runs at a KNOWN clock.
+            #  Floor under this MSM = census floor x today's rate / table rate x this MSM's clock / the probe's clock)
+            cyc_scale = None if not mad_probe else (mad_probe["wave_instr_per_s_per_simd"] / 4.542e8) / (mad_probe["sclk_mhz"] / 2400.0)
+            floor_meas = None if not (issue_floor and zmhz and cyc_scale) else issue_floor * (zmhz / 2400.0) * cyc_scale
             roofline = {"kernel": "k_msm_accum_affine29 (G1 level-1 bucket accumulate, 9 x 29-bit limbs)", "bound": "valu-issue", "bound_note": bound_note,
                         "valu_frac": None if not floor_meas else zsolo["mixed_adds_per_s"] / floor_meas,
                         "valu_frac_at_2400_mhz": None if not issue_floor else zsolo["mixed_adds_per_s"] / issue_floor,
-                        "valu_frac_basis": None if not floor_meas else f"{zsolo['mixed_adds_per_s'] / 1e9:.2f} G mixed additions/s / ({zmhz:.0f} MHz measured under this MSM x 65536 lanes / cycles per wave-addition of the ISA census)",
+                        "valu_frac_basis": None if not floor_meas else (f"{zsolo['mixed_adds_per_s'] / 1e9:.2f} G mixed additions/s / ({zmhz:.0f} MHz measured under this MSM x 65536 lanes / TRUE cycles per wave-addition: "
+                                                                        f"the ISA census's {cen['cycles_per_addition']:.0f} (priced at an assumed 2.4 GHz) / {cyc_scale:.3f}: today's multiply-accumulate probe sustained {mad_probe['wave_instr_per_s_per_simd'] / 1e8:.3f}e8 "
+                                                                        f"wave-instructions/s/SIMD at {mad_probe['sclk_mhz']:.0f} MHz = {mad_probe['cycles_per_mad']:.2f} true cycles against the table's 5.28)"),
+                        "mad_probe": mad_probe,
                         "traffic_ratio": None if not traffic_solo else traffic_solo / (96.0 * zsolo["pairs"]),
                         "basis": f"solo launch: the proof's largest level-1 launch (Z MSM: {zsolo['pairs']} uniform scalars, {zsolo['windows']} windows of {zsolo['window_bits']} bits, fixed-base tables) alone on the GPU",
                         "achieved": zsolo["accum_GBps_algorithmic"], "peak": 8000.0, "unit": "GB/s", "frac": zsolo["accum_GBps_algorithmic"] / 8000.0,
@@ -636,11 +660,11 @@ def main():
             else:
                 import csv
                 per_kernel = {}
-                for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_pmc_valu_proofs.csv"))):
+                for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_pmc_valu_proofs.csv"))):
                     k = _kernel_short(r["Kernel"])
                     if r["Counter"] == "SQ_INSTS_VALU" and not k.startswith(setup):
                         per_kernel[k] = per_kernel.get(k, 0.0) + float(r["Sum"]) / 4.0
-                valu_src = "profiles/r05_pmc_valu_proofs.csv (committed pass, not this run)"
+                valu_src = "profiles/r06_pmc_valu_proofs.csv (committed pass, not this run)"
                 if not (log_n == 23 and args.dist == "whir" and traffic is not None):
                     per_kernel = {}
             per_proof = sum(per_kernel.values())

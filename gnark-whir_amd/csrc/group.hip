@@ -131,7 +131,6 @@ static void range_of(u64 total, int world, int r, u64 &lo, u64 &hi) { lo = total
 static uint32_t lead_share_of(const mi_group *g) {
     if (g->lead_share <= 1000) return g->lead_share;
     const int w = g->world;
-    if (g->sharded_h) return 1000u;   // computeH over the ranks: every rank carries 1 / world of it, so the even cut is the balanced one
     return w <= 1 ? 1000u : w == 2 ? 500u : 0u;
 }
 static void wire_range_of(u64 nb_wires, int world, int r, uint32_t share, u64 &lo, u64 &hi) {
@@ -1336,7 +1335,7 @@ static int32_t prove_sharded_impl(mi_group *g, mi_pk_sharded *spk, bool host, co
     if (n_wires != spk->nb_wires || (lead_here && n_constraints > N)) note(MI_EINVAL, "prove: witness size does not match the proving key");
     if (mode == 1 && !spk->uniform) note(MI_EINVAL, "group: mode 1 needs every part of the key to use the same MSM plan");
     // (mi_group_wire_range answers with the group's CURRENT share: a caller of the _dev entry points would cut W unlike the key's parts)
-    if (lead_share_of(g) != spk->lead_share) note(MI_EINVAL, "group: the lead's wire share (mi_group_set_lead_share / mi_group_set_sharded_compute_h) changed since this key was loaded: reload the key");
+    if (lead_share_of(g) != spk->lead_share) note(MI_EINVAL, "group: the lead's wire share (mi_group_set_lead_share) changed since this key was loaded: reload the key");
     // workspaces, each on its own device: W slice (+ a, b, c on the lead) for host inputs; h (whole on the lead, a slice elsewhere)
     for (int i = 0; i < nl && lrc == MI_OK; i++) {
         (void)hipSetDevice(g->dev[i]);

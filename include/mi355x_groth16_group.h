@@ -59,9 +59,9 @@ int32_t mi_group_destroy(mi_group *g);
  * its Z MSM before h exists, so a lead that carries an equal share of the wire MSMs lengthens the critical path of the proof.
  * permille = the fraction of an even share (nb_wires / world) that rank 0 takes, 0..1000; the other ranks split the rest evenly; the
  * N - 1 pairs of the Z MSM are always cut evenly.  1000 = the even cut.  MI_LEAD_SHARE_AUTO (the default): 1000 for one rank, 500 for
- * two, 0 from three ranks on -- from the measured ratio computeH : wire MSMs = 1 : 2 at N = 2^26 -- and 1000 whatever the
- * world while mi_group_set_sharded_compute_h is on (computeH is then every rank's, 1 / world each).  A key remembers the share it was cut
- * with: a prove under another one returns MI_EINVAL ("reload the key").  Set it -- to the same
+ * two, 0 from three ranks on -- from the measured ratio computeH : wire MSMs = 1 : 2 at N = 2^26; with computeH over the
+ * ranks (mi_group_set_sharded_compute_h) the balanced cut is the even one: say 1000.  A key remembers the share it was cut with: a prove
+ * under another one returns MI_EINVAL ("reload the key").  Set it -- to the same
  * value in every process -- BEFORE mi_pk_load_sharded*: the key's parts are cut by it (a disagreement fails that load on every rank),
  * and a caller that passes device slices (mi_pk_load_sharded_dev, mi_groth16_prove_sharded_dev) cuts its arrays by
  * mi_group_wire_range.  Same proofs whatever the share. */

@@ -342,8 +342,8 @@ def test_lead_share_of_the_wires_gives_the_same_proof(B, grp, share, mode):
 
 
 def test_a_key_remembers_the_wire_cut_it_was_loaded_with(B):
-    """the automatic lead share is the even cut while computeH runs over the ranks (every rank carries 1 / world of it), and a
-    prove under another share than the key's is refused -- mi_group_wire_range would tell a _dev caller a cut the key's parts do not have"""
+    """a prove under another lead share than the key's is refused -- mi_group_wire_range answers with the group's CURRENT share,
+    so a caller of the _dev entry points would cut W unlike the key's parts -- and accepted again once the share is the key's"""
     log_n = 12
     N = 1 << log_n
     nb_wires, n_constraints = N - 50, N - 10
@@ -353,15 +353,18 @@ def test_a_key_remembers_the_wire_cut_it_was_loaded_with(B):
     want = cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])
     g = B.Group([0] * 4)
     try:
-        assert g.wire_range(nb_wires, 0) == (0, 0)                       # automatic, computeH on the lead, 4 ranks: no wires on the lead
-        g.set_sharded_compute_h(True)
-        assert g.wire_range(nb_wires, 0) == (0, nb_wires // 4)           # computeH over the ranks: the even cut
+        assert g.wire_range(nb_wires, 0) == (0, 0)                       # automatic, 4 ranks: no wires on the lead
         spk = g.pk_load(pk)
         assert B.proof_write(g.prove(spk, W, a, b, c, r, s, mode=1)[0]["raw"]) == want
-        g.set_sharded_compute_h(False)                                    # the automatic share is 0 again: not this key's cut
-        with pytest.raises(B.MiError, match="reload the key"):
-            g.prove(spk, W, a, b, c, r, s, mode=1)
-        g.set_lead_share(1000)                                            # the key's own cut, stated explicitly: accepted (computeH on the lead)
+        g.set_sharded_compute_h(True)                                     # computeH over the ranks on the same key: the cut does not move
+        assert B.proof_write(g.prove(spk, W, a, b, c, r, s, mode=1)[0]["raw"]) == want
+        g.set_sharded_compute_h(False)
+        g.set_lead_share(1000)                                            # not this key's cut any more
+        assert g.wire_range(nb_wires, 0) == (0, nb_wires // 4)
+        for mode in (0, 1):
+            with pytest.raises(B.MiError, match="reload the key"):
+                g.prove(spk, W, a, b, c, r, s, mode=mode)
+        g.set_lead_share(0)                                               # the key's own cut, stated explicitly: accepted
         assert B.proof_write(g.prove(spk, W, a, b, c, r, s, mode=0)[0]["raw"]) == want
         g.pk_free(spk)
     finally:

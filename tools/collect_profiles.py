@@ -1,4 +1,4 @@
-"""Turns the raw outputs of the round's final measurement run (gpurun_out/r5_*, tools/final_measure.sh) into the committed summaries under
+"""Turns the raw outputs of the round's final measurement run (gpurun_out/r6_*, tools/final_measure.sh) into the committed summaries under
 profiles/.  usage: python tools/collect_profiles.py"""
 import glob
 import hashlib
@@ -31,21 +31,21 @@ def sha16(path):
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-for src, dst in ((G + "r5_bench_final.log", "profiles/r05_bench_line_final.json"), (G + "r5_prof_def.log", "profiles/r05_bench_line_profiled_default.json"),
-                 (G + "r5_prof_if1.log", "profiles/r05_bench_line_profiled_inflight1.json"), (G + "r5_bench26_final.log", "profiles/r05_bench_line_N2p26.json"),
-                 (G + "r5_rehearse2.log", "profiles/r05_bench_line_rehearsal_2ranks_one_gpu.json")):
+for src, dst in ((G + "r6_bench_final.log", "profiles/r06_bench_line_final.json"), (G + "r6_prof_def.log", "profiles/r06_bench_line_profiled_default.json"),
+                 (G + "r6_prof_if1.log", "profiles/r06_bench_line_profiled_inflight1.json"), (G + "r6_bench26_final.log", "profiles/r06_bench_line_N2p26.json"),
+                 (G + "r6_rehearse2.log", "profiles/r06_bench_line_rehearsal_2ranks_one_gpu.json")):
     if not os.path.exists(src):
         print("missing", src); continue
     l = line(src); open(dst, "w").write(l); d = json.loads(l)
     print(dst, {k: round(d[k], 3) if isinstance(d.get(k), float) else d.get(k) for k in ("value", "ms_per_step", "value_hbm_resident_inputs", "single_proof_latency_ms", "single_proof_latency_host_inputs_ms", "hbm_in_use_gb")},
           "launch_ms", round(d["roofline"]["launch_ms"], 2), "frac", round(d["roofline"]["frac"], 4), "ntt frac", round(d["roofline_ntt"]["frac"], 4))
-for d_, out in (("r5_prof_def", "profiles/r05_kernel_stats_default.csv"), ("r5_prof_if1", "profiles/r05_kernel_stats_inflight1.csv"),
-                ("r5_prof_solo_z", "profiles/r05_kernel_stats_solo_z.csv")):   # (solo_z: the launch the roofline line is quoted on, alone: its average must agree with roofline.launch_ms)
+for d_, out in (("r6_prof_def", "profiles/r06_kernel_stats_default.csv"), ("r6_prof_if1", "profiles/r06_kernel_stats_inflight1.csv"),
+                ("r6_prof_solo_z", "profiles/r06_kernel_stats_solo_z.csv")):   # (solo_z: the launch the roofline line is quoted on, alone: its average must agree with roofline.launch_ms)
     if os.path.isdir(G + d_):
         subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "stats", db(d_), out], stdout=subprocess.DEVNULL)
-if os.path.isdir(G + "r5_pmc_fetch") and os.path.isdir(G + "r5_pmc_write"):
+if os.path.isdir(G + "r6_pmc_fetch") and os.path.isdir(G + "r6_pmc_write"):
     out = {}
-    for name, d_ in (("FETCH_SIZE", "r5_pmc_fetch"), ("WRITE_SIZE", "r5_pmc_write")):
+    for name, d_ in (("FETCH_SIZE", "r6_pmc_fetch"), ("WRITE_SIZE", "r6_pmc_write")):
         c = sqlite3.connect(db(d_))
         agg = defaultdict(lambda: [set(), 0.0])
         for k, did, v in c.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=?", (name,)):
@@ -56,9 +56,9 @@ if os.path.isdir(G + "r5_pmc_fetch") and os.path.isdir(G + "r5_pmc_write"):
     out["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 bench.py --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-hbm-resident "
                     "--sharded-msm-log-n 0 --sharded-prove-log-n 0 --no-sensitivity --no-solo-legs --n-committed 0` (no commitment: the per-launch averages are those of the proof's own MSMs), N=2^23, final round-5 code (_sources: sha256[:16] of the kernel sources the passes ran on; bench.py withholds "
                     "`traffic` when they differ); KB as rocprofv3 reports them, summed over the counter's dimensions; FETCH_SIZE raw (64-B gathers need no correction; 16-B-per-lane streams need x2)")
-    if os.path.isdir(G + "r5_pmc_solo_fetch") and os.path.isdir(G + "r5_pmc_solo_write"):   # the solo Z-shaped launch (tools/solo_z_msm.py): the roofline line's basis
+    if os.path.isdir(G + "r6_pmc_solo_fetch") and os.path.isdir(G + "r6_pmc_solo_write"):   # the solo Z-shaped launch (tools/solo_z_msm.py): the roofline line's basis
         solo = {}
-        for name, d_ in (("FETCH_SIZE", "r5_pmc_solo_fetch"), ("WRITE_SIZE", "r5_pmc_solo_write")):
+        for name, d_ in (("FETCH_SIZE", "r6_pmc_solo_fetch"), ("WRITE_SIZE", "r6_pmc_solo_write")):
             c = sqlite3.connect(db(d_))
             tot, ids = 0.0, set()
             for k, did, v in c.execute("select kernel_name, dispatch_id, value from counters_collection where counter_name=?", (name,)):
@@ -67,14 +67,14 @@ if os.path.isdir(G + "r5_pmc_fetch") and os.path.isdir(G + "r5_pmc_write"):
             solo[name + "_kb"] = tot / max(1, len(ids)); solo["launches_" + name] = len(ids)
         solo["what"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `python3 tools/solo_z_msm.py 23 2`: KB per launch of k_msm_accum_affine29 (the Z-shaped fixed-base MSM alone on the GPU)"
         out["solo_z"] = solo
-    json.dump(out, open("profiles/r05_pmc_bench_traffic.json", "w"), indent=1)
+    json.dump(out, open("profiles/r06_pmc_bench_traffic.json", "w"), indent=1)
     for k in ("k_msm_accum_affine29", "k_ntt_pass_wave", "k_msm2_scatter2_staged"):
         if k not in out["FETCH_SIZE"]:
             continue
         print(k, "fetch MB/launch", round(out["FETCH_SIZE"][k]["kb_per_launch"] / 1e3, 1), "write", round(out["WRITE_SIZE"].get(k, {"kb_per_launch": 0})["kb_per_launch"] / 1e3, 1))
-if os.path.isdir(G + "r5_pmc_valu"):
-    subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "pmc", db("r5_pmc_valu"), "profiles/r05_pmc_valu_proofs.csv"], stdout=subprocess.DEVNULL)
-p = G + "r5_bench_final.log"
+if os.path.isdir(G + "r6_pmc_valu"):
+    subprocess.check_call([sys.executable, "tools/rocpd_summary.py", "pmc", db("r6_pmc_valu"), "profiles/r06_pmc_valu_proofs.csv"], stdout=subprocess.DEVNULL)
+p = G + "r6_bench_final.log"
 if os.path.exists(p):
     d = json.loads(line(p))
     sens = d.get("sensitivity")
@@ -86,6 +86,6 @@ if os.path.exists(p):
             x = sens[key]
             rows.append(f"witness `{key}`".ljust(22) + f": value {x['value']:.2f} proofs/s, HBM-resident {x['value_hbm_resident_inputs']:.2f}, single proof {x['single_proof_latency_ms']:.2f} ms, "
                         f"G1 level-1 additions per proof {x['g1_level1_additions_per_proof'] / 1e6:.1f} M")
-        open("profiles/r05_scalar_mix.txt", "w").write("the `sensitivity` block of profiles/r05_bench_line_final.json (python bench.py, defaults: N = 2^23, three proofs in flight, the step = Commit + host-input prove "
+        open("profiles/r06_scalar_mix.txt", "w").write("the `sensitivity` block of profiles/r06_bench_line_final.json (python bench.py, defaults: N = 2^23, three proofs in flight, the step = Commit + host-input prove "
                                                         "with the PoK; same key, same box, same run; every proof compared with its leg's reference proof)\n" + "\n".join(rows) + "\n")
         print("\n".join(rows))

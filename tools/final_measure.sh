@@ -10,24 +10,24 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
 Q="--no-cpu-baseline --no-live-pmc --sharded-msm-log-n 0 --sharded-prove-log-n 0"
 case "$1" in
-1)  timeout -k 10 600 python3 bench.py > $O/r5_bench_final.log 2>&1; tail -c 300 $O/r5_bench_final.log ;;
-1b) rm -rf $O/r5_prof_def
-    timeout -k 10 400 rocprofv3 --kernel-trace -d $O/r5_prof_def -o d -- python3 bench.py $Q --no-hbm-resident --no-sensitivity > $O/r5_prof_def.log 2>&1; tail -c 200 $O/r5_prof_def.log ;;
-2)  rm -rf $O/r5_prof_if1 $O/r5_pmc_fetch $O/r5_pmc_write
-    timeout -k 10 300 rocprofv3 --kernel-trace -d $O/r5_prof_if1 -o i -- python3 bench.py --in-flight 1 --steps 10 $Q --no-hbm-resident --no-sensitivity > $O/r5_prof_if1.log 2>&1
+1)  timeout -k 10 600 python3 bench.py > $O/r6_bench_final.log 2>&1; tail -c 300 $O/r6_bench_final.log ;;
+1b) rm -rf $O/r6_prof_def
+    timeout -k 10 400 rocprofv3 --kernel-trace -d $O/r6_prof_def -o d -- python3 bench.py $Q --no-hbm-resident --no-sensitivity > $O/r6_prof_def.log 2>&1; tail -c 200 $O/r6_prof_def.log ;;
+2)  rm -rf $O/r6_prof_if1 $O/r6_pmc_fetch $O/r6_pmc_write
+    timeout -k 10 300 rocprofv3 --kernel-trace -d $O/r6_prof_if1 -o i -- python3 bench.py --in-flight 1 --steps 10 $Q --no-hbm-resident --no-sensitivity > $O/r6_prof_if1.log 2>&1
     # (--n-committed 0: the per-launch averages of k_msm_accum_affine29 must be those of the proof's four MSMs, not mixed with the two small Pedersen launches)
-    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/r5_pmc_fetch -o f -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 $Q --no-hbm-resident --no-sensitivity --no-solo-legs --n-committed 0 > $O/r5_pmc_fetch.log 2>&1
-    timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/r5_pmc_write -o w -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 $Q --no-hbm-resident --no-sensitivity --no-solo-legs --n-committed 0 > $O/r5_pmc_write.log 2>&1
-    tail -c 200 $O/r5_pmc_write.log ;;
-3)  rm -rf $O/r5_pmc_valu
-    timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU -d $O/r5_pmc_valu -o v -- python3 tools/prof_proof.py 23 4 > $O/r5_pmc_valu.log 2>&1; tail -1 $O/r5_pmc_valu.log | cut -c1-200 ;;
-4)  timeout -k 10 900 python3 bench.py --log-n 26 --steps 6 --warmup 1 > $O/r5_bench26_final.log 2>&1; tail -c 300 $O/r5_bench26_final.log ;;
-5)  timeout -k 10 400 python3 bench.py --gpus 2 --rehearse-on-one-gpu --log-n 20 --steps 10 --no-cpu-baseline --sharded-msm-log-n 22 --sharded-prove-log-n 20 > $O/r5_rehearse2.log 2>&1; tail -c 200 $O/r5_rehearse2.log ;;
-6)  rm -rf $O/r5_pmc_solo_fetch $O/r5_pmc_solo_write
-    timeout -k 10 200 python3 tools/solo_z_msm.py 23 3 > $O/r5_solo_z.log 2>&1
-    timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/r5_pmc_solo_fetch -o f -- python3 tools/solo_z_msm.py 23 2 > $O/r5_pmc_solo_fetch.log 2>&1
-    timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/r5_pmc_solo_write -o w -- python3 tools/solo_z_msm.py 23 2 > $O/r5_pmc_solo_write.log 2>&1
-    rm -rf $O/r5_prof_solo_z
-    timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/r5_prof_solo_z -o s -- python3 tools/solo_z_msm.py 23 5 > $O/r5_prof_solo_z.log 2>&1
-    tail -2 $O/r5_solo_z.log ;;
+    timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $O/r6_pmc_fetch -o f -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 $Q --no-hbm-resident --no-sensitivity --no-solo-legs --n-committed 0 > $O/r6_pmc_fetch.log 2>&1
+    timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d $O/r6_pmc_write -o w -- python3 bench.py --in-flight 1 --steps 2 --warmup 1 $Q --no-hbm-resident --no-sensitivity --no-solo-legs --n-committed 0 > $O/r6_pmc_write.log 2>&1
+    tail -c 200 $O/r6_pmc_write.log ;;
+3)  rm -rf $O/r6_pmc_valu
+    timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU -d $O/r6_pmc_valu -o v -- python3 tools/prof_proof.py 23 4 > $O/r6_pmc_valu.log 2>&1; tail -1 $O/r6_pmc_valu.log | cut -c1-200 ;;
+4)  timeout -k 10 900 python3 bench.py --log-n 26 --steps 6 --warmup 1 > $O/r6_bench26_final.log 2>&1; tail -c 300 $O/r6_bench26_final.log ;;
+5)  timeout -k 10 400 python3 bench.py --gpus 2 --rehearse-on-one-gpu --log-n 20 --steps 10 --no-cpu-baseline --sharded-msm-log-n 22 --sharded-prove-log-n 20 > $O/r6_rehearse2.log 2>&1; tail -c 200 $O/r6_rehearse2.log ;;
+6)  rm -rf $O/r6_pmc_solo_fetch $O/r6_pmc_solo_write
+    timeout -k 10 200 python3 tools/solo_z_msm.py 23 3 > $O/r6_solo_z.log 2>&1
+    timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $O/r6_pmc_solo_fetch -o f -- python3 tools/solo_z_msm.py 23 2 > $O/r6_pmc_solo_fetch.log 2>&1
+    timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $O/r6_pmc_solo_write -o w -- python3 tools/solo_z_msm.py 23 2 > $O/r6_pmc_solo_write.log 2>&1
+    rm -rf $O/r6_prof_solo_z
+    timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/r6_prof_solo_z -o s -- python3 tools/solo_z_msm.py 23 5 > $O/r6_prof_solo_z.log 2>&1
+    tail -2 $O/r6_solo_z.log ;;
 esac

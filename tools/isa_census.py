@@ -1,6 +1,6 @@
 """ISA census of the dominant kernel, k_msm_accum_affine29 (G1 level-1 bucket accumulate, csrc/msm_g1.hip): vector instructions per
 mixed addition by class, from the gfx950 assembly hipcc emits for the shipped source, priced with the measured cycles per wave64
-instruction of profiles/r02_probe_instr_rate.txt.  bench.py reads the result (profiles/r05_isa_census_accum_affine29.json) for the
+instruction of profiles/r02_probe_instr_rate.txt.  bench.py reads the result (profiles/r06_isa_census_accum_affine29.json) for the
 kernel's instruction-issue floor (`valu.issue_floor_adds_per_s`) instead of a literal.
 
     python tools/isa_census.py            (no GPU needed: hipcc cross-compiles; ~15 s)
@@ -28,7 +28,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gnark-whir_amd", "csrc", "msm_g1.hip")
 KERNEL = "k_msm_accum_affine29"
-OUT = os.path.join(ROOT, "profiles", "r05_isa_census_accum_affine29.json")
+OUT = os.path.join(ROOT, "profiles", "r06_isa_census_accum_affine29.json")
 INSTANCE = "ILi4ELi3EE"   # <WG = 4 waves per workgroup, WPS = 3 waves per SIMD>: the default build (csrc/msm_g1.hip)
 
 

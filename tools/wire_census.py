@@ -186,7 +186,7 @@ def census(p: Params, hash_cost="lo"):
     # ---------------- one Merkle multi-proof (mtUtilities.go:109-141)
     def merkle(nl, height, where):
         c, w = to_binary(height)
-        add(f"Merkle {where}: ToBinary(leaf index, height)", "mtUtilities.go:114", nl * c, {k: nl * v for k, v in w.items()}, in_a=nl * height, in_b=0, a_cls="bit", b_cls="bit")
+        add(f"Merkle {where}: ToBinary(leaf index, height)", "mtUtilities.go:114", nl * c, {k: nl * v for k, v in w.items()}, in_a=nl * height, in_b=nl * height, a_cls="bit", b_cls="bit")   # (booleanity b (1 - b) = 0 puts a bit on both sides)
         unknown(f"Merkle {where}: leaf Compress chain ({leaf_len - 1} a leaf) + one Compress a level", "mtUtilities.go:116-119,125,136", "skyscraper.Compress", nl * (leaf_len - 1 + height))
         # two Selects a level (bit x (full - full)); the And with the constant 1 is free
         add(f"Merkle {where}: left / right Select a level + root equality", "mtUtilities.go:122-123,132-134,138", nl * (2 * height + 1), {"full": nl * 2 * height}, a_cls="bit", b_cls="full")
@@ -200,11 +200,11 @@ def census(p: Params, hash_cost="lo"):
         nbytes = (max(1, p.tree_height(0)) + 7) // 8
         unknown(f"STIR challenge bytes {where} (Arthur)", "mtUtilities.go:34-35", "arthur.challenge_bytes32", math.ceil(nq * nbytes / 32))
         c, w = to_binary(254)
-        add(f"GetStirChallenges {where}: ToBinary(full width) a query", "mtUtilities.go:48", nq * c, {k: nq * v for k, v in w.items()}, in_a=nq * 254, in_b=0, a_cls="bit", b_cls="bit")
+        add(f"GetStirChallenges {where}: ToBinary(full width) a query", "mtUtilities.go:48", nq * c, {k: nq * v for k, v in w.items()}, in_a=nq * 254, in_b=nq * 254, a_cls="bit", b_cls="bit")
 
     def exponent(nl, where):
         c, w = to_binary(254)
-        add(f"Exponent a leaf {where}: ToBinary(full width)", "utilities.go:154; mt.go:101,114; mtUtilities.go:217", nl * c, {k: nl * v for k, v in w.items()}, in_a=nl * 254, in_b=0, a_cls="bit", b_cls="bit")
+        add(f"Exponent a leaf {where}: ToBinary(full width)", "utilities.go:154; mt.go:101,114; mtUtilities.go:217", nl * c, {k: nl * v for k, v in w.items()}, in_a=nl * 254, in_b=nl * 254, a_cls="bit", b_cls="bit")
         add(f"Exponent a leaf {where}: product, Select, squaring a bit", "utilities.go:156-159", nl * 3 * 254, {"full": nl * 3 * 254}, a_cls="full", b_cls="full")
 
     def pow_check(where):
