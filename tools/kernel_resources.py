@@ -45,8 +45,46 @@ def kernels_of(src):
     return res
 
 
+def scratch_blocks(src, needle):
+    """WHERE a kernel's scratch is touched: per basic block of the kernel whose mangled name contains `needle`, the instruction lines, the
+    v_mad_u64_u32 among them (the hot path of the curve arithmetic is where the multiplies are) and the scratch_load / scratch_store
+    instructions.  A private segment that only cold blocks touch costs its allocation, not time.
+        python tools/kernel_resources.py --scratch-blocks k_msm_accum_xyzz29 gnark-whir_amd/csrc/msm_g1.hip"""
+    import bisect
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "x.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S", src, "-o", asm], stderr=subprocess.DEVNULL)
+        L = open(asm).read().split("\n")
+    starts = [i for i, l in enumerate(L) if re.match(r"^_Z\w+:", l) and needle in l.split(":")[0]]
+    for st in starts:
+        sym = L[st].split(":")[0]
+        end = next(i for i in range(st, len(L)) if L[i].strip().startswith(".Lfunc_end"))
+        body = L[st:end]
+        labels = [(i, l.split(":")[0]) for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
+        idx = [i for i, _ in labels]
+        stat = {}
+        for i, l in enumerate(body):
+            if not l.startswith("\t") or l.lstrip().startswith((";", ".")):
+                continue
+            k = bisect.bisect_right(idx, i) - 1
+            name = labels[k][1] if k >= 0 else "entry"
+            s = stat.setdefault(name, [0, 0, 0])
+            s[0] += 1
+            s[1] += "v_mad_u64_u32" in l
+            s[2] += "scratch_" in l
+        tot = [sum(v[j] for v in stat.values()) for j in range(3)]
+        print(f"{demangle([sym])[sym][:110]}")
+        print(f"  {len(stat)} basic blocks, {tot[0]} instructions, {tot[1]} v_mad_u64_u32, {tot[2]} scratch instructions; blocks with >= 100 multiplies or any scratch access:")
+        print(f"  {'block':12s} {'instructions':>12s} {'v_mad_u64_u32':>14s} {'scratch':>8s}")
+        for name in ["entry"] + [n for _, n in labels]:
+            if name in stat and (stat[name][1] >= 100 or stat[name][2]):
+                print(f"  {name:12s} {stat[name][0]:12d} {stat[name][1]:14d} {stat[name][2]:8d}")
+
+
 def main():
     args = sys.argv[1:]
+    if args and args[0] == "--scratch-blocks":
+        return scratch_blocks(args[2], args[1])
     out_json = None
     if args and args[0] == "--json":
         out_json = args[1]
