@@ -674,8 +674,19 @@ def main():
                              "on_the_callers_path": per_proof / (dt / args.steps) / 6.4e11,
                              "hbm_resident_inputs": None if dev_ms is None else per_proof / (dev_ms * 1e-3) / 6.4e11,
                              # the same two at the shader clock the chip sustained during the HBM-resident region (1024 SIMDs x sclk / 3.84 cycles)
-                             "at_measured_sclk": None if not clocks else {"sclk_mhz": clocks["sclk_mhz_mean"], "on_the_callers_path": per_proof / (dt / args.steps) / (1024 * clocks["sclk_mhz_mean"] * 1e6 / 3.84),
-                                                                          "hbm_resident_inputs": None if dev_ms is None else per_proof / (dev_ms * 1e-3) / (1024 * clocks["sclk_mhz_mean"] * 1e6 / 3.84)},
+                             # The 3.84 cycles come from a rate table that ASSUMED 2.4 GHz (profiles/r02_probe_instr_rate.txt) while such loads run at
+                             # ~2.2 GHz: the table's cycles are too many by true / table cycles of its own multiply-accumulate row, which this run
+                             # measures at a KNOWN clock (mad_probe).  Round 5's `at_measured_sclk` scaled the 6.4e11 by the job's clock without that
+                             # correction -- counting the clock twice, 8-10 % too flattering; it stays as `..._r5_definition` for continuity.
+                             "at_measured_sclk": None if not (clocks and mad_probe) else (lambda rate: {
+                                 "sclk_mhz": clocks["sclk_mhz_mean"], "true_over_table_cycles": mad_probe["cycles_per_mad"] / 5.28, "sustained_wave_instructions_per_s": rate,
+                                 "on_the_callers_path": per_proof / (dt / args.steps) / rate,
+                                 "hbm_resident_inputs": None if dev_ms is None else per_proof / (dev_ms * 1e-3) / rate,
+                                 "how": "1024 SIMDs x the job's shader clock / (3.84 table cycles x true / table cycles of v_mad_u64_u32 measured by this run's probe at a known clock)"})(
+                                     1024 * clocks["sclk_mhz_mean"] * 1e6 / (3.84 * mad_probe["cycles_per_mad"] / 5.28)),
+                             "at_measured_sclk_r5_definition": None if not clocks else {"sclk_mhz": clocks["sclk_mhz_mean"], "on_the_callers_path": per_proof / (dt / args.steps) / (1024 * clocks["sclk_mhz_mean"] * 1e6 / 3.84),
+                                                                          "hbm_resident_inputs": None if dev_ms is None else per_proof / (dev_ms * 1e-3) / (1024 * clocks["sclk_mhz_mean"] * 1e6 / 3.84),
+                                                                          "note": "counts the clock twice (see above): not comparable with a utilisation"},
                              "shares": {"g1_level1": share("k_msm_accum_affine29"), "g2_level1": share("k_msm_accum_affine_g2_29"), "ntt": share("k_ntt_"),
                                         "upper_levels_and_finisher": share("k_msm_accum_xyzz", "k_msm_finish"), "sorts": share("k_msm2_", "k_scan_"),
                                         "reduces": share("k_msm_bucket_reduce", "k_msm_sum_tree")},
