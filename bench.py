@@ -76,9 +76,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)   # ~1 s of proofs: one rare runtime hiccup then moves the result by < 2 %
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=23, help="FFT domain (2^23 = BASELINE configs[1])")
-    ap.add_argument("--dist", choices=["whir", "half", "uniform", "census"], default="whir",
+    ap.add_argument("--dist", type=lambda v: v if v in ("whir", "half", "uniform", "census") or v.startswith("mix:") else ap.error(f"--dist {v}"), default="whir",
                     help="witness (W, a) distribution: the WHIR mix of SURVEY 8d / BASELINE.md 3 (a documented guess), uniform Fr, half of each (row by row), or "
-                         "`census`: the midpoint mix tools/wire_census.py derives from the reference's circuit (profiles/r06_wire_census.txt)")
+                         "`census`: the midpoint mix tools/wire_census.py derives from the reference's circuit (profiles/r06_wire_census.txt), or mix:BIT,BYTE,U64 = per-mille "
+                         "shares of one's own census (tools/wire_census.py --params FILE prints them); the rest full-width")
     ap.add_argument("--no-solo-legs", action="store_true", help="skip the solo MSM / computeH / probe legs after the proofs (PMC passes: their launches would mix into the per-kernel averages); the roofline line then falls back to the in-job launch")
     ap.add_argument("--no-sensitivity", action="store_true", help="skip the `sensitivity` legs (the same key proved with a half-uniform and a uniform witness)")
     ap.add_argument("--stream-plan", type=int, default=-1, help="tuning: mi_debug_set_stream_plan before the pool is created (0, 1, 2; -1 = the library's default)")

@@ -75,6 +75,32 @@ def test_prove_bytes_equal_oracle_at_baseline_size(ctx, case, knob, label):
     assert len(B.proof_write(got["raw"])) == 164
 
 
+def test_census_witness_at_baseline_size_equals_oracle(ctx, case):
+    """The same key at N = 2^23 with the witness mix tools/wire_census.py derives from the reference's circuit (74 % of the wire values
+    full-width, mtUtilities.go:494-532; MI_DIST_MIX through the device generator = cref's): 2.6 x the level-1 additions of the BASELINE mix
+    through the production plan (fixed-base tables, c = 19 / 17 / 20), c formed on the device: proof bytes == oracle proof bytes"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import wire_census
+    B = load_binding()
+    dist = B.dist_mix(*wire_census.census_mix_permille())
+    pk, nc = case["pk"], case["n_constraints"]
+    nw = pk["nb_wires"]
+    W = ctx.gen_scalars(nw, 808, dist).download((nw, 4)); a = ctx.gen_scalars(nc, 809, dist).download((nc, 4))
+    assert np.array_equal(W[:3000], cref.gen_scalars(3000, 808, dist))
+    b = case["b"]
+    c = cref.field_op(0, 2, a, b)
+    t0 = time.perf_counter()
+    want = cref.proof_write(cref.prove(pk, W, a, b, c, case["r"], case["s"])["raw"])
+    print(f"oracle prove, census mix, N=2^{LOG_N}: {time.perf_counter() - t0:.1f} s")
+    pkh = ctx.pk_load(pk)
+    got, st = ctx.prove(pkh, W, a, b, None, case["r"], case["s"])
+    ctx.pk_free(pkh)
+    assert B.proof_write(got["raw"]) == want
+    assert st["g1_level1_additions"] > 300e6, "the dense regime: > 300 M G1 level-1 additions a proof (BASELINE mix: ~200 M)"
+
+
 def test_compute_h_equals_oracle_at_baseline_size(ctx, case):
     """all 2^23 coefficients of h (bit-reversed order, as gnark leaves them) against the oracle's"""
     got = ctx.compute_h(LOG_N, case["a"], case["b"], case["c"])

@@ -65,3 +65,20 @@ def test_every_term_cites_the_reference_and_unknowns_are_bounded_not_priced():
     txt = wc.report()
     committed = open(os.path.join(ROOT, "profiles", "r06_wire_census.txt")).read()
     assert txt.strip() == committed.strip(), "profiles/r06_wire_census.txt is not what tools/wire_census.py prints: python tools/wire_census.py --write profiles/r06_wire_census.txt"
+
+
+def test_census_of_a_concrete_params_file():
+    """`tools/wire_census.py --params FILE`: the census of ONE configuration as ProveKit's params file states it (main.go:41-58) -- queries,
+    OOD samples and PoW bits per round taken from the file, not from the WHIR formulas; here the committed params fixture of the ingestion tests"""
+    import json
+    cfg = json.loads(json.load(open(os.path.join(ROOT, "tests", "golden", "whir_params_small.json")))["text"])
+    p = wc.Params.from_config(cfg, nnz_total=3 * 5 * (1 << 17), batch=2)
+    assert p.n_rounds == 4 and [p.queries(r) for r in range(5)] == [103, 46, 30, 23, 18] and [p.ood_at(r) for r in range(4)] == [2, 2, 1, 1]
+    assert [p.pow_at(r) for r in range(5)] == [18, 20, 22, 22, 21] and abs(p.nnz_per_row - 5.0) < 1e-9
+    E, info = wc.census(p, "lo")
+    calls = wc.totals(E, "lo")[3]
+    # Merkle: 2 first-round trees x 103 leaves x (15 + 17) + 46 x (15 + 16) + 30 x (15 + 15) + 23 x (15 + 14); PoW: one Compress a round + final
+    assert calls["skyscraper.Compress"] == 2 * 103 * 32 + 46 * 31 + 30 * 30 + 23 * 29 + 5
+    assert info["transcript_len"] == cfg["transcript_len"]
+    txt = wc.report_config(cfg, None, 1)
+    assert "ASSUMED" in txt and "--dist mix:" in txt

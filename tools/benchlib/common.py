@@ -28,6 +28,8 @@ def dist_id_of(B, name):
     `uniform`, `census` = the midpoint mix tools/wire_census.py derives from the reference's circuit (profiles/r06_wire_census.txt)"""
     if name == "uniform":
         return B.DIST_UNIFORM
+    if name.startswith("mix:"):   # a user's own census (tools/wire_census.py --params ...): per-mille of bits, bytes, 64-bit values
+        return B.dist_mix(*[int(x) for x in name[4:].split(",")])
     if name == "census":
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import wire_census

@@ -43,10 +43,41 @@ class Params:
     ood: int = 2                # OOD samples per round
     nnz_per_row: float = 2.0    # nnz(A) = nnz(B) = nnz(C) = nnz_per_row * 2^log_m
     n_statement: int = 3        # LinearStatementEvaluations: ansA, ansB, ansC (mtUtilities.go:512)
+    # what a REAL params file fixes (Params.from_config: main.go:41-58); None = derived by the formulas above
+    cfg_queries: tuple = None   # Config.NumQueries per round + (Config.FinalQueries,)
+    cfg_ood: tuple = None       # Config.OODSamples per round
+    cfg_pow: tuple = None       # Config.PowBits per round
+    cfg_final_pow: int = None   # Config.FinalPowBits (mtUtilities.go:440)
+    cfg_final_folding_pow: int = 0   # Config.FinalFoldingPowBits (mt.go:160)
+    cfg_transcript_len: int = None   # Config.TranscriptLen (mt.go:337)
+
+    @staticmethod
+    def from_config(cfg: dict, nnz_total: int = None, batch: int = 1, **kw):
+        """the census of ONE concrete configuration: ProveKit's params file as main.go:41-58 reads it (a dict of its JSON), the number of
+        non-zeros of the R1CS matrices (r1cs.json: len(a.values) + len(b.values) + len(c.values), main.go:66-90) and the batch size"""
+        ff = cfg["folding_factor"]
+        p = Params(n_vars=cfg["n_vars"], log_m=cfg["log_num_constraints"], ff=4 if len(ff) == 1 else ff[0], rate=cfg["rate"], batch=batch,
+                   cfg_queries=tuple(cfg["num_queries"]) + (cfg["final_queries"],), cfg_ood=tuple(cfg["ood_samples"]), cfg_pow=tuple(cfg["pow_bits"]),
+                   cfg_final_pow=cfg.get("final_pow_bits", 0), cfg_final_folding_pow=cfg.get("final_folding_pow_bits", 0),
+                   cfg_transcript_len=cfg.get("transcript_len"), n_statement=len(cfg.get("statement_evaluations", [0, 0, 0])) or 3, **kw)
+        if nnz_total is not None:
+            p.nnz_per_row = nnz_total / (3.0 * (1 << p.log_m))
+        return p
 
     @property
-    def n_rounds(self):         # rounds of the loop mt.go:73: every variable is folded, final_sumcheck_rounds = n_vars % ff (mt.go:317,320)
+    def n_rounds(self):         # rounds of the loop mt.go:73 (= len(RoundParametersOODSamples)); derived: every variable is folded, final_sumcheck_rounds = n_vars % ff (mt.go:317,320)
+        if self.cfg_ood is not None:
+            return len(self.cfg_ood)
         return (self.n_vars - self.n_vars % self.ff) // self.ff - 1
+
+    def ood_at(self, r):
+        return self.cfg_ood[r] if self.cfg_ood is not None else self.ood
+
+    def pow_at(self, r):
+        """proof-of-work bits of round r (r = n_rounds: the final PoW, mtUtilities.go:440)"""
+        if self.cfg_pow is not None:
+            return self.cfg_final_pow if r >= len(self.cfg_pow) else self.cfg_pow[r]
+        return self.pow_bits
 
     @property
     def final_sumcheck_rounds(self):
@@ -56,6 +87,8 @@ class Params:
         """STIR queries of round r (r = n_rounds: the final queries).  The WHIR parameter formula (whir crate, WhirConfig::queries): the code's
         rate falls by ff - 1 bits per round; ConjectureList ceil(l / log_inv_rate), ProvableList ceil(2 l / log_inv_rate), UniqueDecoding
         ceil(-l / log2((1 + rho) / 2)), l = security - pow_bits."""
+        if self.cfg_queries is not None:
+            return self.cfg_queries[r]
         lir = self.rate + r * (self.ff - 1)
         lam = max(0, self.security - self.pow_bits)
         if self.soundness == "ConjectureList":
@@ -148,8 +181,8 @@ def census(p: Params, hash_cost="lo"):
         E.append(Entry(term, cite, unknown_calls=calls, bucket=bucket))
 
     # ---------------- witness inputs (no constraints): the circuit's secret / public fields
-    n_scalars_transcript = (4 * m) + 2 * Bt + (R + 1) * 3 * ff + R * (1 + p.ood) + (1 << p.final_sumcheck_rounds) + 3 * p.final_sumcheck_rounds
-    transcript_len = 32 * n_scalars_transcript + 8 * (R + 2)
+    n_scalars_transcript = (4 * m) + 2 * Bt + (R + 1) * 3 * ff + sum(1 + p.ood_at(r) for r in range(R)) + (1 << p.final_sumcheck_rounds) + 3 * p.final_sumcheck_rounds
+    transcript_len = p.cfg_transcript_len if p.cfg_transcript_len is not None else 32 * n_scalars_transcript + 8 * (R + 2)
     add("Transcript bytes (PUBLIC wires)", "mtUtilities.go:92; mt.go:337-343", 0, {"byte": transcript_len}, public=transcript_len)
     add("generator, statement values / evaluations, statement points", "mtUtilities.go:65,81-84; mt.go:328-356", 0, {"full": 1 + 2 * p.n_statement, "bit": n})
     first_leaves = Bt * leaves[0]
@@ -214,7 +247,7 @@ def census(p: Params, hash_cost="lo"):
 
     # ---------------- the round loop (mt.go:73-140)
     for r in range(R):
-        unknown(f"round {r}: root, OOD points / answers (Arthur)", "mt.go:76,81; mtUtilities.go:182-186", "arthur.scalar", 1 + 2 * p.ood)
+        unknown(f"round {r}: root, OOD points / answers (Arthur)", "mt.go:76,81; mtUtilities.go:182-186", "arthur.scalar", 1 + 2 * p.ood_at(r))
         stir(q[r], f"round {r}")
         if r == 0:
             for _ in range(Bt):
@@ -224,9 +257,9 @@ def census(p: Params, hash_cost="lo"):
             merkle(leaves[r], p.tree_height(r), f"round {r}")
             is_subset(q[r], leaves[r], f"round {r}")
         exponent(leaves[r], f"round {r}")
-        if p.pow_bits > 0:
+        if p.pow_at(r) > 0:
             pow_check(f"round {r}")
-        ncomb = p.ood + leaves[r]
+        ncomb = p.ood_at(r) + leaves[r]
         unknown(f"round {r}: combination randomness (Arthur)", "mtUtilities.go:225", "arthur.scalar", 1)
         add(f"round {r}: ExpandRandomness + shift DotProduct", "mt.go:122-127; utilities.go:168-176,210-216", 2 * (ncomb - 1), {"full": 2 * (ncomb - 1)}, a_cls="full", b_cls="full")
         sumcheck_rounds(ff, f"round {r}")
@@ -238,11 +271,13 @@ def census(p: Params, hash_cost="lo"):
     stir(q[R], "final")
     is_subset(q[R], leaves[R], "final")
     exponent(leaves[R], "final")
-    if p.pow_bits > 0:
+    if p.pow_at(R) > 0:
         pow_check("final")
     add("final: fold equalities", "mt.go:149-151", leaves[R], {})
     if p.final_sumcheck_rounds:
         sumcheck_rounds(p.final_sumcheck_rounds, "final")
+    if p.cfg_final_folding_pow > 0:
+        pow_check("final folding")
 
     # ---------------- ComputeWPoly (mtUtilities.go:289-326)
     def eq_outside(npts, nv, where):
@@ -252,7 +287,7 @@ def census(p: Params, hash_cost="lo"):
     nv = n
     for r in range(R):
         nv -= ff
-        eq_outside(p.ood + leaves[r], nv, f"round {r} points")
+        eq_outside(p.ood_at(r) + leaves[r], nv, f"round {r} points")
     # evaluateR1CSMatrixExtension: THE terms that make N (mtUtilities.go:494-532)
     for name, k, side in (("rows", m, "a"), ("columns", n, "b")):
         tot = (1 << (k + 1)) - 4                       # level 0 multiplies the constant 1: free; levels 1..k-1 make 2^(j+1) products each
@@ -381,11 +416,42 @@ def report():
     return "\n".join(L)
 
 
+def report_config(cfg, nnz_total, batch):
+    """the census of ONE configuration (a params file): the ledger's totals under the three bucket bounds, and the MI_DIST_MIX to bench with"""
+    L = []
+    p = Params.from_config(cfg, nnz_total=nnz_total, batch=batch)
+    L.append(f"params: n_vars {p.n_vars}, log_num_constraints {p.log_m}, folding factor {p.ff}, rate {p.rate}, rounds {p.n_rounds}, queries {list(p.cfg_queries)}, "
+             f"OOD samples {list(p.cfg_ood)}, PoW bits {list(p.cfg_pow)} + {p.cfg_final_pow}, batch {batch}, non-zeros of A + B + C {int(3 * p.nnz_per_row * (1 << p.log_m)):,}"
+             + ("" if nnz_total is not None else "  (ASSUMED: 2 a row and matrix -- pass --r1cs for the real count)"))
+    mixes = []
+    for hc in ("lo", "mid", "hi"):
+        E, _ = census(p, hc)
+        c, w, pub, calls, ab = totals(E, hc)
+        m_ = mix_of(w)
+        mixes.append(m_)
+        L.append(f"[{hc:>3}] constraints {c:>12,.0f} = 2^{math.log2(c):.2f} -> FFT domain 2^{math.ceil(math.log2(c))};  " + ", ".join(f"{k} {100 * m_[k]:.1f} %" for k in CLASSES) +
+                 f";  Compress calls {calls.get('skyscraper.Compress', 0):,.0f}")
+    mid = mixes[1]
+    L.append(f"bench it: python bench.py --log-n <the domain above> --dist mix:{round(1000 * mid['bit'])},{round(1000 * mid['byte'])},{round(1000 * mid['u64'])}   (MI_DIST_MIX per-mille of bits, bytes, 64-bit; the rest full-width)")
+    return "\n".join(L)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", default="")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--params", default="", help="ProveKit's params file (the JSON main.go:41-58 reads): the census of THAT configuration instead of the scenario grid")
+    ap.add_argument("--r1cs", default="", help="with --params: ProveKit's r1cs.json (main.go:82-90): the real number of non-zeros of A, B, C")
+    ap.add_argument("--batch", type=int, default=1, help="with --params: len(round0_merkle_paths) of the proof (mt.go:435)")
     a = ap.parse_args()
+    if a.params:
+        cfg = json.load(open(a.params))
+        nnz = None
+        if a.r1cs:
+            r = json.load(open(a.r1cs))
+            nnz = sum(len(r[k]["values"]) for k in ("a", "b", "c"))
+        print(report_config(cfg, nnz, a.batch))
+        sys.exit(0)
     if a.json:
         S, rng, mid, pm = census_range()
         print(json.dumps({"range": rng, "midpoint": mid, "permille": pm, "scenarios_kept": len(S)}))
