@@ -82,10 +82,17 @@ if os.path.exists(p):
         g1 = d["g1_msm_solo"]
         rows = [f"witness `whir`         (45 % {{0,1}} / 25 % bytes / 5 % 64-bit / 25 % uniform): value {d['value']:.2f} proofs/s, HBM-resident {d['value_hbm_resident_inputs']:.2f}, "
                 f"single proof {d['single_proof_latency_ms']:.2f} ms"]
-        for key in ("half_uniform", "uniform"):
+        for key in ("half_uniform", "uniform", "census"):
             x = sens[key]
             rows.append(f"witness `{key}`".ljust(22) + f": value {x['value']:.2f} proofs/s, HBM-resident {x['value_hbm_resident_inputs']:.2f}, single proof {x['single_proof_latency_ms']:.2f} ms, "
                         f"G1 level-1 additions per proof {x['g1_level1_additions_per_proof'] / 1e6:.1f} M")
         open("profiles/r06_scalar_mix.txt", "w").write("the `sensitivity` block of profiles/r06_bench_line_final.json (python bench.py, defaults: N = 2^23, three proofs in flight, the step = Commit + host-input prove "
-                                                        "with the PoK; same key, same box, same run; every proof compared with its leg's reference proof)\n" + "\n".join(rows) + "\n")
+                                                        "with the PoK; same key, same box, same run; every proof compared with its leg's reference proof)\n" + "\n".join(rows) + "\n" +
+                                                        "census = " + sens["census"].get("mix", "") + "\n")
         print("\n".join(rows))
+
+for m in ("census", "whir"):
+    src = G + f"r6_prof_{m}_summary.txt"
+    if os.path.exists(src):
+        open(f"profiles/r06_kernel_profile_{m}.txt", "w").write(f"rocprofv3 --kernel-trace over `python3 tools/prof_proof.py 23 8 x {m}`: kernel time per proof, ONE proof at a time on one context, inputs in HBM "
+                                                                 "(launch durations summed / 8; kernels of different streams overlap, so the column does not add up to the proof's latency)\n" + open(src).read())

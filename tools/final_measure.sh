@@ -5,6 +5,7 @@
 #   3: VALU instruction counts over proofs alone (tools/prof_proof.py)       4: N = 2^26 line with the CPU baseline (~2 min of oracle)
 #   5: the 2-rank rehearsal on one GPU (the witness-distribution sensitivity is part of the default line since round 5)
 #   6: PMC traffic of the SOLO Z-shaped level-1 launch (the basis of the roofline line) + its plain run
+#   7: per-proof kernel profiles (census mix, BASELINE mix)
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out
@@ -30,4 +31,12 @@ case "$1" in
     rm -rf $O/r6_prof_solo_z
     timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $O/r6_prof_solo_z -o s -- python3 tools/solo_z_msm.py 23 5 > $O/r6_prof_solo_z.log 2>&1
     tail -2 $O/r6_solo_z.log ;;
+7)  # kernel time per proof, one proof at a time, for the census mix and the BASELINE mix (tools/prof_proof.py's own summary)
+    for m in census whir; do
+      rm -rf $O/r6_prof_$m
+      timeout -k 10 300 rocprofv3 --kernel-trace -d $O/r6_prof_$m -o p -- python3 tools/prof_proof.py 23 8 x $m > $O/r6_prof_$m.log 2>&1
+      python3 tools/prof_proof.py --summary $(find $O/r6_prof_$m -name "*_results.db" | head -1) 8 > $O/r6_prof_${m}_summary.txt 2>&1
+      rm -rf $O/r6_prof_$m
+    done
+    head -4 $O/r6_prof_census_summary.txt ;;
 esac
