@@ -39,6 +39,7 @@ struct MsmKnobs {
     u32 g1_grid_per_cu = 0, g2_grid_per_cu = 0; // resident-grid cap per CU of the level-1 launches (0 = 128)
     u32 count_per = 0;                          // fixed-base sort: slices per counting workgroup (0 = 32)
     u32 plain_scatter = 0;                      // fixed-base sort: 1 = pass 2 by the plain scatter instead of the staged one
+    u32 dense_L1 = 1;                           // level-1 item size of a DENSE sort (>= half of the scalars' digits non-zero: a witness of mostly full-width values): 0 = automatic (32), 1 = off (the plan's L1), 4..64 = forced
     u32 flat_L1 = 0;                            // level-1 item size of a FLAT sort (fullest bucket <= 2 x the average: uniform scalars, prove's Z MSM): 0 = automatic
                                                 // (msm_accum_enqueue: the average / L2^k that falls into 17..32, so that the levels above are full L2-ary trees), 1 = off (L1), 4..64 = forced
     u32 z_count_fused = 1;                      // 1: prove's Z MSM takes its digit count from computeH's last launch (ctx->zhook) instead of a count pass of its own
@@ -849,17 +850,26 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     // entries per item a bucket leaves level 1 as 13 partial sums -- two items of level 2, then a third level.  An item size of average /
     // L2^k (26 there) makes the levels above full L2-ary trees: 8 partial sums, ONE item, no third level (same-process A/B: +0.4..0.6 % /
     // +0.7 %, 11 and 12 of 12 rounds).  The fullest bucket and the entry count are in host memory by now (the key scan stored them).
+    bool flat = false;
     if (kn->flat_L1 != 1 && pts && srt.max_key_count) {   // (a flat sort's own size wins over the plan's L1)
         const u64 entries = *(const u32 *)((const char *)srt.host_wsum + 128 * 256);
         const u64 avg = entries / (s.nkeys ? s.nkeys : 1);
         if (avg >= 64 && (u64)srt.max_key_count <= 2 * avg) {
-            if (kn->flat_L1 >= 4) L1 = kn->flat_L1;
+            if (kn->flat_L1 >= 4) { L1 = kn->flat_L1; flat = true; }
             else {
                 u64 t = avg;
                 while (t > 32) t = (t + L2 - 1) / L2;
-                if (t >= 17) L1 = (u32)t;
+                if (t >= 17) { L1 = (u32)t; flat = true; }   // (flat = the rule chose: a flat sort it has no size for falls through to the dense rule)
             }
         }
+    }
+    // A DENSE sort that is not flat (the wire values of a witness that is mostly full-width field elements -- what the reference's circuit
+    // implies, profiles/r06_wire_census.txt -- with its bytes and bits piled into a few buckets of window 0): >= half of the n * nwin digits are
+    // entries.  Items of 32 halve the partial sums the dearer upper levels add up; measured only where it pays (census mix: +0.7..1.0 %, 5 of
+    // 5 same-box rounds; BASELINE mix, ~0.3 of the digits: -0.5 %, so it keeps 16).  The count is the sort's own, per call.
+    if (!flat && !kn->L1 && kn->dense_L1 != 1 && pts && srt.max_key_count && srt.nwin_keys == 1) {
+        const u64 entries = *(const u32 *)((const char *)srt.host_wsum + 128 * 256);
+        if (entries >= ((u64)1 << 20) && 2 * entries >= (u64)n * srt.nwin_digits) L1 = kn->dense_L1 >= 4 ? kn->dense_L1 : 32;
     }
     // level-1 decomposition of every key (also: empty keys' buckets = infinity, finisher counters = 0) -- with the block sums of the item
     // scan whenever that scan's inline mode takes them (up to 2^19 keys): one launch less in front of every level-1 accumulation
@@ -1163,6 +1173,7 @@ int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value) {
     else if (is("plain_scatter") && (value == 0 || value == 1)) k->plain_scatter = (u32)value;
     else if (is("z_count_fused") && (value == 0 || value == 1)) k->z_count_fused = (u32)value;
     else if (is("flat_item_l1") && (value == 0 || value == 1 || (value >= 4 && value <= 64))) k->flat_L1 = (u32)value;
+    else if (is("dense_item_l1") && (value == 0 || value == 1 || (value >= 4 && value <= 64))) k->dense_L1 = (u32)value;
     else if (is("finisher") && (value == 0 || value == 1)) k->finisher = (u32)value;
     else if (is("finisher_max") && value >= 0 && value <= (1 << 20)) k->finisher_max = (u32)value;
     else if (is("item_l1") && (value == 0 || (value >= 2 && value <= 64))) k->L1 = (u32)value;     // entries per level-1 item (0 = 16)

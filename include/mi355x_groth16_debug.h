@@ -106,6 +106,9 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
  *   "flat_item_l1" 0 | 1 | 4..64   entries per level-1 item of a FLAT sort (fullest bucket <= 2 x the average: uniform scalars, e.g. the h
  *                            coefficients of a proof's Z MSM).  0 (default) = automatic: average / L2^k where that falls into 17..32 (26 at
  *                            N = 2^23), so that the levels above are full L2-ary trees; 1 = off (the plan's L1); 4..64 = forced
+ *   "dense_item_l1" 0 | 1 | 4..64   entries per level-1 item of a DENSE sort that is not flat (>= half of the n x windows digits non-zero: the wire
+ *                            values of a witness of mostly full-width field elements, what the reference's circuit implies).  1 = off (the
+ *                            plan's L1 = 16); 0 = automatic (32: half the partial sums for the upper levels); 4..64 = forced
  *   "finisher_max" 0..2^20   0 = automatic (G1 4096, G2 1024)
  *   "finisher_min_level" 0..16   the finisher follows accumulate pass number this + 1 at the earliest (default 2: the first two passes
  *                            are where every ordinary bucket ends; a finisher over 2^19 buckets of 13 partial sums each measured -5 %)
