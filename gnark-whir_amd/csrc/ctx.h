@@ -1,6 +1,7 @@
 // Library-internal context shared by the HIP translation units (not part of the C-ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -65,6 +66,7 @@ struct mi_ctx {
     // (msm2_sort_enqueue) then skips its own count pass: h is read once less.  Disarmed again as soon as the launch is enqueued.
     // Behind the knob "z_count_fused" (on by default: throughput equal, a single proof slightly shorter).
     // (only slot MI_ZHOOK_SLOT -- prove's Z MSM -- ever looks at it, and the thread that arms it is the one that enqueues that slot)
+    std::atomic<uint64_t> dense_item_sorts{0};   // accumulations whose item size the dense-sort rule chose (msm.hip; helper threads enqueue too)
     uint64_t z_count_fused_launches = 0;   // computeH last launches that carried the count (mi_debug_get_counter: the tests' proof that the path ran)
     struct ZCountHook { bool armed = false, done = false; int slot = -1; uint32_t n = 0, c = 0; alignas(8) unsigned char shape[64]; uint32_t *C1 = nullptr; const void *h = nullptr; /* the vector whose digits were counted */ } zhook;
     uint32_t hold_accum = 0;             // prove: 1 = the wire MSMs' bucket accumulations wait for computeH (mi_debug_set_prove_schedule; measured: no gain)

@@ -39,7 +39,7 @@ struct MsmKnobs {
     u32 g1_grid_per_cu = 0, g2_grid_per_cu = 0; // resident-grid cap per CU of the level-1 launches (0 = 128)
     u32 count_per = 0;                          // fixed-base sort: slices per counting workgroup (0 = 32)
     u32 plain_scatter = 0;                      // fixed-base sort: 1 = pass 2 by the plain scatter instead of the staged one
-    u32 dense_L1 = 1;                           // level-1 item size of a DENSE sort (>= half of the scalars' digits non-zero: a witness of mostly full-width values): 0 = automatic (32), 1 = off (the plan's L1), 4..64 = forced
+    u32 dense_L1 = 0;                           // level-1 item size of a DENSE sort (>= half of the scalars' digits non-zero: a witness of mostly full-width values): 0 = automatic (32), 1 = off (the plan's L1), 4..64 = forced
     u32 flat_L1 = 0;                            // level-1 item size of a FLAT sort (fullest bucket <= 2 x the average: uniform scalars, prove's Z MSM): 0 = automatic
                                                 // (msm_accum_enqueue: the average / L2^k that falls into 17..32, so that the levels above are full L2-ary trees), 1 = off (L1), 4..64 = forced
     u32 z_count_fused = 1;                      // 1: prove's Z MSM takes its digit count from computeH's last launch (ctx->zhook) instead of a count pass of its own
@@ -447,6 +447,7 @@ static std::atomic<int> g_stream_plan{1};
 extern "C" int32_t mi_debug_get_counter(mi_ctx *ctx, const char *name, uint64_t *out) {
     if (!ctx || !name || !out) return MI_EINVAL;
     if (!std::strcmp(name, "z_count_fused_launches")) { *out = ctx->z_count_fused_launches; return MI_OK; }
+    if (!std::strcmp(name, "dense_item_sorts")) { *out = ctx->dense_item_sorts.load(); return MI_OK; }
     MI_FAIL(ctx, MI_EINVAL, std::string("unknown counter: ") + name);
 }
 extern "C" int32_t mi_debug_set_stream_plan(int32_t plan) {
@@ -865,11 +866,11 @@ static int32_t msm_accum_enqueue(mi_ctx *ctx, const MsmCurveOps &ops, MsmSlot &s
     }
     // A DENSE sort that is not flat (the wire values of a witness that is mostly full-width field elements -- what the reference's circuit
     // implies, profiles/r06_wire_census.txt -- with its bytes and bits piled into a few buckets of window 0): >= half of the n * nwin digits are
-    // entries.  Items of 32 halve the partial sums the dearer upper levels add up; measured only where it pays (census mix: +0.7..1.0 %, 5 of
-    // 5 same-box rounds; BASELINE mix, ~0.3 of the digits: -0.5 %, so it keeps 16).  The count is the sort's own, per call.
+    // entries.  Items of 32 halve the partial sums the dearer upper levels add up; it triggers only where it pays (same-process A/B of the rule: census mix +0.6 % / +1.5 %, uniform +0.2 % / +0.8 %,
+    // 13 of 14 rounds; BASELINE mix, ~0.3 of the digits non-zero: items of 32 measured -0.5 % in r5, the rule leaves it at 16).  The count is the sort's own, per call.
     if (!flat && !kn->L1 && kn->dense_L1 != 1 && pts && srt.max_key_count && srt.nwin_keys == 1) {
         const u64 entries = *(const u32 *)((const char *)srt.host_wsum + 128 * 256);
-        if (entries >= ((u64)1 << 20) && 2 * entries >= (u64)n * srt.nwin_digits) L1 = kn->dense_L1 >= 4 ? kn->dense_L1 : 32;
+        if (entries >= ((u64)1 << 20) && 2 * entries >= (u64)n * srt.nwin_digits) { L1 = kn->dense_L1 >= 4 ? kn->dense_L1 : 32; ctx->dense_item_sorts++; }
     }
     // level-1 decomposition of every key (also: empty keys' buckets = infinity, finisher counters = 0) -- with the block sums of the item
     // scan whenever that scan's inline mode takes them (up to 2^19 keys): one launch less in front of every level-1 accumulation

@@ -107,8 +107,8 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
  *                            coefficients of a proof's Z MSM).  0 (default) = automatic: average / L2^k where that falls into 17..32 (26 at
  *                            N = 2^23), so that the levels above are full L2-ary trees; 1 = off (the plan's L1); 4..64 = forced
  *   "dense_item_l1" 0 | 1 | 4..64   entries per level-1 item of a DENSE sort that is not flat (>= half of the n x windows digits non-zero: the wire
- *                            values of a witness of mostly full-width field elements, what the reference's circuit implies).  1 = off (the
- *                            plan's L1 = 16); 0 = automatic (32: half the partial sums for the upper levels); 4..64 = forced
+ *                            values of a witness of mostly full-width field elements, what the reference's circuit implies).  0 (default) = automatic
+ *                            (32: half the partial sums for the upper levels); 1 = off (the plan's L1 = 16); 4..64 = forced
  *   "finisher_max" 0..2^20   0 = automatic (G1 4096, G2 1024)
  *   "finisher_min_level" 0..16   the finisher follows accumulate pass number this + 1 at the earliest (default 2: the first two passes
  *                            are where every ordinary bucket ends; a finisher over 2^19 buckets of 13 partial sums each measured -5 %)
@@ -117,7 +117,8 @@ int32_t mi_debug_set_msm_precompute_batched(mi_ctx *ctx, uint32_t on);
  *   "ntt_lds_floor_kb" 0..160   LDS every NTT pass workgroup requests at least (caps the workgroups per CU) */
 int32_t mi_debug_set_knob(mi_ctx *ctx, const char *name, int64_t value);
 /* Counters the tests read to prove that an optional path really ran: "z_count_fused_launches" = computeH last launches of this context that
- * carried the Z MSM's digit count (knob "z_count_fused").  MI_EINVAL for an unknown name. */
+ * carried the Z MSM's digit count (knob "z_count_fused"); "dense_item_sorts" = bucket accumulations whose level-1 item size the dense-sort rule
+ * chose (knob "dense_item_l1").  MI_EINVAL for an unknown name. */
 int32_t mi_debug_get_counter(mi_ctx *ctx, const char *name, uint64_t *out);
 /* Process-wide, for contexts created afterwards: how the MSM slots of a context share streams (0: K's stream created, destroyed and
  * pointed at B1's, as rounds 4-5 did; 1, the default: never created; 2: A, B1 and K on one stream).  Same results; an experiment on which

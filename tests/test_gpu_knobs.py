@@ -21,7 +21,7 @@ def ctx():
 
 def _reset(ctx):
     for k, v in (("l1_wg", 4), ("g2_wg", 1), ("l1_waves", 3), ("z_waves", 0), ("finisher", 1), ("finisher_max", 0), ("plain_scatter", 0), ("count_per", 0),
-                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2), ("z_count_fused", 1), ("flat_item_l1", 0)):
+                 ("g1_grid_per_cu", 0), ("g2_grid_per_cu", 0), ("finisher_min_level", 2), ("z_count_fused", 1), ("flat_item_l1", 0), ("dense_item_l1", 0)):
         ctx.set_knob(k, v)
     assert ctx.lib.mi_debug_set_msm_limb29(ctx.h, 1) == 0 and ctx.lib.mi_debug_set_msm_plan(ctx.h, 0, 0, 0, 0, 0) == 0
 
@@ -217,6 +217,41 @@ def test_flat_sort_item_size_agrees_with_oracle(ctx):
             got, _ = ctx.prove(pkh, W, a, b, c, r, s)
             assert B.proof_write(got["raw"]) == want, flat
             assert np.array_equal(ctx.msm_g1(pts, sc), want_msm), flat
+        ctx.pk_free(pkh)
+    finally:
+        _reset(ctx)
+        assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 0, 0, 0) == 0
+
+
+def test_dense_sort_item_size_agrees_with_oracle(ctx):
+    """the DENSE-sort rule (r6: a sort that is not flat in which >= half of the n x windows digits are entries sums level-1 items of 32): a proof
+    whose wire values follow the census mix (74 % full-width: the rule triggers for A + K and B), through fixed-base tables -- automatic, off and
+    forced sizes give the oracle's 164 bytes; a BASELINE-mix witness beside it (the rule must not trigger: ~0.3 of the digits) as well"""
+    B = load_binding()
+    log_n = 20
+    N = 1 << log_n
+    nw, nc = N - 37, N - 5
+    pk = synthetic_pk(log_n, nw, 40, 7900)
+    dist = B.dist_mix(23, 237, 0)
+    cases = []
+    for d in (dist, 1):
+        W = cref.gen_scalars(nw, 11, d); a = cref.gen_scalars(nc, 12, d); b = cref.gen_scalars(nc, 13, 0); c = cref.field_op(0, 2, a, b)
+        r, s = cref.gen_scalars(2, 14, 0)
+        cases.append((W, a, b, c, r, s, cref.proof_write(cref.prove(pk, W, a, b, c, r, s)["raw"])))
+    try:
+        assert ctx.lib.mi_debug_set_prove_fixed_base(ctx.h, 19, 17, 20) == 0
+        pkh = ctx.pk_load(pk)
+        hits = {}
+        for dense in (0, 1, 24, 48, 0):
+            ctx.set_knob("dense_item_l1", dense)
+            for k, (W, a, b, c, r, s, want) in enumerate(cases):
+                before = ctx.counter("dense_item_sorts")
+                got, st = ctx.prove(pkh, W, a, b, c, r, s)
+                assert B.proof_write(got["raw"]) == want, (dense, k)
+                hits[(dense, k)] = ctx.counter("dense_item_sorts") - before
+        # census witness: A, K (one sort, two accumulations), B1, B2 take the rule's size, Z is a flat sort with its own; BASELINE mix: nobody
+        assert hits[(0, 0)] == 4 and hits[(24, 0)] == 4 and hits[(1, 0)] == 0, hits
+        assert all(hits[(d, 1)] == 0 for d in (0, 1, 24, 48)), hits
         ctx.pk_free(pkh)
     finally:
         _reset(ctx)

@@ -28,7 +28,7 @@ def parse(cfg):
 
 
 DEFAULTS = {"l1_wg": 4, "g2_wg": 1, "l1_waves": 3, "z_waves": 0, "g1_grid_per_cu": 0, "g2_grid_per_cu": 0, "count_per": 0, "plain_scatter": 0,
-            "finisher": 1, "finisher_max": 0, "finisher_min_level": 2, "hold_accum": 0, "item_l1": 0, "item_l2": 0, "reduce_seg": 0, "ntt_lds_floor_kb": 0, "z_count_fused": 1, "flat_item_l1": 0, "dense_item_l1": 1}
+            "finisher": 1, "finisher_max": 0, "finisher_min_level": 2, "hold_accum": 0, "item_l1": 0, "item_l2": 0, "reduce_seg": 0, "ntt_lds_floor_kb": 0, "z_count_fused": 1, "flat_item_l1": 0, "dense_item_l1": 0}
 
 
 def main():
