@@ -11,7 +11,8 @@
 //   U2 = ZZ x2  < 1.04      S2 = ZZZ y2 < 1.04      P = U2 + 4p - X  < 5.1      R = S2 + 4p - Y  < 5.1
 //   PP = P^2: (2 * 5.1)(5.1 + 8) / 128 + 1 = 2.05, 5.1 * 10.2 / 128 + 1 = 1.41      RR = R^2: the same
 //   PPP = P PP   < 1.25     Q = X PP   < 1.11      T = PPP + 2Q  < 3.5      X3 = RR + 4p - T  < 6.1  -> conditional -4p, -2p: < 2.1
-//   D = Q + 4p - X3  < 5.3     M1 = R D  < 1.54     M2 = Y PPP  < 1.1     Y3 = M1 + 2p - M2  < 3.6
+//   D = Q + 4p - X3  < 5.3     Y3 = (R D - Y PPP) / R' as ONE reduction per component (f2_29_mul_sub): (5.1 * 5.3 + 5.1 * 8 + 3.6 * 2 + 3.6 * 1.25) / 128 + 1 < 1.7
+//   (r6; before: M1 = R D, M2 = Y PPP, Y3 = M1 + 2p - M2 < 3.6 -- the accumulator's Y bound stays the looser 3.6 below)
 //   ZZ3 = ZZ PP < 1.05      ZZZ3 = ZZZ PPP < 1.03
 #pragma once
 #include "curve.cuh"
@@ -36,6 +37,14 @@ MI_HD F2_29 f2_29_mul(const F2_29 &x, const F2_29 &y, const u32 (&ck)[9]) {
 MI_HD F2_29 f2_29_sqr(const F2_29 &x) {
     const F29 s = f29_wnorm(f29_add(x.a0, x.a1)), d = f29_wnorm(f29_sub<P_>(x.a0, x.a1, P29<P_>::c8));
     return F2_29{f29_mul<P_>(s, d), f29_mul<P_>(x.a0, f29_add(x.a1, x.a1))};
+}
+// x * y - z * w with ONE reduction per component (f29_mul4): a0 = x0 y0 + x1 (Ky p - y1) + z0 (Kw p - w0) + z1 w1,
+// a1 = x0 y1 + x1 y0 + z0 (Kw p - w1) + z1 (Kw p - w0).  cy = Ky p, cw = Kw p (borrowed) must exceed V(y), V(w); every operand weakly
+// normalised.  810 multiplications against the 972 of two products and a subtraction; the result is normalised.
+MI_HD F2_29 f2_29_mul_sub(const F2_29 &x, const F2_29 &y, const u32 (&cy)[9], const F2_29 &z, const F2_29 &w, const u32 (&cw)[9]) {
+    const F29 ny1 = f29_wnorm(f29_sub<P_>(f29_zero(), y.a1, cy));
+    const F29 nw0 = f29_wnorm(f29_sub<P_>(f29_zero(), w.a0, cw)), nw1 = f29_wnorm(f29_sub<P_>(f29_zero(), w.a1, cw));
+    return F2_29{f29_mul4<P_>(x.a0, y.a0, x.a1, ny1, z.a0, nw0, z.a1, w.a1), f29_mul4<P_>(x.a0, y.a1, x.a1, y.a0, z.a0, nw1, z.a1, nw0)};
 }
 // an "almost < 2p" representative of a value < 6.1 p
 MI_HD F29 f29_below_2p(const F29 &x) { return f29_wnorm(f29_condsub(f29_wnorm(f29_condsub(x, P29<P_>::p4)), P29<P_>::p2)); }
@@ -110,9 +119,7 @@ MI_HD void g2x29_madd(Acc &A, bool &inf, const u32 *q, bool negate) {
     X3.a0 = f29_below_2p(X3.a0); X3.a1 = f29_below_2p(X3.a1);
     A.st(0, X3);
     const F2_29 D = f2_29_sub(Q, X3, P29<P_>::c4);
-    const F2_29 M1 = f2_29_mul(R, D, P29<P_>::c8);
-    const F2_29 M2 = f2_29_mul(Y, PPP, P29<P_>::c2);
-    A.st(1, f2_29_sub(M1, M2, P29<P_>::c2));
+    A.st(1, f2_29_mul_sub(R, D, P29<P_>::c8, Y, PPP, P29<P_>::c2));   // Y3 = R D - Y PPP: one reduction per component
 }
 
 // ---- partial sums in the packed R' form (the G2 twin of g1x29_store_rp / g1x29_load_rp / g1x29_add in curve29.cuh)
@@ -123,7 +130,7 @@ MI_HD void f2_29_pack(const F2_29 &x, u32 *w) { f29_pack(f29_norm(x.a0), w); f29
 // Bounds: both operands X < 2.1, Y < 3.6, ZZ, ZZZ < 1.1 (what g2x29_madd and this function leave behind)
 //   U1 = Xa ZZb, U2 = Xb ZZa, S1 = Ya ZZZb, S2 = Yb ZZZa < 1.1      P = U2 + 2p - U1, R = S2 + 2p - S1 < 3.1
 //   PP = P^2 < 1.6 / 1.2     PPP = P PP < 1.1     Q = U1 PP < 1.1     T = PPP + 2Q < 3.3     X3 = R^2 + 4p - T < 5.6 -> below 2p: < 2.1
-//   D = Q + 4p - X3 < 5.1    M1 = R D < 1.4       M2 = S1 PPP < 1.1   Y3 = M1 + 2p - M2 < 3.4
+//   D = Q + 4p - X3 < 5.1    Y3 = (R D - S1 PPP) / R', one reduction per component: (3.1 * 5.1 + 3.1 * 8 + 1.1 * 2 + 1.1 * 1.1) / 128 + 1 < 1.4
 //   ZZ3 = (ZZa ZZb) PP < 1.1     ZZZ3 = (ZZZa ZZZb) PPP < 1.1
 template <class Acc, class LoadB>
 MI_HD void g2x29_add(Acc &A, bool &inf, const LoadB &ldb, bool b_inf) {
@@ -158,7 +165,5 @@ MI_HD void g2x29_add(Acc &A, bool &inf, const LoadB &ldb, bool b_inf) {
     X3.a0 = f29_below_2p(X3.a0); X3.a1 = f29_below_2p(X3.a1);
     A.st(0, X3);
     const F2_29 D = f2_29_sub(Q, X3, P29<P_>::c4);
-    const F2_29 M1 = f2_29_mul(R, D, P29<P_>::c8);
-    const F2_29 M2 = f2_29_mul(S1, PPP, P29<P_>::c2);
-    A.st(1, f2_29_sub(M1, M2, P29<P_>::c2));
+    A.st(1, f2_29_mul_sub(R, D, P29<P_>::c8, S1, PPP, P29<P_>::c2));   // Y3 = R D - S1 PPP
 }

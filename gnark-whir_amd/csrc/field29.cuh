@@ -13,6 +13,7 @@
 //   value bound V(x): the number represented is < V * p
 //   f29_mul(x, y)        needs L(x) + L(y) <= 60; returns a normalised value < (V(x) V(y) / 128 + 1) p
 //   f29_mul2(a,b,c,d)    (ab + cd) / R' with ONE reduction; needs L + L <= 59 per pair; value < ((VaVb + VcVd) / 128 + 1) p
+//   f29_mul4(a,..,h)     (ab + cd + ef + gh) / R' with ONE reduction; every operand weakly normalised; value < (sum of VV / 128 + 1) p
 //   f29_add              limb-wise; L grows by one bit
 //   f29_sub<K>(x, y)     x + K p - y, K p in borrowed form (limbs 0..7 in [2^30 - 2, 2^30 + 2^29)); needs y weak and V(y) < K;
 //                        result limbs < 2^31
@@ -159,6 +160,39 @@ MI_HD F29 f29_mul2(const F29 &a, const F29 &b, const F29 &c, const F29 &d) {
     for (int k = 9; k < 17; k++) {
 #pragma unroll
         for (int i = k - 8; i < 9; i++) { f29_mac(acc, a.l[i], b.l[k - i]); f29_mac(acc, c.l[i], d.l[k - i]); }
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
+        r.l[k - 9] = (u32)acc & M;
+        acc >>= 29;
+    }
+    F29_ASSERT(acc < ((u64)1 << 29));
+    r.l[8] = (u32)acc;
+    return r;
+}
+// (a*b + c*d + e*f + g*h) / 2^261 mod p with ONE reduction: 405 multiplications instead of 2 x 243 -- the two dual products of an Fp2
+// "product minus product" (curve29_g2.cuh: Y3 = R D - Y PPP) share a reduction.  A column holds up to 36 products and 9 reduction terms:
+// 45 x (2^29 + 8)^2 + the carried 2^35 < 2^63.5, so every operand must be weakly normalised (limbs < 2^29 + 8; L + L <= 58 per pair);
+// value < ((VaVb + VcVd + VeVf + VgVh) / 128 + 1) p, normalised.
+template <class P>
+MI_HD F29 f29_mul4(const F29 &a, const F29 &b, const F29 &c, const F29 &d, const F29 &e, const F29 &f, const F29 &g, const F29 &h) {
+    constexpr u32 M = (1u << 29) - 1;
+    u32 m[9];
+    F29 r;
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { f29_mac(acc, a.l[i], b.l[k - i]); f29_mac(acc, c.l[i], d.l[k - i]); f29_mac(acc, e.l[i], f.l[k - i]); f29_mac(acc, g.l[i], h.l[k - i]); }
+#pragma unroll
+        for (int i = 0; i < k; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
+        m[k] = ((u32)acc * P29<P>::inv) & M;
+        f29_mac_k(acc, m[k], P29<P>::p[0]);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) { f29_mac(acc, a.l[i], b.l[k - i]); f29_mac(acc, c.l[i], d.l[k - i]); f29_mac(acc, e.l[i], f.l[k - i]); f29_mac(acc, g.l[i], h.l[k - i]); }
 #pragma unroll
         for (int i = k - 8; i < 9; i++) f29_mac_k(acc, m[i], P29<P>::p[k - i]);
         r.l[k - 9] = (u32)acc & M;
