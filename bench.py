@@ -500,12 +500,16 @@ def main():
     mad_probe = None
     if rank == 0 and not args.no_clock_samples and not args.no_solo_legs:
         thr, it = 256 * 4 * 8 * 64, 20000
-        ctx.bench_valu(0, thr, 256)
-        smp = ClockSampler(local_rank).start()
-        t_end, rates = time.perf_counter() + 0.7, []
-        while time.perf_counter() < t_end:
-            rates.append((thr / 64) * 8 * it / (ctx.bench_valu(0, thr, it) * 1e-3) / 1024.0)
-        ck = smp.stop()
+        ck, rates = None, []
+        try:   # (a probe: whatever goes wrong here must cost the line its `valu_frac`, not the line)
+            ctx.bench_valu(0, thr, 256)
+            smp = ClockSampler(local_rank).start()
+            t_end = time.perf_counter() + 0.7
+            while time.perf_counter() < t_end:
+                rates.append((thr / 64) * 8 * it / (ctx.bench_valu(0, thr, it) * 1e-3) / 1024.0)
+            ck = smp.stop()
+        except B.MiError:
+            ck = None
         if ck and rates:
             rate = max(rates)
             mad_probe = {"wave_instr_per_s_per_simd": rate, "sclk_mhz": ck["sclk_mhz_mean"], "cycles_per_mad": ck["sclk_mhz_mean"] * 1e6 / rate,
